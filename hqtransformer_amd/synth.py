@@ -1,0 +1,87 @@
+"""Deterministic synthetic weights, text prompts and sampler noise.
+
+No checkpoint or dataset is reachable offline and the reference's own throughput harness runs on
+random-init weights (``measure_throughput/__main__.py:25-31`` never loads a checkpoint), so every
+tensor is derived from ``numpy.random.default_rng`` keyed by (seed, state-dict name).  The fixture
+generator (tools/gen_golden.py) loads the same tensors into the reference, so both sides regenerate
+identical weights and nothing but inputs/outputs is stored under tests/golden/.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .spec import Stage1Spec, Stage2Spec, stage1_param_shapes, stage2_param_shapes
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def _stage2_tensor(name: str, shape: Tuple[int, ...], seed: int, profile: str) -> np.ndarray:
+    r = _rng(seed, name)
+    rich = profile == 'fixture'
+    leaf = name.split('.')[-1]
+    is_ln = ('.ln' in name or name.startswith('ln_')) and len(shape) == 1
+    if is_ln:
+        if leaf == 'weight':
+            return (1.0 + (0.2 * r.standard_normal(shape) if rich else 0.0) * np.ones(shape)).astype(np.float32)
+        return ((0.1 * r.standard_normal(shape)) if rich else np.zeros(shape)).astype(np.float32)
+    if leaf == 'bias':
+        return ((0.05 * r.standard_normal(shape)) if rich else np.zeros(shape)).astype(np.float32)
+    if name in ('sos_depth', 'sos'):                       # nn.Parameter(torch.randn) hierarchical_ar.py:77,156
+        return r.standard_normal(shape).astype(np.float32)
+    if rich:
+        if name.startswith('head_'):
+            std = 3.0 / np.sqrt(shape[1])                  # logits with std ~3 so top-k/top-p actually cut
+        elif '.attn.' in name or '.mlp.' in name:
+            std = 1.0 / np.sqrt(shape[1])
+        else:
+            std = 0.5                                      # embeddings
+    else:
+        std = 0.02                                         # hierarchical_ar.py:218-225
+    return (std * r.standard_normal(shape)).astype(np.float32)
+
+
+def _stage1_tensor(name: str, shape: Tuple[int, ...], seed: int, profile: str) -> np.ndarray:
+    r = _rng(seed, name)
+    rich = profile == 'fixture'
+    leaf = name.split('.')[-1]
+    if leaf == 'embedding':                                # quantizer.py:76 randn
+        return r.standard_normal(shape).astype(np.float32)
+    if '.norm' in name and len(shape) == 1:
+        if leaf == 'weight':
+            return (1.0 + (0.2 * r.standard_normal(shape) if rich else 0.0) * np.ones(shape)).astype(np.float32)
+        return ((0.1 * r.standard_normal(shape)) if rich else np.zeros(shape)).astype(np.float32)
+    if leaf == 'bias':
+        return (0.05 * r.standard_normal(shape)).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    return (r.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+
+
+def stage2_weights(spec: Stage2Spec, seed: int = 0, profile: str = 'bench') -> 'OrderedDict[str, np.ndarray]':
+    return OrderedDict((n, _stage2_tensor(n, s, seed, profile)) for n, s in stage2_param_shapes(spec).items())
+
+
+def stage1_weights(spec: Stage1Spec, seed: int = 0, profile: str = 'bench') -> 'OrderedDict[str, np.ndarray]':
+    return OrderedDict((n, _stage1_tensor(n, s, seed, profile)) for n, s in stage1_param_shapes(spec).items())
+
+
+def exp_noise(seed: int, n_steps: int, batch: int, vocab: int) -> np.ndarray:
+    """Exp(1) noise ``q`` for every multinomial draw: ``[n_steps, 5, batch, vocab]`` fp32, draw order
+    per position top, bot0..bot3 (``hierarchical_ar.py:762-785``).  ``torch.multinomial(p, 1)`` is
+    ``argmax(p / q)``; the noise is an explicit input so runs are reproducible
+    on any device."""
+    q = np.random.default_rng([seed, 0x9e3779b9]).standard_exponential((n_steps, 5, batch, vocab), dtype=np.float32)
+    return np.maximum(q, np.float32(1e-30))
+
+
+def class_ids(seed: int, n: int, n_classes: int = 1000) -> np.ndarray:
+    return np.random.default_rng([seed, 1]).integers(0, n_classes, size=n, dtype=np.int64)
+
+
+def text_ids(seed: int, batch: int, ctx: int, vocab: int) -> np.ndarray:
+    return np.random.default_rng([seed, 2]).integers(0, vocab, size=(batch, ctx), dtype=np.int64)

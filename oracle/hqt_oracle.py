@@ -1,0 +1,331 @@
+"""CPU oracle for the HQ-Transformer sampling path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A numpy (fp32) restatement of what the reference computes on its CPU path, where autocast is off and
+every activation is fp32.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this module; nothing under ``hqtransformer_amd/`` does,
+and the product path raises when its HIP library is missing instead of falling back to this.
+
+Parity pin: the reference ships no tests or golden vectors, so this oracle is pinned
+against outputs of the reference itself, generated in the build container by ``tools/gen_golden.py``
+(which imports ``/root/reference``) and committed under ``tests/golden/`` --
+``tests/test_oracle_golden.py`` checks every fixture.
+
+Each function cites the reference lines it restates (paths relative to the reference root).
+Third-party arithmetic the reference relies on is PyTorch's (torch==1.10.0, requirements.txt:11):
+Linear, LayerNorm, GELU(erf), softmax, topk, sort, cumsum, multinomial, Conv2d, GroupNorm, nearest
+interpolate, PixelShuffle, embedding -- restated here from their published definitions.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+from scipy.special import erf
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------- primitives
+def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+    """nn.Linear: y = x W^T + b, W stored [out, in]."""
+    y = x.astype(F32, copy=False) @ w.T
+    if b is not None:
+        y = y + b
+    return y.astype(F32, copy=False)
+
+
+def layer_norm(x: np.ndarray, g: np.ndarray, b: np.ndarray, eps: float = 1e-5) -> np.ndarray:
+    """nn.LayerNorm over the last axis, eps 1e-5 (stage2/layers.py:302-303, hierarchical_ar.py:144,205,208)."""
+    x64 = x.astype(np.float64)
+    mu = x64.mean(-1, keepdims=True)
+    var = ((x64 - mu) ** 2).mean(-1, keepdims=True)
+    return (((x64 - mu) / np.sqrt(var + eps)).astype(F32) * g + b).astype(F32)
+
+
+def gelu(x: np.ndarray, approx: bool) -> np.ndarray:
+    """stage2/layers.py:14-23: exact erf GELU, or x*sigmoid(1.702x) when gelu_use_approx."""
+    if approx:
+        return (x / (1.0 + np.exp(-1.702 * x))).astype(F32)
+    return (x * 0.5 * (1.0 + erf(x / np.sqrt(F32(2.0))))).astype(F32)
+
+
+def softmax(x: np.ndarray) -> np.ndarray:
+    m = x.max(-1, keepdims=True)
+    e = np.exp(x - m)
+    return (e / e.sum(-1, keepdims=True)).astype(F32)
+
+
+# ----------------------------------------------------------------------------- sampler (A7)
+def cutoff_topk_logits(logits: np.ndarray, k: Optional[int]) -> np.ndarray:
+    """hqvae/utils/sampling.py:12-19 -- keep logits >= k-th largest (ties kept), others -> -inf."""
+    if k is None:
+        return logits
+    kth = np.partition(logits, logits.shape[-1] - int(k), axis=-1)[..., logits.shape[-1] - int(k)][..., None]
+    out = logits.copy()
+    out[out < kth] = -np.inf
+    return out
+
+
+def cutoff_topp_probs(probs: np.ndarray, p: Optional[float]) -> np.ndarray:
+    """hqvae/utils/sampling.py:22-37 -- sort desc, running sum, drop where cum >= p shifted right by one
+    (first crossing token kept, head always kept), scatter back, renormalise.  torch.cumsum on the CPU
+    accumulates an fp32 row in a double and rounds every prefix to fp32 (acc_type<float> is double on
+    CPU; checked against torch 2.10 here: bit-identical on 64x8192 rows), which is what decides the
+    ``cum >= p`` cut at p = 1.0."""
+    if p is None:
+        return probs
+    order = np.argsort(-probs, axis=-1, kind='stable')
+    sp = np.take_along_axis(probs, order, axis=-1)
+    cum = np.cumsum(sp.astype(np.float64), axis=-1).astype(F32)
+    remove_sorted = cum >= F32(p)
+    remove_sorted[..., 1:] = remove_sorted[..., :-1].copy()
+    remove_sorted[..., 0] = False
+    remove = np.zeros_like(remove_sorted)
+    np.put_along_axis(remove, order, remove_sorted, axis=-1)
+    out = np.where(remove, F32(0.0), probs)
+    return (out / out.sum(-1, keepdims=True)).astype(F32)
+
+
+def sample_filtered(logits: np.ndarray, q: np.ndarray, temperature: float, top_k: Optional[int],
+                    top_p: Optional[float]) -> Tuple[np.ndarray, np.ndarray]:
+    """hierarchical_ar.py:762-769 / 778-784: logits /= T; top-k; softmax; top-p; multinomial.
+    ``torch.multinomial(p, 1)`` draws ``argmax(p / q)`` with q ~ Exp(1); q is an
+    explicit input here.  Returns (index [R], probs [R, V])."""
+    lg = (logits / F32(temperature)).astype(F32)
+    lg = cutoff_topk_logits(lg, top_k)
+    pr = softmax(lg)
+    pr = cutoff_topp_probs(pr, top_p)
+    idx = np.argmax(pr / q, axis=-1).astype(np.int64)
+    return idx, pr
+
+
+# ----------------------------------------------------------------------------- stage 2 (A1-A6, A14)
+class OracleStage2:
+    """iHQGPT 'parallel' sampling (hierarchical_ar.py:428-563, 667-789; sampling.py:164-237)."""
+
+    def __init__(self, spec, weights: Dict[str, np.ndarray]):
+        self.s = spec
+        self.w = {k: np.ascontiguousarray(v, dtype=F32) for k, v in weights.items()}
+
+    # one transformer block on T new tokens, appending K/V to the cache (stage2/layers.py:61-195,324-328,371-375)
+    def _block(self, prefix: str, x: np.ndarray, cache: Dict[str, np.ndarray], causal_new: bool) -> np.ndarray:
+        w, s = self.w, self.s
+        B, T, D = x.shape
+        nh, hs = s.n_heads, s.head_dim
+        h = layer_norm(x, w[f'{prefix}.ln1.weight'], w[f'{prefix}.ln1.bias'])
+        q = linear(h, w[f'{prefix}.attn.query.weight'], w[f'{prefix}.attn.query.bias'])
+        k = linear(h, w[f'{prefix}.attn.key.weight'], w[f'{prefix}.attn.key.bias'])
+        v = linear(h, w[f'{prefix}.attn.value.weight'], w[f'{prefix}.attn.value.bias'])
+        split = lambda t: t.reshape(B, T, nh, hs).transpose(0, 2, 1, 3)          # [B, nh, T, hs]
+        q, k, v = split(q), split(k), split(v)
+        if prefix in cache:
+            pk, pv = cache[prefix]
+            k = np.concatenate([pk, k], axis=2)
+            v = np.concatenate([pv, v], axis=2)
+        cache[prefix] = (k, v)
+        t_past = k.shape[2] - T
+        att = q @ (k.transpose(0, 1, 3, 2) * F32(1.0 / np.sqrt(hs)))                # scale on K (layers.py:102)
+        if causal_new and T > 1:                                                    # layers.py:107-111,118-123
+            mask = np.concatenate([np.ones((T, t_past), bool), np.tril(np.ones((T, T), bool))], axis=1)
+            att = np.where(mask[None, None], att, F32(-np.inf))
+        att = softmax(att.astype(F32))
+        y = (att @ v).transpose(0, 2, 1, 3).reshape(B, T, D)
+        x = x + linear(y, w[f'{prefix}.attn.proj.weight'], w[f'{prefix}.attn.proj.bias'])
+        h = layer_norm(x, w[f'{prefix}.ln2.weight'], w[f'{prefix}.ln2.bias'])
+        h = gelu(linear(h, w[f'{prefix}.mlp.0.weight'], w[f'{prefix}.mlp.0.bias']), s.gelu_approx)
+        return (x + linear(h, w[f'{prefix}.mlp.2.weight'], w[f'{prefix}.mlp.2.bias'])).astype(F32)
+
+    def _embed(self, code_t: np.ndarray, code_b: np.ndarray, pos: int) -> np.ndarray:
+        """hierarchical_ar.py:505-544: input embedding of one top position from its 1+4 codes."""
+        w, s = self.w, self.s
+        top = w['tok_emb_top.weight'][code_t] + w['pos_emb_top.weight'][pos]          # [B, D]
+        if s.embedding == 1:                                                         # 'reduce' :522-526
+            eb = w['tok_emb_bot.weight'][code_b]                                     # [B, 4, D/4]
+            return (top + eb.transpose(0, 2, 1).reshape(top.shape[0], -1))[:, None, :].astype(F32)   # ch = k*4+slot
+        eb = w['tok_emb_bot.weight'][code_b]                                         # [B, 4, D]   :535-544
+        h = np.concatenate([top[:, None, :], eb], axis=1) + w['pos_emb_emb.weight'][None]
+        return h.mean(axis=1, dtype=F32)[:, None, :].astype(F32)
+
+    def sample(self, cond, batch: int, n_steps: int, noise: np.ndarray,
+               top_k: Sequence[Optional[int]] = (None, None), top_p: Sequence[Optional[float]] = (None, None),
+               temperature: Sequence[float] = (1.0, 1.0), force_top: Optional[np.ndarray] = None,
+               force_bot: Optional[np.ndarray] = None, return_logits: bool = False):
+        """sampling_ihqgpt (sampling.py:164-237).  ``cond``: int64 [B] class ids, or [B, ctx_len_txt]
+        text ids, or None.  ``noise`` [n_steps, 5, B, V].  ``force_top`` [B, n_steps] / ``force_bot``
+        [B, n_steps, 4] teacher-force the codes fed back (force_top = the reference's given_top_code,
+        hierarchical_ar.py:768-774); the draws are still computed and returned."""
+        w, s = self.w, self.s
+        B = batch
+        if s.cond == 1:
+            sos = w['sos.weight'][np.asarray(cond, np.int64).reshape(-1)][:, None, :]      # sampling.py:183-186
+        elif s.cond == 2:
+            sos = w['tok_emb_txt.weight'][np.asarray(cond, np.int64)] + w['pos_emb_txt.weight'][None, :s.ctx_len_txt]
+        else:
+            sos = np.repeat(w['sos'], B, axis=0)                                         # sampling.py:191-192
+        cache: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
+        codes_top = np.zeros((B, n_steps), np.int64)
+        codes_bot = np.zeros((B, n_steps, 4), np.int64)
+        logits_out = np.zeros((n_steps, 5, B, s.vocab_top), F32) if return_logits else None
+        for cnt in range(n_steps):
+            if cnt == 0:
+                xs = sos.astype(F32)
+            else:
+                ct = force_top[:, cnt - 1] if force_top is not None else codes_top[:, cnt - 1]
+                cb = force_bot[:, cnt - 1] if force_bot is not None else codes_bot[:, cnt - 1]
+                xs = self._embed(ct, cb, cnt - 1)
+            for i in range(s.n_layers):                                                  # :501-503,557-559
+                xs = self._block(f'blocks.{i}', xs, cache, causal_new=True)
+            hs = layer_norm(xs, w['ln_f.weight'], w['ln_f.bias'])
+            if hs.shape[1] > 1:                                                          # :684-685
+                hs = hs[:, s.idx_pred - 1:s.idx_pred, :]
+            # depth sub-step 0: top code (hierarchical_ar.py:682-695, 762-775)
+            dcache: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
+            xd = (hs + w['sos_depth']).astype(F32)
+            for j in range(s.n_layers_depth):
+                xd = self._block(f'depths.{j}', xd, dcache, causal_new=False)
+            lt = linear(layer_norm(xd, w['ln_top.weight'], w['ln_top.bias']), w['head_top.weight'])[:, 0]
+            top, _ = sample_filtered(lt, noise[cnt, 0], temperature[0], top_k[0], top_p[0])
+            codes_top[:, cnt] = top
+            if return_logits:
+                logits_out[cnt, 0] = lt
+            fed_top = force_top[:, cnt] if force_top is not None else top
+            # depth sub-step 1: four bottom codes in one pass (hierarchical_ar.py:696-719, 776-785)
+            xd = (w['tok_emb_top_depth.weight'][fed_top][:, None, :] + w['pos_emb_depth.weight'][None, :4]).astype(F32)
+            for j in range(s.n_layers_depth):
+                xd = self._block(f'depths.{j}', xd, dcache, causal_new=False)            # all-ones mask, layers.py:147-152
+            lb = linear(layer_norm(xd, w['ln_bot.weight'], w['ln_bot.bias']), w['head_bot.weight'])  # [B,4,V]
+            for slot in range(4):
+                idx, _ = sample_filtered(lb[:, slot], noise[cnt, 1 + slot], temperature[1], top_k[1], top_p[1])
+                codes_bot[:, cnt, slot] = idx
+                if return_logits:
+                    logits_out[cnt, 1 + slot] = lb[:, slot]
+        if return_logits:
+            return codes_top, codes_bot, logits_out
+        return codes_top, codes_bot
+
+
+# ----------------------------------------------------------------------------- stage 1 (A9-A12)
+def conv2d(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """nn.Conv2d stride 1, 'same' zero padding, kernel 1 or 3, NCHW (stage1/modules/layers.py:40-44,88-98)."""
+    B, C, H, W = x.shape
+    O, _, kh, kw = w.shape
+    if kh == 1:
+        y = np.einsum('oc,bchw->bohw', w[:, :, 0, 0], x, optimize=True)
+    else:
+        xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+        cols = np.empty((B, C, 9, H, W), F32)
+        for dy in range(3):
+            for dx in range(3):
+                cols[:, :, dy * 3 + dx] = xp[:, :, dy:dy + H, dx:dx + W]
+        y = (w.reshape(O, C * 9) @ cols.reshape(B, C * 9, H * W)).reshape(B, O, H, W)
+    return (y + b[None, :, None, None]).astype(F32)
+
+
+def group_norm(x: np.ndarray, g: np.ndarray, b: np.ndarray, groups: int = 32, eps: float = 1e-6) -> np.ndarray:
+    """GroupNorm(32, eps=1e-6, affine) -- stage1/modules/layers.py:17-21; stats per (sample, group)."""
+    B, C, H, W = x.shape
+    xg = x.reshape(B, groups, -1).astype(np.float64)
+    mu = xg.mean(-1, keepdims=True)
+    var = ((xg - mu) ** 2).mean(-1, keepdims=True)
+    xn = ((xg - mu) / np.sqrt(var + eps)).astype(F32).reshape(B, C, H, W)
+    return (xn * g[None, :, None, None] + b[None, :, None, None]).astype(F32)
+
+
+def swish(x: np.ndarray) -> np.ndarray:
+    """stage1/modules/layers.py:12-14."""
+    return (x / (1.0 + np.exp(-x))).astype(F32)
+
+
+def upsample_nearest2(x: np.ndarray) -> np.ndarray:
+    """F.interpolate(scale_factor=2, mode='nearest') -- stage1/modules/layers.py:50."""
+    return x.repeat(2, axis=2).repeat(2, axis=3)
+
+
+def pixel_shuffle2(x: np.ndarray) -> np.ndarray:
+    """nn.PixelShuffle(2): out[c, 2h+i, 2w+j] = in[4c+2i+j, h, w] (generator.py:229,316)."""
+    B, C4, H, W = x.shape
+    return x.reshape(B, C4 // 4, 2, 2, H, W).transpose(0, 1, 4, 2, 5, 3).reshape(B, C4 // 4, 2 * H, 2 * W)
+
+
+class OracleStage1:
+    """SimRQGAN2Generator.decode_code (generator.py:312-367) + Decoder.forward (stage1/modules/layers.py:385-410)."""
+
+    def __init__(self, spec, weights: Dict[str, np.ndarray]):
+        self.s = spec
+        self.w = {k: np.ascontiguousarray(v, dtype=F32) for k, v in weights.items()}
+
+    def _conv(self, name: str, x: np.ndarray) -> np.ndarray:
+        return conv2d(x, self.w[f'{name}.weight'], self.w[f'{name}.bias'])
+
+    def _gn(self, name: str, x: np.ndarray) -> np.ndarray:
+        return group_norm(x, self.w[f'{name}.weight'], self.w[f'{name}.bias'])
+
+    def _resblock(self, name: str, x: np.ndarray) -> np.ndarray:
+        """ResnetBlock.forward (stage1/modules/layers.py:115-133)."""
+        h = self._conv(f'{name}.conv1', swish(self._gn(f'{name}.norm1', x)))
+        h = self._conv(f'{name}.conv2', swish(self._gn(f'{name}.norm2', h)))
+        if f'{name}.nin_shortcut.weight' in self.w:
+            x = self._conv(f'{name}.nin_shortcut', x)
+        return (x + h).astype(F32)
+
+    def _attnblock(self, name: str, x: np.ndarray) -> np.ndarray:
+        """AttnBlock.forward (stage1/modules/layers.py:163-186): single head, scale C^-0.5 after q.k."""
+        B, C, H, W = x.shape
+        h = self._gn(f'{name}.norm', x)
+        q = self._conv(f'{name}.q', h).reshape(B, C, H * W).transpose(0, 2, 1)
+        k = self._conv(f'{name}.k', h).reshape(B, C, H * W)
+        v = self._conv(f'{name}.v', h).reshape(B, C, H * W)
+        wgt = softmax(((q @ k) * F32(int(C) ** (-0.5))).astype(F32))               # [B, i(query), j(key)]
+        o = (v @ wgt.transpose(0, 2, 1)).reshape(B, C, H, W)                       # o[c, i] = sum_j v[c, j] w[i, j]
+        return (x + self._conv(f'{name}.proj_out', o.astype(F32))).astype(F32)
+
+    def decoder(self, z: np.ndarray) -> np.ndarray:
+        s = self.s
+        n = len(s.ch_mult)
+        res = s.z_res
+        h = self._conv('decoder.conv_in', z)
+        if s.use_mid_block:
+            h = self._resblock('decoder.mid.block_1', h)
+            if s.use_attn:
+                h = self._attnblock('decoder.mid.attn_1', h)
+            h = self._resblock('decoder.mid.block_2', h)
+        for lvl in reversed(range(n)):
+            for blk in range(s.num_res_blocks + 1):
+                h = self._resblock(f'decoder.up.{lvl}.block.{blk}', h)
+                if res in s.attn_resolutions and s.use_attn:
+                    h = self._attnblock(f'decoder.up.{lvl}.attn.{blk}', h)
+            if lvl != 0 or s.use_init_downsample:
+                h = self._conv(f'decoder.up.{lvl}.upsample.conv', upsample_nearest2(h))
+                res *= 2
+        h = swish(self._gn('decoder.norm_out', h))
+        return self._conv('decoder.conv_out', h)
+
+    def decode_code(self, code_t: Optional[np.ndarray], code_b: Optional[np.ndarray]) -> np.ndarray:
+        """code_t int64 [B, r/2, r/2] or None, code_b int64 [B, r, r] or None -> fp32 [B, 3, H, W], unclamped.
+        A missing level contributes a zero quant (generator.py:328-358)."""
+        assert code_t is not None or code_b is not None
+        w, s = self.w, self.s
+        if code_t is not None:
+            qt = w['quantize_t.embedding'][code_t].transpose(0, 3, 1, 2)              # quantizer.py:179-186
+        if code_b is not None:
+            qb = w['quantize_b.embedding'][code_b].transpose(0, 3, 1, 2)
+        if code_t is None:
+            qt = np.zeros((qb.shape[0], qb.shape[1] * 4, qb.shape[2] // 2, qb.shape[3] // 2), F32)
+        if code_b is None:
+            qb = np.zeros((qt.shape[0], qt.shape[1] // 4, qt.shape[2] * 2, qt.shape[3] * 2), F32)
+        quant = np.concatenate([pixel_shuffle2(qt), qb], axis=1).astype(F32)          # generator.py:316-318
+        z = self._conv('post_quant_conv_b', quant)
+        return self.decoder(z)
+
+
+def postprocess(pixels: np.ndarray) -> np.ndarray:
+    """clamp(0.5 x + 0.5, 0, 1) -- measure_throughput/__main__.py:113, sampling_hqmodel.py:198-199."""
+    return np.clip(F32(0.5) * pixels + F32(0.5), 0.0, 1.0).astype(F32)
+
+
+def rearrange_codes(codes_top: np.ndarray, codes_bot: np.ndarray, top_res: int) -> Tuple[np.ndarray, np.ndarray]:
+    """sampling_hqmodel.py:119-120: 'B (H W) -> B H W' and 'B (H W) (kh kw) -> B (H kh) (W kw)', kh = kw = 2."""
+    B = codes_top.shape[0]
+    ct = codes_top.reshape(B, top_res, top_res)
+    cb = codes_bot.reshape(B, top_res, top_res, 2, 2).transpose(0, 1, 3, 2, 4).reshape(B, 2 * top_res, 2 * top_res)
+    return ct, cb

@@ -1,0 +1,128 @@
+"""Pins the CPU oracle against outputs of the reference itself (tests/golden/*.npz, written by
+tools/gen_golden.py in the build container).  Bars: sampled code sequences bit-exact; fp32 logits and
+pixels within the tolerances written below (both sides are fp32, summation order differs)."""
+import json
+
+import numpy as np
+import pytest
+
+from hqtransformer_amd import synth
+from hqtransformer_amd.spec import stage1_param_shapes, stage2_param_shapes
+from oracle import hqt_oracle as O
+from tests.helpers import load, oracle_stage1, oracle_stage2
+
+LOGIT_TOL = 2e-4      # abs, fp32 logits of std ~3 after up to 8 blocks
+PIXEL_TOL = 1e-4      # abs, north_star's pixel tolerance
+
+
+def test_sampler_kats():
+    fx = load('g1_sampler.npz')
+    cases = json.loads(str(fx['cases']))
+    for ci, (k, p, T) in enumerate(cases):
+        idx, probs = O.sample_filtered(fx['logits'], fx['noise'], T, k, p)
+        ref = fx[f'probs_{ci}']
+        differs = (probs == 0) != (ref == 0)
+        # the kept set is decided by `cum >= p` on fp32 prefix sums: softmax results that differ from
+        # torch's by one ulp can move the cut by a few extreme-tail tokens (SURVEY.md §7 "Top-p numerics")
+        assert np.where(differs, np.maximum(probs, ref), 0).sum(-1).max() < 2e-6, f'case {ci}: kept set differs'
+        np.testing.assert_allclose(np.where(differs, 0, probs), np.where(differs, 0, ref), rtol=4e-6, atol=1e-9)
+        assert (idx == fx[f'index_{ci}']).all(), f'case {ci}'
+
+
+def test_multinomial_is_argmax_p_over_q():
+    fx = load('g1_sampler.npz')
+    assert (np.argmax(fx['mn_probs'] / fx['mn_noise'], -1) == fx['mn_index']).all()
+
+
+def test_param_shapes_match_reference_state_dict():
+    for name in ('g4_tiny_cls.npz', 'g3_tiny_reduce_uncond.npz', 'g3_tiny_txt.npz'):
+        fx = load(name)
+        spec, _, _ = oracle_stage2(fx)
+        ref = {k: tuple(v) for k, v in json.loads(str(fx['param_shapes'])).items()}
+        assert dict(stage2_param_shapes(spec)) == ref
+    for name in ('g5_decode_64.npz', 'g5_decode_256.npz'):
+        fx = load(name)
+        spec, _, _ = oracle_stage1(fx)
+        ref = {k: tuple(v) for k, v in json.loads(str(fx['param_shapes'])).items()}
+        assert dict(stage1_param_shapes(spec)) == ref
+
+
+@pytest.mark.parametrize('si', [0, 1, 2])
+def test_tiny_cls_sampling_bit_exact(si):
+    fx = load('g4_tiny_cls.npz')
+    spec, _, orc = oracle_stage2(fx)
+    tk, tp, T = json.loads(str(fx['settings']))[si]
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = synth.exp_noise(int(fx['noise_seed']), n, B, spec.vocab_top)
+    ct, cb, lg = orc.sample(np.full(B, 7), B, n, noise, tk, tp, T, return_logits=True)
+    assert float(fx[f'margin_{si}']) > 1.00005          # fixture is well-conditioned for bit-exactness
+    assert (ct == fx[f'codes_top_{si}']).all()
+    assert (cb == fx[f'codes_bot_{si}']).all()
+    scale = np.array([T[0]] + [T[1]] * 4, np.float32)[None, :, None, None]
+    np.testing.assert_allclose(lg[fx['keep_steps']] / scale, fx[f'logits_{si}'], atol=LOGIT_TOL, rtol=0)
+
+
+def test_tiny_cls_given_top_code():
+    fx = load('g4_tiny_cls.npz')
+    spec, _, orc = oracle_stage2(fx)
+    B = int(fx['B'])
+    noise = synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:8]
+    ct, cb, lg = orc.sample(np.full(B, 3), B, 8, noise, force_top=fx['given_top'], return_logits=True)
+    assert (cb == fx['given_codes_bot']).all()
+    np.testing.assert_allclose(lg, fx['given_logits'], atol=LOGIT_TOL, rtol=0)
+
+
+def test_tiny_reduce_uncond_bit_exact():
+    fx = load('g3_tiny_reduce_uncond.npz')
+    spec, _, orc = oracle_stage2(fx)
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = synth.exp_noise(int(fx['noise_seed']), n, B, spec.vocab_top)
+    k, p, T = int(fx['top_k']), float(fx['top_p']), [float(t) for t in fx['temps']]
+    ct, cb, lg = orc.sample(None, B, n, noise, (k, k), (p, p), T, return_logits=True)
+    assert (ct == fx['codes_top']).all() and (cb == fx['codes_bot']).all()
+    scale = np.array([T[0]] + [T[1]] * 4, np.float32)[None, :, None, None]
+    np.testing.assert_allclose(lg[fx['keep_steps']] / scale, fx['logits'], atol=LOGIT_TOL, rtol=0)
+
+
+def test_tiny_txt_prefill_bit_exact():
+    fx = load('g3_tiny_txt.npz')
+    spec, _, orc = oracle_stage2(fx)
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = synth.exp_noise(int(fx['noise_seed']), n, B, spec.vocab_top)
+    txt = synth.text_ids(int(fx['text_seed']), B, spec.ctx_len_txt, spec.vocab_txt)
+    ct, cb, lg = orc.sample(txt, B, n, noise, return_logits=True)
+    assert (ct == fx['codes_top']).all() and (cb == fx['codes_bot']).all()
+    np.testing.assert_allclose(lg[fx['keep_steps']], fx['logits'], atol=LOGIT_TOL, rtol=0)
+
+
+def test_decode_64_pixels_and_intermediates():
+    fx = load('g5_decode_64.npz')
+    spec, _, orc = oracle_stage1(fx)
+    px = orc.decode_code(fx['code_t'], fx['code_b'])
+    np.testing.assert_allclose(px, fx['pixels'], atol=PIXEL_TOL, rtol=0)
+    np.testing.assert_allclose(orc.decode_code(fx['code_t'][:1], None), fx['pixels_top_only'], atol=PIXEL_TOL, rtol=0)
+    np.testing.assert_allclose(orc.decode_code(None, fx['code_b'][:1]), fx['pixels_bot_only'], atol=PIXEL_TOL, rtol=0)
+    w = orc.w
+    qt = w['quantize_t.embedding'][fx['code_t'][:1]].transpose(0, 3, 1, 2)
+    qb = w['quantize_b.embedding'][fx['code_b'][:1]].transpose(0, 3, 1, 2)
+    z = orc._conv('post_quant_conv_b', np.concatenate([O.pixel_shuffle2(qt), qb], 1))
+    np.testing.assert_allclose(z, fx['z'], atol=1e-5, rtol=0)
+    h0 = orc._conv('decoder.conv_in', z)
+    np.testing.assert_allclose(h0, fx['conv_in'], atol=2e-5, rtol=0)
+    h1 = orc._resblock('decoder.mid.block_1', h0)
+    np.testing.assert_allclose(h1, fx['mid_block_1'], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(orc._attnblock('decoder.mid.attn_1', h1), fx['mid_attn_1'], atol=5e-5, rtol=0)
+
+
+def test_decode_256_pixels():
+    fx = load('g5_decode_256.npz')
+    spec, _, orc = oracle_stage1(fx)
+    px = orc.decode_code(fx['code_t'], fx['code_b'])
+    np.testing.assert_allclose(px, fx['pixels'], atol=PIXEL_TOL, rtol=0)
+
+
+def test_index_maps():
+    fx = load('g6_index_maps.npz')
+    gt, gb = O.rearrange_codes(fx['codes_top'], fx['codes_bot'], 8)
+    assert (gt == fx['grid_top']).all() and (gb == fx['grid_bot']).all()
+    assert (O.pixel_shuffle2(fx['pixel_shuffle_in']) == fx['pixel_shuffle_out']).all()
