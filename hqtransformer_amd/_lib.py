@@ -1,0 +1,133 @@
+"""ctypes binding of libhqt.so (C ABI: include/hqt.h) and its in-tree build recipe.
+
+There is deliberately no CPU fallback: if the shared library is missing or cannot be loaded, every
+entry point of the package raises ``HqtLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libhqt.so')
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip']
+ABI_VERSION = 1
+
+PRECISION_EXACT, PRECISION_FAST = 0, 1
+
+
+class HqtLibraryError(RuntimeError):
+    pass
+
+
+class HqtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f'libhqt error {code}: {msg}')
+        self.code = code
+
+
+class hqt_config(C.Structure):
+    _fields_ = [
+        ('abi_version', C.c_int32),
+        ('has_stage2', C.c_int32),
+        ('embed_dim', C.c_int32), ('n_layers', C.c_int32), ('n_heads', C.c_int32), ('n_layers_depth', C.c_int32),
+        ('vocab_top', C.c_int32), ('vocab_bot', C.c_int32), ('vocab_txt', C.c_int32),
+        ('ctx_len_img', C.c_int32), ('ctx_len_txt', C.c_int32), ('n_classes', C.c_int32),
+        ('cond_type', C.c_int32), ('embedding_type', C.c_int32), ('gelu_approx', C.c_int32),
+        ('has_stage1', C.c_int32),
+        ('s1_ch', C.c_int32), ('s1_n_mult', C.c_int32), ('s1_ch_mult', C.c_int32 * 8),
+        ('s1_num_res_blocks', C.c_int32),
+        ('s1_n_attn_res', C.c_int32), ('s1_attn_res', C.c_int32 * 4),
+        ('s1_resolution', C.c_int32), ('s1_z_channels', C.c_int32), ('s1_embed_dim', C.c_int32),
+        ('s1_n_embed', C.c_int32), ('s1_out_ch', C.c_int32),
+        ('s1_use_init_downsample', C.c_int32), ('s1_use_mid_block', C.c_int32), ('s1_use_attn', C.c_int32),
+        ('max_batch', C.c_int32), ('max_steps', C.c_int32),
+    ]
+
+
+class hqt_sample_opts(C.Structure):
+    _fields_ = [
+        ('precision', C.c_int32), ('n_steps', C.c_int32),
+        ('top_k_top', C.c_int32), ('top_k_bot', C.c_int32),
+        ('top_p_top', C.c_float), ('top_p_bot', C.c_float),
+        ('temperature_top', C.c_float), ('temperature_bot', C.c_float),
+        ('seed', C.c_uint64), ('sample_offset', C.c_int64),
+        ('use_graph', C.c_int32),
+    ]
+
+
+# every symbol include/hqt.h declares: name -> (restype, argtypes)
+_VP, _I64P, _F32P = C.c_void_p, C.c_void_p, C.c_void_p
+SYMBOLS = {
+    'hqt_abi_version': (C.c_int, []),
+    'hqt_last_error': (C.c_char_p, []),
+    'hqt_create': (C.c_int, [C.POINTER(hqt_config), C.c_int, C.POINTER(_VP)]),
+    'hqt_set_weight': (C.c_int, [_VP, C.c_char_p, _VP, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    'hqt_finalize_weights': (C.c_int, [_VP]),
+    'hqt_sample': (C.c_int, [_VP, C.c_int, _I64P, C.POINTER(hqt_sample_opts), _F32P, _I64P, _I64P, _F32P, _I64P, _I64P, _VP]),
+    'hqt_decode': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
+    'hqt_decode_seq': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
+    'hqt_param_count': (C.c_int64, [_VP, C.c_int]),
+    'hqt_workspace_bytes': (C.c_int64, [_VP]),
+    'hqt_timing_enable': (C.c_int, [_VP, C.c_int]),
+    'hqt_timing_reset': (C.c_int, [_VP]),
+    'hqt_timing_get': (C.c_int, [_VP, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    'hqt_timing_slots': (C.c_int, [_VP]),
+    'hqt_destroy': (C.c_int, [_VP]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libhqt.so for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
+        [os.path.join(os.path.dirname(HERE), 'include', 'hqt.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
+           '-Wno-unused-result', '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise HqtLibraryError('hipcc failed:\n' + proc.stdout)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HqtLibraryError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(hqtransformer_amd has no CPU fallback)')
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HqtLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HqtLibraryError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hqt_abi_version() != ABI_VERSION:
+        raise HqtLibraryError(f'ABI version {lib.hqt_abi_version()} != {ABI_VERSION}: rebuild libhqt.so')
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise HqtError(code, load().hqt_last_error().decode('utf-8', 'replace'))
+
+
+def exported_symbols() -> List[str]:
+    return list(SYMBOLS)

@@ -1,0 +1,77 @@
+// Shared declarations of libhqt.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+
+__device__ __host__ inline float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)v) << 16;
+    return c.f;
+}
+// round-to-nearest-even; NaN stays NaN
+__device__ __host__ inline bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    if ((c.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((c.u >> 16) | 0x40);
+    return (bf16_t)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
+
+enum { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_SIGMOID = 2 };
+enum { STORE_ROWS = 0, STORE_NCHW = 1, STORE_QKV = 2 };
+
+// One NT GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]  (+bias, act, +residual) with
+//   * an optional implicit-GEMM A operand: 1x1 / 3x3 'same' convolution over an NHWC tensor, with
+//     nearest-x2 upsampling folded into the addressing and GroupNorm(+swish) applied on load;
+//   * an output row remap (KV-cache append), a per-image transposed store (NCHW / V^T), or a
+//     three-way column split (fused QKV).
+struct GemmArgs {
+    // ---- A
+    const void* A;           // plain: [M, lda]; conv: NHWC [batch_img, Hin, Win, Cin]
+    int lda;
+    long long a_batch_stride;  // elements, blockIdx.z batches (decoder attention)
+    int a_rows_per_group;    // plain A row remap: a_row = (m / rpg) * a_group_stride + m % rpg + a_row_offset
+    int a_group_stride;
+    int a_row_offset;
+    int conv_taps;           // 0 = plain, 1 = 1x1, 9 = 3x3
+    int H, W, Cin;           // output spatial size and input channels (conv)
+    int upsample;            // 1: input is (H/2, W/2), nearest x2 before the conv
+    const float* gn_stats;   // [batch_img][groups][2] mean, rstd  (NULL: no GroupNorm on load)
+    const float* gn_gamma;
+    const float* gn_beta;
+    int gn_groups;
+    int gn_swish;
+    // ---- B (weights or second activation), [N, ldb]
+    const void* Bw;
+    int ldb;
+    long long b_batch_stride;
+    // ---- C
+    void* C;
+    int ldc;
+    long long c_batch_stride;
+    int M, N, K, batch;
+    const float* bias;       // [N] or NULL
+    const void* resid;       // same indexing as C (may alias C), or NULL
+    int act;
+    float alpha;
+    int store;               // STORE_*
+    int rows_per_group;      // STORE_ROWS: out_row = (m / rpg) * group_stride + m % rpg + row_offset
+    int group_stride;
+    int row_offset;
+    const int* row_offset_dev;   // optional device int added to row_offset (graph replays)
+    int rows_per_image;      // STORE_NCHW: C[(img * N + n) * rpi + m % rpi]
+    int clamp01;             // STORE_NCHW epilogue clamp(0.5 x + 0.5, 0, 1)
+    // STORE_QKV: columns [0,D) -> C, [D,2D) -> C2, [2D,3D) -> C3 ; C2/C3 use the row remap, C plain
+    void* C2;
+    void* C3;
+    int qkv_D;
+};
+
+struct StepState {           // lives in device memory; lets one captured graph serve every position
+    int step;                // current top position (0-based)
+    int t_base;              // KV rows already in the body cache
+};
+
+#define HQT_MAX_V 16384

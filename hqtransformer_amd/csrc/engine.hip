@@ -1,0 +1,822 @@
+// libhqt.so host side: handle, weight registry, workspaces and the launch sequences behind the C ABI
+// of include/hqt.h.  No CPU compute path exists here: every tensor operation is a HIP kernel.
+#include "../../include/hqt.h"
+#include "kernels.h"
+#include "fast_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(HQT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                              \
+    } while (0)
+#define CHK(expr)                  \
+    do {                           \
+        int r_ = (expr);           \
+        if (r_ != HQT_OK) return r_; \
+    } while (0)
+
+struct Tensor {
+    float* d = nullptr;
+    std::vector<int64_t> shape;
+    size_t n = 0;
+};
+
+struct Lin {            // one nn.Linear / conv filter bank in every layout the kernels read
+    const float* w32 = nullptr;   // [N, K] fp32 (conv: tap-major [O][tap][I])
+    const float* b32 = nullptr;   // [N] or null
+    bf16_t* w16 = nullptr;        // [N, K] bf16 row-major (FAST generic + conv MFMA)
+    bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)
+    int N = 0, K = 0;
+};
+
+struct BlockW {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    Lin qkv, proj, fc1, fc2;
+};
+
+struct DecLayer {
+    int kind;            // 0 conv3, 1 res, 2 attn, 3 upconv, 4 out
+    std::string name;
+    int cin, cout, res;
+    Lin conv1, conv2, nin, q, k, v, proj;      // conv3/upconv/out use conv1
+    const float *n1_g = nullptr, *n1_b = nullptr, *n2_g = nullptr, *n2_b = nullptr;
+};
+
+struct TimingSlot {
+    std::string name;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    int64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct hqt_handle {
+    hqt_config cfg;
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, Tensor> w;
+    std::vector<void*> owned;                 // every device allocation, freed in destroy
+    size_t workspace_bytes = 0;
+    int64_t params[3] = {0, 0, 0};
+    // ---- stage 2
+    std::vector<BlockW> body, depth;
+    Lin head_top, head_bot;
+    int Tmax = 0;
+    float *x = nullptr, *xd = nullptr, *logits = nullptr;
+    void *hbuf = nullptr, *qbuf = nullptr, *abuf = nullptr, *mbuf = nullptr;    // fp32-sized, reused as bf16 in FAST
+    void *kcache = nullptr, *vcache = nullptr, *dk = nullptr, *dv = nullptr;
+    float* splitk = nullptr;                  // split-K partial slabs of the streaming GEMM
+    size_t splitk_elems = 0;
+    StepState* state = nullptr;
+    // ---- stage 1
+    std::vector<DecLayer> dec;
+    Lin post_quant;
+    void* act[3] = {nullptr, nullptr, nullptr};
+    size_t act_elems = 0;
+    int dec_chunk = 0;
+    void *aq = nullptr, *ak = nullptr, *av = nullptr, *ao = nullptr, *as = nullptr, *quant = nullptr;
+    float* gn = nullptr;                      // [chunk][32][2] x 2
+    // ---- graph cache
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<uint64_t> graph_key;
+    // ---- timing
+    bool timing = false;
+    std::vector<TimingSlot> slots;
+};
+
+static int dev_alloc(hqt_handle* h, void** p, size_t bytes, bool workspace) {
+    HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+    h->owned.push_back(*p);
+    if (workspace) h->workspace_bytes += bytes;
+    return HQT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ timing
+static int slot_id(hqt_handle* h, const char* name) {
+    for (size_t i = 0; i < h->slots.size(); ++i)
+        if (h->slots[i].name == name) return (int)i;
+    h->slots.push_back(TimingSlot());
+    h->slots.back().name = name;
+    return (int)h->slots.size() - 1;
+}
+struct Timed {
+    hqt_handle* h; int slot; hipStream_t st; bool on;
+    Timed(hqt_handle* h_, const char* name, hipStream_t st_) : h(h_), slot(-1), st(st_), on(h_->timing) {
+        if (!on) return;
+        slot = slot_id(h, name);
+        TimingSlot& s = h->slots[slot];
+        if (s.used == s.ev.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            s.ev.push_back({a, b});
+        }
+        hipEventRecord(s.ev[s.used].first, st);
+    }
+    ~Timed() {
+        if (!on) return;
+        TimingSlot& s = h->slots[slot];
+        hipEventRecord(s.ev[s.used].second, st);
+        s.used++;
+    }
+};
+static void timing_collect(hqt_handle* h) {
+    for (auto& s : h->slots) {
+        for (size_t i = 0; i < s.used; ++i) {
+            hipEventSynchronize(s.ev[i].second);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.ev[i].first, s.ev[i].second) == hipSuccess) { s.total_ms += ms; s.launches++; }
+        }
+        s.used = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ plan
+static void build_decoder_plan(hqt_handle* h) {
+    const hqt_config& c = h->cfg;
+    const int n = c.s1_n_mult;
+    int block_in = c.s1_ch * c.s1_ch_mult[n - 1];
+    int res = c.s1_resolution >> (c.s1_use_init_downsample ? n : n - 1);
+    auto is_attn_res = [&](int r) {
+        for (int i = 0; i < c.s1_n_attn_res; ++i) if (c.s1_attn_res[i] == r) return true;
+        return false;
+    };
+    auto add = [&](int kind, const std::string& name, int cin, int cout, int r) {
+        DecLayer l; l.kind = kind; l.name = name; l.cin = cin; l.cout = cout; l.res = r;
+        h->dec.push_back(l);
+    };
+    add(0, "decoder.conv_in", c.s1_z_channels, block_in, res);
+    if (c.s1_use_mid_block) {
+        add(1, "decoder.mid.block_1", block_in, block_in, res);
+        if (c.s1_use_attn) add(2, "decoder.mid.attn_1", block_in, block_in, res);
+        add(1, "decoder.mid.block_2", block_in, block_in, res);
+    }
+    for (int lvl = n - 1; lvl >= 0; --lvl) {
+        const int block_out = c.s1_ch * c.s1_ch_mult[lvl];
+        for (int b = 0; b <= c.s1_num_res_blocks; ++b) {
+            add(1, "decoder.up." + std::to_string(lvl) + ".block." + std::to_string(b), block_in, block_out, res);
+            block_in = block_out;
+            if (is_attn_res(res) && c.s1_use_attn)
+                add(2, "decoder.up." + std::to_string(lvl) + ".attn." + std::to_string(b), block_in, block_in, res);
+        }
+        if (lvl != 0 || c.s1_use_init_downsample) {
+            add(3, "decoder.up." + std::to_string(lvl) + ".upsample.conv", block_in, block_in, res);
+            res *= 2;
+        }
+    }
+    add(4, "decoder", block_in, c.s1_out_ch, res);
+}
+
+// ------------------------------------------------------------------------------------------ create
+extern "C" int hqt_abi_version(void) { return HQT_ABI_VERSION; }
+extern "C" const char* hqt_last_error(void) { return g_err.c_str(); }
+
+extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
+    if (!cfg || !out) return fail(HQT_ERR_INVALID, "null argument");
+    if (cfg->abi_version != HQT_ABI_VERSION) return fail(HQT_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, HQT_ABI_VERSION);
+    if (cfg->max_batch < 1) return fail(HQT_ERR_INVALID, "max_batch must be >= 1");
+    HIPCHK(hipSetDevice(device));
+    std::unique_ptr<hqt_handle> h(new hqt_handle());
+    h->cfg = *cfg;
+    h->device = device;
+    const hqt_config& c = h->cfg;
+    const size_t B = (size_t)c.max_batch;
+    if (c.has_stage2) {
+        if (c.embed_dim % c.n_heads || c.embed_dim % 16) return fail(HQT_ERR_INVALID, "embed_dim must be a multiple of n_heads and 16");
+        const int hs = c.embed_dim / c.n_heads;
+        if (hs % 4 || hs > 256) return fail(HQT_ERR_INVALID, "head_dim %d unsupported", hs);
+        if (c.vocab_top != c.vocab_bot) return fail(HQT_ERR_INVALID, "vocab_top != vocab_bot");
+        if (c.vocab_top > HQT_MAX_V || c.vocab_top % 4) return fail(HQT_ERR_INVALID, "vocab size %d unsupported", c.vocab_top);
+        if (c.cond_type == HQT_COND_CLASS && c.n_classes < 1) return fail(HQT_ERR_INVALID, "n_classes");
+        if (c.max_steps < 1 || c.max_steps > c.ctx_len_img) return fail(HQT_ERR_INVALID, "max_steps must be in [1, ctx_len_img]");
+        const size_t D = c.embed_dim;
+        const int Tp = c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1;    // rows of the widest body pass
+        h->Tmax = (c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 0) + c.max_steps;
+        const size_t rows = B * (size_t)std::max(Tp, 4);
+        CHK(dev_alloc(h.get(), (void**)&h->x, rows * D * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->xd, B * 4 * D * 4, true));
+        CHK(dev_alloc(h.get(), &h->hbuf, rows * D * 4, true));
+        CHK(dev_alloc(h.get(), &h->qbuf, rows * D * 4, true));
+        CHK(dev_alloc(h.get(), &h->abuf, rows * D * 4, true));
+        CHK(dev_alloc(h.get(), &h->mbuf, rows * 4 * D * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->logits, B * 4 * (size_t)c.vocab_top * 4, true));
+        const size_t kv = (size_t)c.n_layers * B * h->Tmax * D * 4;
+        CHK(dev_alloc(h.get(), &h->kcache, kv, true));
+        CHK(dev_alloc(h.get(), &h->vcache, kv, true));
+        const size_t dkv = (size_t)c.n_layers_depth * B * 5 * D * 4;
+        CHK(dev_alloc(h.get(), &h->dk, dkv, true));
+        CHK(dev_alloc(h.get(), &h->dv, dkv, true));
+        h->splitk_elems = (size_t)16 * rows * (size_t)std::max<size_t>(4 * D, (size_t)c.vocab_top);
+        CHK(dev_alloc(h.get(), (void**)&h->splitk, h->splitk_elems * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->state, sizeof(StepState), true));
+    }
+    if (c.has_stage1) {
+        if (c.s1_n_mult < 1 || c.s1_n_mult > 8) return fail(HQT_ERR_INVALID, "s1_n_mult");
+        if (c.s1_ch % 32) return fail(HQT_ERR_INVALID, "GroupNorm(32) needs ch %% 32 == 0");
+        if (c.s1_z_channels % 16 || (2 * c.s1_embed_dim) % 16) return fail(HQT_ERR_INVALID, "z_channels and 2*embed_dim must be multiples of 16");
+        build_decoder_plan(h.get());
+        size_t per_img = 0;
+        for (auto& l : h->dec) {
+            const size_t in_e = (size_t)l.res * l.res * l.cin;
+            const size_t out_r = l.kind == 3 ? 2 * l.res : l.res;
+            const size_t out_e = out_r * out_r * (size_t)(l.kind == 4 ? 0 : l.cout);
+            per_img = std::max(per_img, std::max(in_e, out_e));
+        }
+        h->dec_chunk = std::min<int>(c.max_batch, 64);
+        h->act_elems = per_img * h->dec_chunk;
+        for (int i = 0; i < 3; ++i) CHK(dev_alloc(h.get(), &h->act[i], h->act_elems * 4, true));
+        const int r = h->dec.front().res;
+        size_t attn_c = 0;
+        for (auto& l : h->dec) if (l.kind == 2) attn_c = std::max(attn_c, (size_t)l.cin * l.res * l.res);
+        const size_t hw = (size_t)r * r;
+        if (attn_c) {
+            CHK(dev_alloc(h.get(), &h->aq, attn_c * h->dec_chunk * 4, true));
+            CHK(dev_alloc(h.get(), &h->ak, attn_c * h->dec_chunk * 4, true));
+            CHK(dev_alloc(h.get(), &h->av, attn_c * h->dec_chunk * 4, true));
+            CHK(dev_alloc(h.get(), &h->ao, attn_c * h->dec_chunk * 4, true));
+            size_t smax = 0;
+            for (auto& l : h->dec) if (l.kind == 2) smax = std::max(smax, (size_t)l.res * l.res * l.res * l.res);
+            CHK(dev_alloc(h.get(), &h->as, smax * h->dec_chunk * 4, true));
+        }
+        CHK(dev_alloc(h.get(), &h->quant, hw * 2 * c.s1_embed_dim * h->dec_chunk * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->gn, (size_t)h->dec_chunk * 32 * 2 * 2 * 4, true));
+    }
+    *out = h.release();
+    return HQT_OK;
+}
+
+extern "C" int hqt_destroy(hqt_handle* h) {
+    if (!h) return HQT_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    for (auto& s : h->slots) for (auto& e : s.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (void* p : h->owned) hipFree(p);
+    delete h;
+    return HQT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ weights
+extern "C" int hqt_set_weight(hqt_handle* h, const char* name, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (!h || !name || !data || !shape || ndim < 1 || ndim > 4) return fail(HQT_ERR_INVALID, "bad argument");
+    if (dtype != HQT_DTYPE_F32) return fail(HQT_ERR_INVALID, "only fp32 weights are accepted");
+    if (h->finalized) return fail(HQT_ERR_STATE, "weights already finalized");
+    HIPCHK(hipSetDevice(h->device));
+    Tensor t;
+    t.n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.n *= (size_t)shape[i]; }
+    auto it = h->w.find(name);
+    if (it != h->w.end()) {
+        if (it->second.n != t.n) return fail(HQT_ERR_SHAPE, "%s: re-set with a different size", name);
+        t.d = it->second.d;
+    } else {
+        CHK(dev_alloc(h, (void**)&t.d, t.n * 4, false));
+        const int stage = strncmp(name, "stage1.", 7) == 0 ? 1 : 2;
+        h->params[stage] += (int64_t)t.n;
+    }
+    HIPCHK(hipMemcpy(t.d, data, t.n * 4, hipMemcpyDefault));
+    h->w[name] = t;
+    return HQT_OK;
+}
+
+static int get_w(hqt_handle* h, const std::string& name, std::vector<int64_t> shape, const float** out) {
+    auto it = h->w.find(name);
+    if (it == h->w.end()) return fail(HQT_ERR_MISSING_WEIGHT, "missing weight '%s'", name.c_str());
+    if (it->second.shape != shape) {
+        std::string got, want;
+        for (auto v : it->second.shape) got += std::to_string(v) + ",";
+        for (auto v : shape) want += std::to_string(v) + ",";
+        return fail(HQT_ERR_SHAPE, "weight '%s' has shape [%s] expected [%s]", name.c_str(), got.c_str(), want.c_str());
+    }
+    *out = it->second.d;
+    return HQT_OK;
+}
+
+static int make_lin(hqt_handle* h, Lin& l, const float* w32, const float* b32, int N, int K, bool stream_pack) {
+    l.w32 = w32; l.b32 = b32; l.N = N; l.K = K;
+    CHK(dev_alloc(h, (void**)&l.w16, (size_t)N * K * 2, false));
+    HIPCHK(launch_f32_to_bf16(w32, l.w16, (size_t)N * K, 0));
+    if (stream_pack && stream_gemm_supported(N, K)) {
+        CHK(dev_alloc(h, (void**)&l.wpk, (size_t)N * K * 2, false));
+        HIPCHK(launch_pack_stream_weights(w32, l.wpk, N, K, 0));
+    }
+    return HQT_OK;
+}
+
+static int load_block(hqt_handle* h, const std::string& p, BlockW& b) {
+    const int64_t D = h->cfg.embed_dim;
+    CHK(get_w(h, p + ".ln1.weight", {D}, &b.ln1_g));
+    CHK(get_w(h, p + ".ln1.bias", {D}, &b.ln1_b));
+    CHK(get_w(h, p + ".ln2.weight", {D}, &b.ln2_g));
+    CHK(get_w(h, p + ".ln2.bias", {D}, &b.ln2_b));
+    const float *wq, *wk, *wv, *bq, *bk, *bv, *w, *bias;
+    CHK(get_w(h, p + ".attn.query.weight", {D, D}, &wq));
+    CHK(get_w(h, p + ".attn.key.weight", {D, D}, &wk));
+    CHK(get_w(h, p + ".attn.value.weight", {D, D}, &wv));
+    CHK(get_w(h, p + ".attn.query.bias", {D}, &bq));
+    CHK(get_w(h, p + ".attn.key.bias", {D}, &bk));
+    CHK(get_w(h, p + ".attn.value.bias", {D}, &bv));
+    float *wqkv, *bqkv;                       // fused [query; key; value] rows
+    CHK(dev_alloc(h, (void**)&wqkv, (size_t)3 * D * D * 4, false));
+    CHK(dev_alloc(h, (void**)&bqkv, (size_t)3 * D * 4, false));
+    HIPCHK(hipMemcpy(wqkv, wq, D * D * 4, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(wqkv + D * D, wk, D * D * 4, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(wqkv + 2 * D * D, wv, D * D * 4, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(bqkv, bq, D * 4, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(bqkv + D, bk, D * 4, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(bqkv + 2 * D, bv, D * 4, hipMemcpyDeviceToDevice));
+    CHK(make_lin(h, b.qkv, wqkv, bqkv, 3 * D, D, true));
+    CHK(get_w(h, p + ".attn.proj.weight", {D, D}, &w));
+    CHK(get_w(h, p + ".attn.proj.bias", {D}, &bias));
+    CHK(make_lin(h, b.proj, w, bias, D, D, true));
+    CHK(get_w(h, p + ".mlp.0.weight", {4 * D, D}, &w));
+    CHK(get_w(h, p + ".mlp.0.bias", {4 * D}, &bias));
+    CHK(make_lin(h, b.fc1, w, bias, 4 * D, D, true));
+    CHK(get_w(h, p + ".mlp.2.weight", {D, 4 * D}, &w));
+    CHK(get_w(h, p + ".mlp.2.bias", {D}, &bias));
+    CHK(make_lin(h, b.fc2, w, bias, D, 4 * D, true));
+    return HQT_OK;
+}
+
+static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int ksz, Lin& l) {
+    const float *w, *b;
+    CHK(get_w(h, "stage1." + name + ".weight", {O, I, ksz, ksz}, &w));
+    CHK(get_w(h, "stage1." + name + ".bias", {O}, &b));
+    const int taps = ksz * ksz;
+    float* wt = const_cast<float*>(w);
+    if (taps > 1) {                          // [O][I][kh][kw] -> tap-major [O][kh*kw][I] (k = tap * I + i)
+        CHK(dev_alloc(h, (void**)&wt, (size_t)O * I * taps * 4, false));
+        HIPCHK(launch_repack_conv(w, wt, O, I, taps, 0));
+    }
+    return make_lin(h, l, wt, b, O, I * taps, false);
+}
+
+extern "C" int hqt_finalize_weights(hqt_handle* h) {
+    if (!h) return fail(HQT_ERR_INVALID, "null handle");
+    if (h->finalized) return HQT_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const hqt_config& c = h->cfg;
+    if (c.has_stage2) {
+        h->body.resize(c.n_layers);
+        h->depth.resize(c.n_layers_depth);
+        for (int i = 0; i < c.n_layers; ++i) CHK(load_block(h, "stage2.blocks." + std::to_string(i), h->body[i]));
+        for (int i = 0; i < c.n_layers_depth; ++i) CHK(load_block(h, "stage2.depths." + std::to_string(i), h->depth[i]));
+        const float* w;
+        const int64_t D = c.embed_dim;
+        CHK(get_w(h, "stage2.head_top.weight", {c.vocab_top, D}, &w));
+        CHK(make_lin(h, h->head_top, w, nullptr, c.vocab_top, D, true));
+        CHK(get_w(h, "stage2.head_bot.weight", {c.vocab_bot, D}, &w));
+        CHK(make_lin(h, h->head_bot, w, nullptr, c.vocab_bot, D, true));
+        // presence/shape checks of the remaining tensors happen here so that sample() cannot fail late
+        const float* t;
+        CHK(get_w(h, "stage2.ln_f.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_f.bias", {D}, &t));
+        CHK(get_w(h, "stage2.ln_top.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_top.bias", {D}, &t));
+        CHK(get_w(h, "stage2.ln_bot.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_bot.bias", {D}, &t));
+        CHK(get_w(h, "stage2.sos_depth", {1, 1, D}, &t));
+        CHK(get_w(h, "stage2.tok_emb_top.weight", {c.vocab_top, D}, &t));
+        CHK(get_w(h, "stage2.tok_emb_bot.weight", {c.vocab_bot, c.embedding_type == HQT_EMB_REDUCE ? D / 4 : D}, &t));
+        if (c.embedding_type == HQT_EMB_TRANSFORMER1) CHK(get_w(h, "stage2.pos_emb_emb.weight", {5, D}, &t));
+        CHK(get_w(h, "stage2.pos_emb_top.weight", {c.ctx_len_img, D}, &t));
+        CHK(get_w(h, "stage2.tok_emb_top_depth.weight", {c.vocab_top, D}, &t));
+        CHK(get_w(h, "stage2.pos_emb_depth.weight", {5, D}, &t));
+        if (c.cond_type == HQT_COND_CLASS) CHK(get_w(h, "stage2.sos.weight", {c.n_classes, D}, &t));
+        else if (c.cond_type == HQT_COND_TEXT) {
+            CHK(get_w(h, "stage2.tok_emb_txt.weight", {c.vocab_txt, D}, &t));
+            CHK(get_w(h, "stage2.pos_emb_txt.weight", {c.ctx_len_txt, D}, &t));
+        } else CHK(get_w(h, "stage2.sos", {1, 1, D}, &t));
+    }
+    if (c.has_stage1) {
+        const int E = c.s1_embed_dim;
+        const float* t;
+        CHK(get_w(h, "stage1.quantize_t.embedding", {c.s1_n_embed, 4 * E}, &t));
+        CHK(get_w(h, "stage1.quantize_b.embedding", {c.s1_n_embed, E}, &t));
+        CHK(load_conv(h, "post_quant_conv_b", c.s1_z_channels, 2 * E, 1, h->post_quant));
+        for (auto& l : h->dec) {
+            if (l.kind == 0 || l.kind == 3) CHK(load_conv(h, l.name, l.cout, l.cin, 3, l.conv1));
+            else if (l.kind == 1) {
+                CHK(get_w(h, "stage1." + l.name + ".norm1.weight", {l.cin}, &l.n1_g));
+                CHK(get_w(h, "stage1." + l.name + ".norm1.bias", {l.cin}, &l.n1_b));
+                CHK(get_w(h, "stage1." + l.name + ".norm2.weight", {l.cout}, &l.n2_g));
+                CHK(get_w(h, "stage1." + l.name + ".norm2.bias", {l.cout}, &l.n2_b));
+                CHK(load_conv(h, l.name + ".conv1", l.cout, l.cin, 3, l.conv1));
+                CHK(load_conv(h, l.name + ".conv2", l.cout, l.cout, 3, l.conv2));
+                if (l.cin != l.cout) CHK(load_conv(h, l.name + ".nin_shortcut", l.cout, l.cin, 1, l.nin));
+            } else if (l.kind == 2) {
+                CHK(get_w(h, "stage1." + l.name + ".norm.weight", {l.cin}, &l.n1_g));
+                CHK(get_w(h, "stage1." + l.name + ".norm.bias", {l.cin}, &l.n1_b));
+                CHK(load_conv(h, l.name + ".q", l.cin, l.cin, 1, l.q));
+                CHK(load_conv(h, l.name + ".k", l.cin, l.cin, 1, l.k));
+                CHK(load_conv(h, l.name + ".v", l.cin, l.cin, 1, l.v));
+                CHK(load_conv(h, l.name + ".proj_out", l.cin, l.cin, 1, l.proj));
+            } else {
+                CHK(get_w(h, "stage1.decoder.norm_out.weight", {l.cin}, &l.n1_g));
+                CHK(get_w(h, "stage1.decoder.norm_out.bias", {l.cin}, &l.n1_b));
+                CHK(load_conv(h, "decoder.conv_out", l.cout, l.cin, 3, l.conv1));
+            }
+        }
+    }
+    HIPCHK(hipDeviceSynchronize());
+    h->finalized = true;
+    return HQT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ GEMM dispatch
+struct Mode {
+    bool fast;
+    int act_dt() const { return fast ? DT_BF16 : DT_F32; }
+    size_t act_sz() const { return fast ? 2 : 4; }
+};
+
+// y = x W^T (+b)(act)(+resid): picks the MFMA kernels in FAST mode when the shape allows
+static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, int a_dt, int c_dt, hipStream_t st,
+                      const char* tag) {
+    g.N = l.N; g.K = l.K; g.ldb = l.K;
+    g.bias = l.b32;
+    if (g.alpha == 0.0f) g.alpha = 1.0f;
+    if (g.lda == 0) g.lda = l.K;
+    Timed t(h, tag, st);
+    if (md.fast) {
+        if (l.wpk && !g.conv_taps && stream_gemm_ok(g, a_dt, c_dt)) {
+            HIPCHK(launch_stream_gemm(g, l.wpk, a_dt, c_dt, h->splitk, h->splitk_elems, st));
+            return HQT_OK;
+        }
+        g.Bw = l.w16;
+        if (mfma_gemm_ok(g, a_dt, DT_BF16, c_dt)) { HIPCHK(launch_mfma_gemm(g, a_dt, DT_BF16, c_dt, st)); return HQT_OK; }
+        HIPCHK(launch_gemm_generic(g, a_dt, DT_BF16, c_dt, st));
+        return HQT_OK;
+    }
+    g.Bw = l.w32;
+    HIPCHK(launch_gemm_generic(g, DT_F32, DT_F32, DT_F32, st));
+    return HQT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ stage 2
+struct SampleCtx {
+    int B;
+    const int64_t* cond;
+    hqt_sample_opts o;
+    const float* noise;
+    const int64_t *feed_top, *feed_bot;
+    float* logits_out;
+    int64_t *out_top, *out_bot;
+    hipStream_t st;
+    Mode md;
+};
+
+static const float* W(hqt_handle* h, const char* name) { return h->w[std::string("stage2.") + name].d; }
+
+// One transformer block over M = B*Tq rows (stage2/layers.py:324-328,371-375)
+static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float* x, int Tq, void* kc, void* vc, int Tcache,
+                     int t_base, const int* t_base_dev, int causal) {
+    const int D = h->cfg.embed_dim, M = c.B * Tq;
+    const int adt = c.md.act_dt();
+    {
+        Timed t(h, "layernorm", c.st);
+        LNArgs ln{x, bw.ln1_g, bw.ln1_b, nullptr, h->hbuf, M, D, 1, 0, 1e-5f, adt};
+        HIPCHK(launch_layernorm(ln, c.st));
+    }
+    GemmArgs g{};
+    g.A = h->hbuf; g.M = M; g.batch = 1;
+    g.C = h->qbuf; g.C2 = kc; g.C3 = vc; g.ldc = D; g.qkv_D = D; g.store = STORE_QKV;
+    g.rows_per_group = Tq; g.group_stride = Tcache; g.row_offset = t_base; g.row_offset_dev = t_base_dev;
+    CHK(run_linear(h, c.md, g, bw.qkv, adt, adt, c.st, "gemm_qkv"));
+    {
+        Timed t(h, "attention", c.st);
+        AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, adt};
+        HIPCHK(launch_attention(a, c.st));
+    }
+    g = GemmArgs{};
+    g.A = h->abuf; g.M = M; g.batch = 1; g.C = x; g.ldc = D; g.resid = x; g.store = STORE_ROWS;
+    CHK(run_linear(h, c.md, g, bw.proj, adt, DT_F32, c.st, "gemm_proj"));
+    {
+        Timed t(h, "layernorm", c.st);
+        LNArgs ln{x, bw.ln2_g, bw.ln2_b, nullptr, h->hbuf, M, D, 1, 0, 1e-5f, adt};
+        HIPCHK(launch_layernorm(ln, c.st));
+    }
+    g = GemmArgs{};
+    g.A = h->hbuf; g.M = M; g.batch = 1; g.C = h->mbuf; g.ldc = 4 * D; g.store = STORE_ROWS;
+    g.act = h->cfg.gelu_approx ? ACT_GELU_SIGMOID : ACT_GELU_ERF;
+    CHK(run_linear(h, c.md, g, bw.fc1, adt, adt, c.st, "gemm_fc1"));
+    g = GemmArgs{};
+    g.A = h->mbuf; g.M = M; g.batch = 1; g.C = x; g.ldc = D; g.resid = x; g.store = STORE_ROWS;
+    CHK(run_linear(h, c.md, g, bw.fc2, adt, DT_F32, c.st, "gemm_fc2"));
+    return HQT_OK;
+}
+
+// Everything of one top position after the body input x is ready (hierarchical_ar.py:482-563,667-789)
+static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body_t_base, bool body_tbase_from_state) {
+    const hqt_config& cf = h->cfg;
+    const int D = cf.embed_dim, B = c.B, V = cf.vocab_top;
+    const int adt = c.md.act_dt();
+    const size_t esz = c.md.act_sz();
+    const size_t kv_layer = (size_t)cf.max_batch * h->Tmax * D * esz;
+    for (int l = 0; l < cf.n_layers; ++l)
+        CHK(run_block(h, c, h->body[l], h->x, Tq_body, (char*)h->kcache + l * kv_layer, (char*)h->vcache + l * kv_layer,
+                      h->Tmax, body_t_base, body_tbase_from_state ? &h->state->t_base : nullptr, 1));
+    {   // ln_f on the last token of each sample, + sos_depth (hierarchical_ar.py:561,684-686)
+        Timed t(h, "layernorm", c.st);
+        LNArgs ln{h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, 1e-5f, DT_F32};
+        HIPCHK(launch_layernorm(ln, c.st));
+    }
+    const size_t dkv_layer = (size_t)cf.max_batch * 5 * D * esz;
+    // ---- depth sub-step 0: top code
+    for (int l = 0; l < cf.n_layers_depth; ++l)
+        CHK(run_block(h, c, h->depth[l], h->xd, 1, (char*)h->dk + l * dkv_layer, (char*)h->dv + l * dkv_layer, 5, 0, nullptr, 0));
+    {
+        Timed t(h, "layernorm", c.st);
+        LNArgs ln{h->xd, W(h, "ln_top.weight"), W(h, "ln_top.bias"), nullptr, h->hbuf, B, D, 1, 0, 1e-5f, adt};
+        HIPCHK(launch_layernorm(ln, c.st));
+    }
+    GemmArgs g{};
+    g.A = h->hbuf; g.M = B; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
+    CHK(run_linear(h, c.md, g, h->head_top, adt, DT_F32, c.st, "gemm_head"));
+    {
+        Timed t(h, "sampler", c.st);
+        SamplerArgs s{h->logits, B, V, 1, B, c.o.temperature_top, c.o.top_k_top, c.o.top_p_top, c.noise, 0, c.o.seed,
+                      c.o.sample_offset, h->state, c.o.n_steps, c.out_top, c.logits_out};
+        HIPCHK(launch_sampler(s, c.st));
+    }
+    // ---- depth sub-step 1: four bottom codes in one pass
+    {
+        Timed t(h, "embed", c.st);
+        HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
+                                  h->xd, B, D, c.st));
+    }
+    for (int l = 0; l < cf.n_layers_depth; ++l)
+        CHK(run_block(h, c, h->depth[l], h->xd, 4, (char*)h->dk + l * dkv_layer, (char*)h->dv + l * dkv_layer, 5, 1, nullptr, 0));
+    {
+        Timed t(h, "layernorm", c.st);
+        LNArgs ln{h->xd, W(h, "ln_bot.weight"), W(h, "ln_bot.bias"), nullptr, h->hbuf, 4 * B, D, 1, 0, 1e-5f, adt};
+        HIPCHK(launch_layernorm(ln, c.st));
+    }
+    g = GemmArgs{};
+    g.A = h->hbuf; g.M = 4 * B; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
+    CHK(run_linear(h, c.md, g, h->head_bot, adt, DT_F32, c.st, "gemm_head"));
+    {
+        Timed t(h, "sampler", c.st);
+        SamplerArgs s{h->logits, 4 * B, V, 4, B, c.o.temperature_bot, c.o.top_k_bot, c.o.top_p_bot, c.noise, 1, c.o.seed,
+                      c.o.sample_offset, h->state, c.o.n_steps, c.out_bot, c.logits_out};
+        HIPCHK(launch_sampler(s, c.st));
+    }
+    return HQT_OK;
+}
+
+static int run_decode_step(hqt_handle* h, const SampleCtx& c) {      // one KV-cached position, Tq = 1
+    const hqt_config& cf = h->cfg;
+    {
+        Timed t(h, "embed", c.st);
+        EmbedArgs e{c.B, cf.embed_dim, c.o.n_steps, cf.embedding_type, cf.cond_type, h->state, c.cond,
+                    cf.cond_type == HQT_COND_CLASS ? W(h, "sos.weight") : (cf.cond_type == HQT_COND_NONE ? W(h, "sos") : nullptr),
+                    W(h, "tok_emb_top.weight"), W(h, "tok_emb_bot.weight"), W(h, "pos_emb_top.weight"),
+                    cf.embedding_type == HQT_EMB_TRANSFORMER1 ? W(h, "pos_emb_emb.weight") : nullptr,
+                    c.feed_top, c.feed_bot, h->x};
+        HIPCHK(launch_embed_step(e, c.st));
+    }
+    CHK(run_position(h, c, 1, 0, true));
+    HIPCHK(launch_advance_step(h->state, 1, c.st));
+    return HQT_OK;
+}
+
+extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_sample_opts* opts, const float* noise,
+                          const int64_t* force_top, const int64_t* force_bot, float* logits_out, int64_t* out_top,
+                          int64_t* out_bot, void* stream) {
+    if (!h || !opts || !out_top || !out_bot) return fail(HQT_ERR_INVALID, "null argument");
+    if (!h->finalized) return fail(HQT_ERR_STATE, "hqt_finalize_weights has not run");
+    const hqt_config& cf = h->cfg;
+    if (!cf.has_stage2) return fail(HQT_ERR_STATE, "handle was created without stage 2");
+    if (B < 1 || B > cf.max_batch) return fail(HQT_ERR_INVALID, "B=%d outside [1, max_batch=%d]", B, cf.max_batch);
+    if (opts->n_steps < 1 || opts->n_steps > cf.max_steps) return fail(HQT_ERR_INVALID, "n_steps=%d outside [1, %d]", opts->n_steps, cf.max_steps);
+    if (cf.cond_type != HQT_COND_NONE && !cond) return fail(HQT_ERR_INVALID, "cond is required for class/text conditioning");
+    if (!(opts->temperature_top > 0.f) || !(opts->temperature_bot > 0.f)) return fail(HQT_ERR_INVALID, "temperatures must be > 0");
+    if ((opts->top_p_top > 0.f || opts->top_p_bot > 0.f) && cf.vocab_top > 8192) return fail(HQT_ERR_INVALID, "top-p needs vocab <= 8192");
+    HIPCHK(hipSetDevice(h->device));
+    SampleCtx c;
+    c.B = B; c.cond = cond; c.o = *opts; c.noise = noise;
+    c.feed_top = force_top ? force_top : out_top;
+    c.feed_bot = force_bot ? force_bot : out_bot;
+    c.logits_out = logits_out; c.out_top = out_top; c.out_bot = out_bot;
+    c.st = (hipStream_t)stream;
+    c.md.fast = opts->precision == HQT_PRECISION_FAST;
+
+    HIPCHK(sampler_configure(cf.vocab_top, opts->top_p_top > 0.f || opts->top_p_bot > 0.f));
+    HIPCHK(launch_set_step(h->state, 0, 0, c.st));
+    int first = 0;
+    if (cf.cond_type == HQT_COND_TEXT) {     // 64-token causal prefill (sampling.py:187-190, layers.py:107-111)
+        const int T = cf.ctx_len_txt;
+        HIPCHK(launch_embed_text(cond, W(h, "tok_emb_txt.weight"), W(h, "pos_emb_txt.weight"), h->x, B, T, cf.embed_dim, c.st));
+        CHK(run_position(h, c, T, 0, false));
+        HIPCHK(launch_advance_step(h->state, T, c.st));
+        first = 1;
+    }
+    const int remaining = opts->n_steps - first;
+    if (remaining <= 0) return HQT_OK;
+    if (opts->use_graph && !h->timing) {
+        std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)cond, (uint64_t)noise, (uint64_t)c.feed_top, (uint64_t)c.feed_bot,
+                                     (uint64_t)logits_out, (uint64_t)out_top, (uint64_t)out_bot, (uint64_t)opts->precision,
+                                     (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot, opts->seed,
+                                     (uint64_t)opts->sample_offset};
+        uint32_t f[4];
+        memcpy(f, &opts->top_p_top, 4); memcpy(f + 1, &opts->top_p_bot, 4);
+        memcpy(f + 2, &opts->temperature_top, 4); memcpy(f + 3, &opts->temperature_bot, 4);
+        for (int i = 0; i < 4; ++i) key.push_back(f[i]);
+        if (!h->graph_exec || key != h->graph_key) {
+            if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            hipStream_t cs;
+            HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            SampleCtx cc = c;
+            cc.st = cs;
+            HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            int rc = run_decode_step(h, cc);
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamEndCapture(cs, &graph);
+            hipStreamDestroy(cs);
+            if (rc != HQT_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+            HIPCHK(e);
+            HIPCHK(hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+            h->graph_key = key;
+        }
+        for (int s = 0; s < remaining; ++s) HIPCHK(hipGraphLaunch(h->graph_exec, c.st));
+        return HQT_OK;
+    }
+    for (int s = 0; s < remaining; ++s) CHK(run_decode_step(h, c));
+    return HQT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ stage 1
+static const float* W1(hqt_handle* h, const std::string& name) { return h->w["stage1." + name].d; }
+
+static GemmArgs conv_args(const void* in, int nimg, int res_out, int cin, int taps, int upsample, void* out, int cout) {
+    GemmArgs g{};
+    g.A = in; g.conv_taps = taps; g.H = res_out; g.W = res_out; g.Cin = cin; g.upsample = upsample;
+    g.M = nimg * res_out * res_out; g.batch = 1;
+    g.C = out; g.ldc = cout; g.store = STORE_ROWS;
+    return g;
+}
+static void with_gn(GemmArgs& g, const float* stats, const float* gamma, const float* beta, int swish) {
+    g.gn_stats = stats; g.gn_gamma = gamma; g.gn_beta = beta; g.gn_groups = 32; g.gn_swish = swish;
+}
+
+static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64_t* code_b, int seq_layout, float* out,
+                        int clamp01, const Mode& md, hipStream_t st) {
+    const hqt_config& cf = h->cfg;
+    const int adt = md.act_dt();
+    const int r = h->dec.front().res, E = cf.s1_embed_dim;
+    float* gn1 = h->gn;
+    float* gn2 = h->gn + (size_t)h->dec_chunk * 64;
+    {
+        Timed t(h, "quant_gather", st);
+        QuantArgs q{code_t, code_b, seq_layout, W1(h, "quantize_t.embedding"), W1(h, "quantize_b.embedding"), h->quant, n, r, E, adt};
+        HIPCHK(launch_quant_gather(q, st));
+    }
+    void* cur = h->act[0];
+    void* t1 = h->act[1];
+    void* t2 = h->act[2];
+    {
+        GemmArgs g = conv_args(h->quant, n, r, 2 * E, 1, 0, cur, cf.s1_z_channels);
+        CHK(run_linear(h, md, g, h->post_quant, adt, adt, st, "conv1x1"));
+    }
+    for (auto& l : h->dec) {
+        const int res = l.res, hw = res * res;
+        if (l.kind == 0 || l.kind == 3) {
+            const int ro = l.kind == 3 ? 2 * res : res;
+            GemmArgs g = conv_args(cur, n, ro, l.cin, 9, l.kind == 3, t1, l.cout);
+            CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
+            std::swap(cur, t1);
+        } else if (l.kind == 1) {               // ResnetBlock (stage1/modules/layers.py:115-133)
+            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(cur, adt, gn1, n, hw, l.cin, 32, 1e-6f, st)); }
+            GemmArgs g = conv_args(cur, n, res, l.cin, 9, 0, t1, l.cout);
+            with_gn(g, gn1, l.n1_g, l.n1_b, 1);
+            CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
+            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(t1, adt, gn2, n, hw, l.cout, 32, 1e-6f, st)); }
+            const void* shortcut = cur;
+            void* outbuf = t2;
+            if (l.cin != l.cout) {
+                GemmArgs s = conv_args(cur, n, res, l.cin, 1, 0, t2, l.cout);
+                CHK(run_linear(h, md, s, l.nin, adt, adt, st, "conv1x1"));
+                shortcut = t2;
+                outbuf = cur;                   // x is dead once the shortcut is computed
+            }
+            g = conv_args(t1, n, res, l.cout, 9, 0, outbuf, l.cout);
+            with_gn(g, gn2, l.n2_g, l.n2_b, 1);
+            g.resid = shortcut;
+            CHK(run_linear(h, md, g, l.conv2, adt, adt, st, "conv3x3"));
+            if (outbuf == t2) std::swap(cur, t2);
+        } else if (l.kind == 2) {               // AttnBlock (stage1/modules/layers.py:163-186)
+            const int C = l.cin;
+            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(cur, adt, gn1, n, hw, C, 32, 1e-6f, st)); }
+            GemmArgs g = conv_args(cur, n, res, C, 1, 0, h->aq, C);
+            with_gn(g, gn1, l.n1_g, l.n1_b, 0);
+            CHK(run_linear(h, md, g, l.q, adt, adt, st, "conv1x1"));
+            g = conv_args(cur, n, res, C, 1, 0, h->ak, C);
+            with_gn(g, gn1, l.n1_g, l.n1_b, 0);
+            CHK(run_linear(h, md, g, l.k, adt, adt, st, "conv1x1"));
+            g = conv_args(cur, n, res, C, 1, 0, h->av, C);
+            with_gn(g, gn1, l.n1_g, l.n1_b, 0);
+            g.store = STORE_NCHW; g.rows_per_image = hw;                 // V^T per image: [C][hw]
+            CHK(run_linear(h, md, g, l.v, adt, adt, st, "conv1x1"));
+            {   // S[i, j] = q_i . k_j * C^-0.5
+                Timed t(h, "attn_gemm", st);
+                GemmArgs s{};
+                s.A = h->aq; s.lda = C; s.a_batch_stride = (long long)hw * C;
+                s.Bw = h->ak; s.ldb = C; s.b_batch_stride = (long long)hw * C;
+                s.C = h->as; s.ldc = hw; s.c_batch_stride = (long long)hw * hw;
+                s.M = hw; s.N = hw; s.K = C; s.batch = n; s.alpha = 1.0f / sqrtf((float)C); s.store = STORE_ROWS;
+                if (md.fast && mfma_gemm_ok(s, adt, adt, adt)) HIPCHK(launch_mfma_gemm(s, adt, adt, adt, st));
+                else HIPCHK(launch_gemm_generic(s, adt, adt, adt, st));
+            }
+            { Timed t(h, "softmax", st); HIPCHK(launch_softmax_rows(h->as, adt, n * hw, hw, st)); }
+            {   // o[i, c] = sum_j w[i, j] v[c, j]
+                Timed t(h, "attn_gemm", st);
+                GemmArgs s{};
+                s.A = h->as; s.lda = hw; s.a_batch_stride = (long long)hw * hw;
+                s.Bw = h->av; s.ldb = hw; s.b_batch_stride = (long long)hw * C;
+                s.C = h->ao; s.ldc = C; s.c_batch_stride = (long long)hw * C;
+                s.M = hw; s.N = C; s.K = hw; s.batch = n; s.alpha = 1.0f; s.store = STORE_ROWS;
+                if (md.fast && mfma_gemm_ok(s, adt, adt, adt)) HIPCHK(launch_mfma_gemm(s, adt, adt, adt, st));
+                else HIPCHK(launch_gemm_generic(s, adt, adt, adt, st));
+            }
+            g = conv_args(h->ao, n, res, C, 1, 0, t1, C);
+            g.resid = cur;
+            CHK(run_linear(h, md, g, l.proj, adt, adt, st, "conv1x1"));
+            std::swap(cur, t1);
+        } else {                                // norm_out -> swish -> conv_out, NCHW fp32 (+clamp)
+            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(cur, adt, gn1, n, hw, l.cin, 32, 1e-6f, st)); }
+            GemmArgs g = conv_args(cur, n, res, l.cin, 9, 0, out, l.cout);
+            with_gn(g, gn1, l.n1_g, l.n1_b, 1);
+            g.store = STORE_NCHW; g.rows_per_image = hw; g.clamp01 = clamp01;
+            CHK(run_linear(h, md, g, l.conv1, adt, DT_F32, st, "conv_out"));
+        }
+    }
+    return HQT_OK;
+}
+
+static int decode_impl(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_b, int seq_layout, float* out,
+                       int clamp01, int precision, void* stream) {
+    if (!h || !out) return fail(HQT_ERR_INVALID, "null argument");
+    if (!h->finalized) return fail(HQT_ERR_STATE, "hqt_finalize_weights has not run");
+    if (!h->cfg.has_stage1) return fail(HQT_ERR_STATE, "handle was created without stage 1");
+    if (!code_t && !code_b) return fail(HQT_ERR_INVALID, "code_t and code_b are both NULL");
+    if (B < 1) return fail(HQT_ERR_INVALID, "B must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    Mode md;
+    md.fast = precision == HQT_PRECISION_FAST;
+    const int r = h->dec.front().res, rt = r / 2;
+    const size_t out_per = (size_t)h->cfg.s1_out_ch * h->dec.back().res * h->dec.back().res;
+    for (int b0 = 0; b0 < B; b0 += h->dec_chunk) {
+        const int n = std::min(h->dec_chunk, B - b0);
+        const int64_t* ct = code_t ? code_t + (size_t)b0 * rt * rt : nullptr;
+        const int64_t* cb = code_b ? code_b + (size_t)b0 * r * r : nullptr;       // both layouts hold r*r codes per image
+        CHK(decode_chunk(h, n, ct, cb, seq_layout, out + (size_t)b0 * out_per, clamp01, md, (hipStream_t)stream));
+    }
+    return HQT_OK;
+}
+extern "C" int hqt_decode(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_b, float* out, int clamp01,
+                          int precision, void* stream) {
+    return decode_impl(h, B, code_t, code_b, 0, out, clamp01, precision, stream);
+}
+extern "C" int hqt_decode_seq(hqt_handle* h, int B, const int64_t* codes_top, const int64_t* codes_bot, float* out,
+                              int clamp01, int precision, void* stream) {
+    return decode_impl(h, B, codes_top, codes_bot, 1, out, clamp01, precision, stream);
+}
+
+// ------------------------------------------------------------------------------------------ introspection
+extern "C" int64_t hqt_param_count(const hqt_handle* h, int stage) { return (h && (stage == 1 || stage == 2)) ? h->params[stage] : -1; }
+extern "C" int64_t hqt_workspace_bytes(const hqt_handle* h) { return h ? (int64_t)h->workspace_bytes : -1; }
+extern "C" int hqt_timing_enable(hqt_handle* h, int on) { if (!h) return fail(HQT_ERR_INVALID, "null"); h->timing = on != 0; return HQT_OK; }
+extern "C" int hqt_timing_reset(hqt_handle* h) {
+    if (!h) return fail(HQT_ERR_INVALID, "null");
+    timing_collect(h);
+    for (auto& s : h->slots) { s.launches = 0; s.total_ms = 0.0; }
+    return HQT_OK;
+}
+extern "C" int hqt_timing_slots(const hqt_handle* h) { return h ? (int)h->slots.size() : -1; }
+extern "C" int hqt_timing_get(hqt_handle* h, int slot, char* name, int name_len, int64_t* launches, double* total_ms) {
+    if (!h || slot < 0 || slot >= (int)h->slots.size()) return fail(HQT_ERR_INVALID, "bad slot");
+    timing_collect(h);
+    const TimingSlot& s = h->slots[slot];
+    if (name && name_len > 0) { strncpy(name, s.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (launches) *launches = s.launches;
+    if (total_ms) *total_ms = s.total_ms;
+    return HQT_OK;
+}

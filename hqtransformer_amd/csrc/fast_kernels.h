@@ -1,0 +1,20 @@
+// FAST-precision kernels: bf16 MFMA GEMMs (weight-streaming skinny GEMM for the AR loop, tiled
+// implicit-GEMM for the decoder) plus the weight repack/convert passes run at finalize.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
+// [O][I][taps] -> [O][taps][I]
+hipError_t launch_repack_conv(const float* src, float* dst, int O, int I, int taps, hipStream_t st);
+
+// ---- weight-streaming GEMM (AR loop, M = B or 4B rows): y[M,N] = x[M,K] W[N,K]^T, W pre-packed
+bool stream_gemm_supported(int N, int K);
+hipError_t launch_pack_stream_weights(const float* w32, bf16_t* packed, int N, int K, hipStream_t st);
+bool stream_gemm_ok(const GemmArgs& g, int a_dt, int c_dt);
+hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, float* splitk, size_t splitk_elems,
+                              hipStream_t st);
+
+// ---- tiled MFMA GEMM / implicit-GEMM conv (decoder, text prefill)
+bool mfma_gemm_ok(const GemmArgs& g, int a_dt, int b_dt, int c_dt);
+hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hipStream_t st);

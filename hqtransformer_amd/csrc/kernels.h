@@ -1,0 +1,104 @@
+// Host-side launch wrappers of every kernel in libhqt.so.  All asynchronous on `st`.
+#pragma once
+#include "common.h"
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+// generic GEMM (vector ALUs).  ta/tb/tc are DT_*.
+hipError_t launch_gemm_generic(const GemmArgs& g, int ta, int tb, int tc, hipStream_t st);
+
+struct EmbedArgs {
+    int B, D, n_steps;
+    int embedding;               // HQT_EMB_*
+    int cond_type;               // HQT_COND_*
+    const StepState* state;      // position = state->step
+    const int64_t* cond;         // [B] class ids (class-cond)
+    const float* sos;            // class: [n_classes, D]; uncond: [D]
+    const float* tok_top;        // [V, D]
+    const float* tok_bot;        // [V, D] or [V, D/4]
+    const float* pos_top;        // [ctx_img, D]
+    const float* pos_emb;        // [5, D] (transformer1)
+    const int64_t* codes_top;    // [B, n_steps]    (drawn or teacher-forced)
+    const int64_t* codes_bot;    // [B, n_steps, 4]
+    float* x;                    // [B, D]
+};
+hipError_t launch_embed_step(const EmbedArgs& a, hipStream_t st);
+
+// text prefix: x[b, t, :] = tok_emb_txt[cond[b, t]] + pos_emb_txt[t]
+hipError_t launch_embed_text(const int64_t* cond, const float* tok, const float* pos, float* x, int B, int T, int D,
+                             hipStream_t st);
+
+// depth sub-step 1 input: x[b*4+s, :] = tok_top_depth[top[b, step]] + pos_depth[s]
+hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
+                              const float* pos, float* x, int B, int D, hipStream_t st);
+
+struct LNArgs {
+    const float* x;              // [rows_in, D]
+    const float* gamma;
+    const float* beta;
+    const float* add;            // optional [D] vector added after the affine (sos_depth)
+    void* y;                     // [M, D] fp32 or bf16
+    int M, D;
+    int in_rows_per_group;       // input row = m * in_rows_per_group + in_row_offset  (pick one token per sample)
+    int in_row_offset;
+    float eps;
+    int out_dtype;               // DT_*
+};
+hipError_t launch_layernorm(const LNArgs& a, hipStream_t st);
+
+struct AttnArgs {
+    const void* q;               // [B*Tq, D]
+    const void* kcache;          // [B, Tmax, D]
+    const void* vcache;
+    void* out;                   // [B*Tq, D]
+    int B, Tq, n_heads, head_dim, Tmax;
+    int t_base;                  // keys already cached before this call's Tq tokens
+    const int* t_base_dev;       // optional device int added to t_base
+    int causal;                  // 1: query i sees keys [0, t_base + i]; 0: all t_base + Tq keys
+    int dtype;                   // DT_* of q / cache / out
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
+
+struct SamplerArgs {
+    const float* logits;         // [R, V], row r = b * slots + slot
+    int R, V, slots, B;
+    float temperature;
+    int top_k;                   // <= 0: none
+    float top_p;                 // <= 0: none
+    const float* noise;          // [n_steps, 5, B, V] or NULL
+    int draw0;                   // first draw index of slot 0 (0 for top, 1 for bottom)
+    uint64_t seed;
+    int64_t sample_offset;
+    const StepState* state;
+    int n_steps;
+    int64_t* out;                // top: [B, n_steps]; bottom: [B, n_steps, 4]
+    float* logits_out;           // optional [n_steps, 5, B, V]
+};
+hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
+// raises the dynamic-LDS limit of the sampler for (V, top-p) outside any stream capture
+hipError_t sampler_configure(int V, bool use_top_p);
+
+hipError_t launch_advance_step(StepState* state, int d_tbase, hipStream_t st);
+hipError_t launch_set_step(StepState* state, int step, int t_base, hipStream_t st);
+
+// int64 codes [B, n_steps(,4)] written by the sampler are final; this copies forced codes into the
+// feed-back arrays when teacher forcing is on.
+// ---- decoder
+struct QuantArgs {
+    const int64_t* code_t;       // grid [B, r/2, r/2] or seq [B, (r/2)^2]; NULL = zeros
+    const int64_t* code_b;       // grid [B, r, r] or seq [B, (r/2)^2, 4]; NULL = zeros
+    int seq_layout;              // 1: sampler layout (rearranges folded into the addressing)
+    const float* emb_t;          // [n_embed, 4*E]
+    const float* emb_b;          // [n_embed, E]
+    void* quant;                 // NHWC [B, r, r, 2E]
+    int B, r, E;
+    int out_dtype;
+};
+hipError_t launch_quant_gather(const QuantArgs& a, hipStream_t st);
+
+// GroupNorm statistics over NHWC x: stats[b][g] = (mean, rstd)
+hipError_t launch_gn_stats(const void* x, int dtype, float* stats, int B, int HW, int C, int groups, float eps,
+                           hipStream_t st);
+
+// in-place softmax over the last axis of fp32 [rows, n]
+hipError_t launch_softmax_rows(void* x, int dtype, int rows, int n, hipStream_t st);

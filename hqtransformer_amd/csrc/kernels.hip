@@ -1,0 +1,514 @@
+// Small kernels of the HQ-Transformer sampling path: embeddings, LayerNorm, KV-cache attention, the
+// fused sampler, codebook gather, GroupNorm statistics.  gfx950 only (wave = 64).
+#include "kernels.h"
+#include "gemm_generic.h"
+
+// ---------------------------------------------------------------------------------------------
+// reductions (256-thread workgroups = 4 waves), deterministic for a fixed launch shape
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, 64));
+    return v;
+}
+template <typename T, typename Op>
+__device__ __forceinline__ T block_reduce(T v, Op op, T* scratch /* >= 4 */) {
+    v = wave_reduce(v, op);
+    const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wid] = v;
+    __syncthreads();
+    T r = scratch[0];
+    for (int i = 1; i < nw; ++i) r = op(r, scratch[i]);
+    return r;
+}
+struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { return a + b; } };
+struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
+struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { return a < b ? a : b; } };
+
+// ---------------------------------------------------------------------------------------------
+// step state
+// ---------------------------------------------------------------------------------------------
+__global__ void advance_step_kernel(StepState* s, int d_tbase) { s->step += 1; s->t_base += d_tbase; }
+__global__ void set_step_kernel(StepState* s, int step, int t_base) { s->step = step; s->t_base = t_base; }
+hipError_t launch_advance_step(StepState* s, int d_tbase, hipStream_t st) {
+    advance_step_kernel<<<1, 1, 0, st>>>(s, d_tbase);
+    return hipGetLastError();
+}
+hipError_t launch_set_step(StepState* s, int step, int t_base, hipStream_t st) {
+    set_step_kernel<<<1, 1, 0, st>>>(s, step, t_base);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// A3/K1: input embedding of one top position (hierarchical_ar.py:493-544)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_step_kernel(EmbedArgs a) {
+    const int b = blockIdx.x, D = a.D;
+    const int step = a.state->step;
+    float* x = a.x + (long long)b * D;
+    if (step == 0) {
+        const float* src = a.cond_type == 1 ? a.sos + a.cond[b] * (long long)D : a.sos;
+        for (int d = threadIdx.x; d < D; d += blockDim.x) x[d] = src[d];
+        return;
+    }
+    const int p = step - 1;
+    const long long ct = a.codes_top[(long long)b * a.n_steps + p];
+    long long cb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) cb[s] = a.codes_bot[((long long)b * a.n_steps + p) * 4 + s];
+    if (a.embedding == 1) {                      // 'reduce': channel k*4+slot of the bottom part (:522-526)
+        const int Dq = D / 4;
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            const float top = a.tok_top[ct * D + d] + a.pos_top[(long long)p * D + d];
+            x[d] = top + a.tok_bot[cb[d & 3] * Dq + (d >> 2)];
+        }
+    } else {                                     // 'transformer1': mean over the 5 tokens (:535-544)
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            float s = (a.tok_top[ct * D + d] + a.pos_top[(long long)p * D + d]) + a.pos_emb[d];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += a.tok_bot[cb[k] * D + d] + a.pos_emb[(1 + k) * D + d];
+            x[d] = s / 5.0f;
+        }
+    }
+}
+hipError_t launch_embed_step(const EmbedArgs& a, hipStream_t st) {
+    embed_step_kernel<<<a.B, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* cond, const float* tok, const float* pos,
+                                                         float* x, int T, int D) {
+    const int row = blockIdx.x, t = row % T;
+    const long long id = cond[row];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long long)row * D + d] = tok[id * D + d] + pos[(long long)t * D + d];
+}
+hipError_t launch_embed_text(const int64_t* cond, const float* tok, const float* pos, float* x, int B, int T, int D,
+                             hipStream_t st) {
+    embed_text_kernel<<<B * T, 256, 0, st>>>(cond, tok, pos, x, T, D);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void depth_embed_kernel(const int64_t* codes_top, int n_steps, const StepState* state,
+                                                          const float* tok, const float* pos, float* x, int D) {
+    const int row = blockIdx.x, b = row >> 2, s = row & 3;
+    const long long code = codes_top[(long long)b * n_steps + state->step];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long long)row * D + d] = tok[code * D + d] + pos[(long long)s * D + d];
+}
+hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
+                              const float* pos, float* x, int B, int D, hipStream_t st) {
+    depth_embed_kernel<<<B * 4, 256, 0, st>>>(codes_top, n_steps, state, tok, pos, x, D);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-5), two-pass, one workgroup per row
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(LNArgs a) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, D = a.D;
+    const float* x = a.x + ((long long)m * a.in_rows_per_group + a.in_row_offset) * D;
+    float s = 0.0f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) s += x[d];
+    const float mean = block_reduce(s, OpAdd(), red) / (float)D;
+    float v = 0.0f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) { const float t = x[d] - mean; v += t * t; }
+    const float var = block_reduce(v, OpAdd(), red) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    TO* y = reinterpret_cast<TO*>(a.y) + (long long)m * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float t = (x[d] - mean) * rstd * a.gamma[d] + a.beta[d];
+        if (a.add) t += a.add[d];
+        st1<TO>(y + d, t);
+    }
+}
+hipError_t launch_layernorm(const LNArgs& a, hipStream_t st) {
+    if (a.out_dtype == DT_BF16) layernorm_kernel<bf16_t><<<a.M, 256, 0, st>>>(a);
+    else layernorm_kernel<float><<<a.M, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// A4/K3: KV-cache attention, one wave per (sample, head, query) -- stage2/layers.py:93-102,183-187.
+// The scale 1/sqrt(hs) is applied to K before the product, as the reference does (:102).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* qs = reinterpret_cast<float*>(smem_raw);            // [hs]
+    float* ps = qs + a.head_dim;                               // [Tmax]
+    const int lane = threadIdx.x;
+    const int gid = blockIdx.x;
+    const int qi = gid % a.Tq;
+    const int h = (gid / a.Tq) % a.n_heads;
+    const int b = gid / (a.Tq * a.n_heads);
+    const int hs = a.head_dim, D = a.n_heads * hs;
+    const int tb = a.t_base + (a.t_base_dev ? *a.t_base_dev : 0);
+    const int nkeys = a.causal ? tb + qi + 1 : tb + a.Tq;
+    const T* q = reinterpret_cast<const T*>(a.q) + ((long long)(b * a.Tq + qi)) * D + h * hs;
+    const T* kc = reinterpret_cast<const T*>(a.kcache) + (long long)b * a.Tmax * D + h * hs;
+    const T* vc = reinterpret_cast<const T*>(a.vcache) + (long long)b * a.Tmax * D + h * hs;
+    for (int d = lane; d < hs; d += 64) qs[d] = ld1<T>(q + d);
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)hs);
+    float lmax = -INFINITY;
+    for (int j = lane; j < nkeys; j += 64) {
+        const T* kr = kc + (long long)j * D;
+        float s = 0.0f;
+        for (int d = 0; d < hs; d += 4) {
+            float kv[4];
+            ld4<T>(kr + d, kv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s = fmaf(qs[d + i], kv[i] * scale, s);
+        }
+        ps[j] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    lmax = wave_reduce(lmax, OpMax());
+    float lsum = 0.0f;
+    for (int j = lane; j < nkeys; j += 64) { const float e = expf(ps[j] - lmax); ps[j] = e; lsum += e; }
+    lsum = wave_reduce(lsum, OpAdd());
+    __syncthreads();
+    for (int j = lane; j < nkeys; j += 64) ps[j] = ps[j] / lsum;
+    __syncthreads();
+    T* o = reinterpret_cast<T*>(a.out) + ((long long)(b * a.Tq + qi)) * D + h * hs;
+    for (int d = lane; d < hs; d += 64) {
+        float acc = 0.0f;
+        for (int j = 0; j < nkeys; ++j) acc = fmaf(ps[j], ld1<T>(vc + (long long)j * D + d), acc);
+        st1<T>(o + d, acc);
+    }
+}
+hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
+    const size_t smem = (size_t)(a.head_dim + a.Tmax) * sizeof(float);
+    const int grid = a.B * a.n_heads * a.Tq;
+    if (a.dtype == DT_BF16) attention_kernel<bf16_t><<<grid, 64, smem, st>>>(a);
+    else attention_kernel<float><<<grid, 64, smem, st>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// A7/K6: fused sampler -- temperature, top-k, softmax, top-p, argmax(p / q), code write-back.
+// One 256-thread workgroup per logits row.  Restates hqvae/utils/sampling.py:12-37 and
+// hierarchical_ar.py:762-785; torch.multinomial(p, 1) == argmax(p / q), q ~ Exp(1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // layout: double dsum[256]; float redf[4]; int redi[4]; unsigned hist[256]; int sel[4]; float lp[V];
+    //         (top-p only) float skey[n2]; unsigned short sidx[n2]; unsigned char keep[V]
+    double* dsum = reinterpret_cast<double*>(smem_raw);
+    float* redf = reinterpret_cast<float*>(dsum + 256);
+    int* redi = reinterpret_cast<int*>(redf + 4);
+    unsigned* hist = reinterpret_cast<unsigned*>(redi + 4);
+    int* sel = reinterpret_cast<int*>(hist + 256);
+    float* lp = reinterpret_cast<float*>(sel + 4);
+    const int V = a.V, tid = threadIdx.x;
+    float* skey = lp + V;
+    unsigned short* sidx = reinterpret_cast<unsigned short*>(skey + n2);
+    unsigned char* keep = reinterpret_cast<unsigned char*>(sidx + n2);
+
+    const int r = blockIdx.x, b = r / a.slots, slot = r % a.slots;
+    const int step = a.state->step;
+    const int draw = a.draw0 + slot;
+    const float* lg = a.logits + (long long)r * V;
+    const long long nidx = (((long long)step * 5 + draw) * a.B + b) * V;
+
+    // ---- temperature (logits /= T, hierarchical_ar.py:763,779) and raw-logit dump
+    for (int i = tid; i < V; i += 256) {
+        const float v = lg[i];
+        if (a.logits_out) a.logits_out[nidx + i] = v;
+        lp[i] = v / a.temperature;
+    }
+    __syncthreads();
+
+    // ---- top-k: exact k-th largest by 4-pass radix select, keep >= threshold (sampling.py:12-19)
+    if (a.top_k > 0 && a.top_k < V) {
+        uint32_t prefix = 0;
+        int remaining = a.top_k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t himask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
+            for (int i = tid; i < V; i += 256) {
+                const uint32_t o = f2ord(lp[i]);
+                if ((o & himask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, bin = 255;
+                for (; bin > 0; --bin) {
+                    if (cum + (int)hist[bin] >= remaining) break;
+                    cum += (int)hist[bin];
+                }
+                sel[0] = bin;
+                sel[1] = remaining - cum;
+            }
+            __syncthreads();
+            prefix |= ((uint32_t)sel[0]) << shift;
+            remaining = sel[1];
+            __syncthreads();
+        }
+        for (int i = tid; i < V; i += 256)
+            if (f2ord(lp[i]) < prefix) lp[i] = -INFINITY;
+        __syncthreads();
+    }
+
+    // ---- softmax (fp32): p = exp(l - max) / sum
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, lp[i]);
+    m = block_reduce(m, OpMax(), redf);
+    float s = 0.0f;
+    for (int i = tid; i < V; i += 256) { const float e = expf(lp[i] - m); lp[i] = e; s += e; }
+    s = block_reduce(s, OpAdd(), redf);
+    for (int i = tid; i < V; i += 256) lp[i] = lp[i] / s;
+    __syncthreads();
+
+    // ---- top-p (sampling.py:22-37): descending sort, prefix sums accumulated in double and rounded
+    //      to fp32 per element (what torch.cumsum does on the CPU), cut after the first prefix >= p
+    float renorm = 1.0f;
+    const bool use_p = a.top_p > 0.0f;
+    if (use_p) {
+        for (int i = tid; i < n2; i += 256) {
+            skey[i] = i < V ? lp[i] : -1.0f;
+            sidx[i] = (unsigned short)i;
+        }
+        __syncthreads();
+        for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < n2; i += 256) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const float ka = skey[i], kb = skey[ixj];
+                        const unsigned short ia = sidx[i], ib = sidx[ixj];
+                        const bool a_first = ka > kb || (ka == kb && ia < ib);   // order: prob desc, index asc
+                        const bool up = (i & k2) == 0;
+                        if (up ? !a_first : a_first) { skey[i] = kb; skey[ixj] = ka; sidx[i] = ib; sidx[ixj] = ia; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const int chunk = n2 / 256;
+        double local = 0.0;
+        for (int c = 0; c < chunk; ++c) { const int j = tid * chunk + c; if (j < V) local += (double)skey[j]; }
+        dsum[tid] = local;
+        __syncthreads();
+        if (tid == 0) {
+            double run = 0.0;
+            for (int t = 0; t < 256; ++t) { const double v = dsum[t]; dsum[t] = run; run += v; }
+        }
+        __syncthreads();
+        double run = dsum[tid];
+        int first = V;                                   // first sorted position whose prefix >= p
+        for (int c = 0; c < chunk; ++c) {
+            const int j = tid * chunk + c;
+            if (j < V) {
+                run += (double)skey[j];
+                if ((float)run >= a.top_p && j < first) first = j;
+            }
+        }
+        first = block_reduce(first, OpMin(), redi);
+        for (int i = tid; i < V; i += 256) keep[i] = 0;
+        __syncthreads();
+        for (int j = tid; j < V; j += 256)
+            if (j <= first) keep[sidx[j]] = 1;           // position `first` itself is kept (shifted mask)
+        __syncthreads();
+        float ks = 0.0f;
+        for (int i = tid; i < V; i += 256) { if (!keep[i]) lp[i] = 0.0f; ks += lp[i]; }
+        renorm = block_reduce(ks, OpAdd(), redf);
+        __syncthreads();
+    }
+
+    // ---- draw: argmax_i p_i / q_i, lowest index on ties
+    float best = -1.0f;
+    int besti = 0;
+    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+    const uint64_t grow = (uint64_t)(a.sample_offset + b);
+    for (int i4 = tid; i4 * 4 < V; i4 += 256) {
+        float q[4];
+        if (a.noise) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = (i4 * 4 + e < V) ? a.noise[nidx + i4 * 4 + e] : 1.0f;
+        } else {
+            uint32_t rnd[4];
+            philox4x32_10((uint32_t)i4, (uint32_t)(step * 5 + draw), (uint32_t)grow, (uint32_t)(grow >> 32), k0, k1, rnd);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = -logf(((float)(rnd[e] >> 8) + 0.5f) * (1.0f / 16777216.0f));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i4 * 4 + e;
+            if (i < V) {
+                float p = lp[i];
+                if (use_p) p = p / renorm;
+                const float ratio = p / q[e];
+                if (ratio > best) { best = ratio; besti = i; }      // ascending i per lane: first max wins
+            }
+        }
+    }
+    // reduce (value desc, index asc)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(besti, off, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { redf[tid >> 6] = best; redi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (redf[w] > best || (redf[w] == best && redi[w] < besti)) { best = redf[w]; besti = redi[w]; }
+        a.out[((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
+    }
+}
+
+static size_t sampler_smem(int V, bool use_p, int& n2) {
+    n2 = 256;
+    while (n2 < V) n2 <<= 1;
+    size_t sz = 256 * sizeof(double) + 4 * sizeof(float) + 4 * sizeof(int) + 256 * sizeof(unsigned) + 4 * sizeof(int) +
+                (size_t)V * sizeof(float);
+    if (use_p) sz += (size_t)n2 * sizeof(float) + (size_t)n2 * sizeof(unsigned short) + (size_t)V;
+    return (sz + 15) & ~(size_t)15;
+}
+static size_t g_sampler_configured = 0;
+hipError_t sampler_configure(int V, bool use_top_p) {
+    int n2;
+    const size_t smem = sampler_smem(V, use_top_p, n2);
+    if (smem > 160 * 1024 || (use_top_p && V > 65536)) return hipErrorInvalidValue;
+    if (smem > g_sampler_configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        g_sampler_configured = smem;
+    }
+    return hipSuccess;
+}
+hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
+    int n2;
+    const size_t smem = sampler_smem(a.V, a.top_p > 0.0f, n2);
+    if (smem > g_sampler_configured) return hipErrorInvalidValue;     // sampler_configure must run first
+    sampler_kernel<<<a.R, 256, smem, st>>>(a, n2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// A9/A10/A13: codebook gather + PixelShuffle(2) + concat, NHWC output
+// (quantizer.py:179-186, generator.py:316-318,361-364; sampling_hqmodel.py:119-120)
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void quant_gather_kernel(QuantArgs a) {
+    const int pix = blockIdx.x;                      // b * r * r + Y * r + X
+    const int r = a.r, rt = r / 2, E = a.E;
+    const int b = pix / (r * r), Y = (pix / r) % r, X = pix % r;
+    long long ct = -1, cb = -1;
+    if (a.code_t) ct = a.code_t[((long long)b * rt + (Y >> 1)) * rt + (X >> 1)];
+    if (a.code_b) {
+        if (a.seq_layout) cb = a.code_b[(((long long)b * rt + (Y >> 1)) * rt + (X >> 1)) * 4 + (Y & 1) * 2 + (X & 1)];
+        else cb = a.code_b[((long long)b * r + Y) * r + X];
+    }
+    TO* out = reinterpret_cast<TO*>(a.quant) + (long long)pix * 2 * E;
+    const int sub = (Y & 1) * 2 + (X & 1);
+    for (int c = threadIdx.x; c < 2 * E; c += blockDim.x) {
+        float v = 0.0f;
+        if (c < E) { if (ct >= 0) v = a.emb_t[ct * 4 * E + 4 * c + sub]; }        // out[c, 2h+i, 2w+j] = in[4c+2i+j, h, w]
+        else if (cb >= 0) v = a.emb_b[cb * E + (c - E)];
+        st1<TO>(out + c, v);
+    }
+}
+hipError_t launch_quant_gather(const QuantArgs& a, hipStream_t st) {
+    const int grid = a.B * a.r * a.r;
+    if (a.out_dtype == DT_BF16) quant_gather_kernel<bf16_t><<<grid, 256, 0, st>>>(a);
+    else quant_gather_kernel<float><<<grid, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics (32 groups, eps 1e-6; stage1/modules/layers.py:17-21), NHWC input.
+// One workgroup per (sample, group); sums in double.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, float* stats, int HW, int C, int groups, float eps) {
+    __shared__ double red[4];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups;
+    const T* base = x + (long long)b * HW * C + g * cpg;
+    const long long n = (long long)HW * cpg;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) s += (double)ld1<T>(base + (i / cpg) * C + (i % cpg));
+    const double mean = block_reduce(s, OpAdd(), red) / (double)n;
+    double v = 0.0;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const double t = (double)ld1<T>(base + (i / cpg) * C + (i % cpg)) - mean;
+        v += t * t;
+    }
+    const double var = block_reduce(v, OpAdd(), red) / (double)n;
+    if (threadIdx.x == 0) {
+        stats[(long long)blockIdx.x * 2] = (float)mean;
+        stats[(long long)blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+hipError_t launch_gn_stats(const void* x, int dtype, float* stats, int B, int HW, int C, int groups, float eps,
+                           hipStream_t st) {
+    if (dtype == DT_BF16) gn_stats_kernel<bf16_t><<<B * groups, 256, 0, st>>>((const bf16_t*)x, stats, HW, C, groups, eps);
+    else gn_stats_kernel<float><<<B * groups, 256, 0, st>>>((const float*)x, stats, HW, C, groups, eps);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// row softmax (decoder AttnBlock, stage1/modules/layers.py:177), in place
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* x, int n) {
+    __shared__ float red[4];
+    T* row = x + (long long)blockIdx.x * n;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, ld1<T>(row + i));
+    m = block_reduce(m, OpMax(), red);
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += expf(ld1<T>(row + i) - m);
+    s = block_reduce(s, OpAdd(), red);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) st1<T>(row + i, expf(ld1<T>(row + i) - m) / s);
+}
+hipError_t launch_softmax_rows(void* x, int dtype, int rows, int n, hipStream_t st) {
+    if (dtype == DT_BF16) softmax_rows_kernel<bf16_t><<<rows, 256, 0, st>>>((bf16_t*)x, n);
+    else softmax_rows_kernel<float><<<rows, 256, 0, st>>>((float*)x, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic GEMM dispatch
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_gemm_generic(const GemmArgs& g, int ta, int tb, int tc, hipStream_t st) {
+    if (g.K % 16 != 0 || (g.conv_taps && g.Cin % 4 != 0)) return hipErrorInvalidValue;
+    const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, g.batch > 0 ? g.batch : 1);
+    const int key = ta * 4 + tb * 2 + tc;
+    switch (key) {
+        case 0: gemm_tile_kernel<float, float, float><<<grid, 256, 0, st>>>(g); break;
+        case 7: gemm_tile_kernel<bf16_t, bf16_t, bf16_t><<<grid, 256, 0, st>>>(g); break;
+        case 6: gemm_tile_kernel<bf16_t, bf16_t, float><<<grid, 256, 0, st>>>(g); break;
+        case 2: gemm_tile_kernel<float, bf16_t, float><<<grid, 256, 0, st>>>(g); break;
+        case 3: gemm_tile_kernel<float, bf16_t, bf16_t><<<grid, 256, 0, st>>>(g); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

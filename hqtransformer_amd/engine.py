@@ -1,0 +1,191 @@
+"""Thin torch-tensor wrapper over one libhqt handle.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens inside libhqt.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PRECISION_EXACT, PRECISION_FAST, hqt_config, hqt_sample_opts
+from .spec import Stage1Spec, Stage2Spec
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def make_config(s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], max_batch: int, max_steps: int) -> hqt_config:
+    c = hqt_config()
+    c.abi_version = _lib.ABI_VERSION
+    c.max_batch = int(max_batch)
+    c.max_steps = int(max_steps)
+    if s2 is not None:
+        c.has_stage2 = 1
+        c.embed_dim, c.n_layers, c.n_heads, c.n_layers_depth = s2.embed_dim, s2.n_layers, s2.n_heads, s2.n_layers_depth
+        c.vocab_top, c.vocab_bot, c.vocab_txt = s2.vocab_top, s2.vocab_bot, s2.vocab_txt
+        c.ctx_len_img, c.ctx_len_txt, c.n_classes = s2.ctx_len_img, s2.ctx_len_txt, s2.n_classes
+        c.cond_type, c.embedding_type, c.gelu_approx = s2.cond, s2.embedding, int(s2.gelu_approx)
+    if s1 is not None:
+        c.has_stage1 = 1
+        c.s1_ch, c.s1_n_mult = s1.ch, len(s1.ch_mult)
+        for i, m in enumerate(s1.ch_mult):
+            c.s1_ch_mult[i] = m
+        c.s1_num_res_blocks = s1.num_res_blocks
+        c.s1_n_attn_res = len(s1.attn_resolutions)
+        for i, r in enumerate(s1.attn_resolutions):
+            c.s1_attn_res[i] = r
+        c.s1_resolution, c.s1_z_channels, c.s1_embed_dim = s1.resolution, s1.z_channels, s1.embed_dim
+        c.s1_n_embed, c.s1_out_ch = s1.n_embed, s1.out_ch
+        c.s1_use_init_downsample, c.s1_use_mid_block, c.s1_use_attn = (int(s1.use_init_downsample), int(s1.use_mid_block),
+                                                                        int(s1.use_attn))
+    return c
+
+
+class Engine:
+    """One libhqt handle on one GPU.  Not thread-safe; asynchronous on torch's current stream."""
+
+    def __init__(self, s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], device: torch.device, max_batch: int,
+                 max_steps: Optional[int] = None):
+        self.lib = _lib.load()                      # raises HqtLibraryError when the HIP library is absent
+        self.s2, self.s1 = s2, s1
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.HqtLibraryError(f'libhqt runs on an MI355X only; got device {self.device} (no CPU fallback)')
+        self.max_batch = int(max_batch)
+        self.max_steps = int(max_steps if max_steps is not None else (s2.ctx_len_img if s2 else 1))
+        self.cfg = make_config(s2, s1, self.max_batch, self.max_steps)
+        h = C.c_void_p()
+        _lib.check(self.lib.hqt_create(C.byref(self.cfg), self.device.index or 0, C.byref(h)))
+        self.h = h
+        self.finalized = False
+
+    def close(self) -> None:
+        if getattr(self, 'h', None) is not None and self.h.value:
+            self.lib.hqt_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def set_weight(self, name: str, t) -> None:
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+        t = t.detach().to(dtype=torch.float32).contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        _lib.check(self.lib.hqt_set_weight(self.h, name.encode(), C.c_void_p(t.data_ptr()), 0, shape, t.dim()))
+
+    def load(self, stage2: Optional[Dict[str, object]] = None, stage1: Optional[Dict[str, object]] = None) -> None:
+        for prefix, sd in (('stage2.', stage2), ('stage1.', stage1)):
+            for k, v in (sd or {}).items():
+                self.set_weight(prefix + k, v)
+
+    def finalize(self) -> None:
+        _lib.check(self.lib.hqt_finalize_weights(self.h))
+        self.finalized = True
+
+    # ------------------------------------------------------------------ stage 2
+    def sample(self, batch: int, cond: Optional[torch.Tensor], n_steps: int, *, precision: int = PRECISION_FAST,
+               top_k: Sequence[Optional[int]] = (None, None), top_p: Sequence[Optional[float]] = (None, None),
+               temperature: Sequence[float] = (1.0, 1.0), noise: Optional[torch.Tensor] = None, seed: int = 0,
+               sample_offset: int = 0, force_top: Optional[torch.Tensor] = None, force_bot: Optional[torch.Tensor] = None,
+               return_logits: bool = False, use_graph: bool = True,
+               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        dev = self.device
+        B, V = int(batch), self.s2.vocab_top
+        o = hqt_sample_opts()
+        o.precision, o.n_steps = int(precision), int(n_steps)
+        o.top_k_top = int(top_k[0]) if top_k[0] else 0
+        o.top_k_bot = int(top_k[1]) if top_k[1] else 0
+        o.top_p_top = float(top_p[0]) if top_p[0] else 0.0
+        o.top_p_bot = float(top_p[1]) if top_p[1] else 0.0
+        o.temperature_top, o.temperature_bot = float(temperature[0]), float(temperature[1])
+        o.seed, o.sample_offset, o.use_graph = int(seed) & (2 ** 64 - 1), int(sample_offset), int(bool(use_graph))
+
+        def prep(t, shape, dtype, what):
+            if t is None:
+                return None
+            t = torch.as_tensor(t).to(device=dev, dtype=dtype).contiguous()
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f'{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
+            return t
+        if self.s2.cond == 1:
+            cond = prep(cond, (B,), torch.int64, 'cond')
+        elif self.s2.cond == 2:
+            cond = prep(cond, (B, self.s2.ctx_len_txt), torch.int64, 'cond')
+        else:
+            cond = None
+        noise = prep(noise, (n_steps, 5, B, V), torch.float32, 'noise')
+        force_top = prep(force_top, (B, n_steps), torch.int64, 'force_top')
+        force_bot = prep(force_bot, (B, n_steps, 4), torch.int64, 'force_bot')
+        if out is None:
+            out_top = torch.empty((B, n_steps), dtype=torch.int64, device=dev)
+            out_bot = torch.empty((B, n_steps, 4), dtype=torch.int64, device=dev)
+        else:
+            out_top, out_bot = out
+        logits = torch.empty((n_steps, 5, B, V), dtype=torch.float32, device=dev) if return_logits else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.hqt_sample(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(force_top), _ptr(force_bot),
+                                           _ptr(logits), _ptr(out_top), _ptr(out_bot), C.c_void_p(stream)))
+        # inputs must outlive the asynchronous launches
+        self._keep = (cond, noise, force_top, force_bot)
+        if return_logits:
+            return out_top, out_bot, logits
+        return out_top, out_bot
+
+    # ------------------------------------------------------------------ stage 1
+    def decode(self, code_t: Optional[torch.Tensor], code_b: Optional[torch.Tensor], *, precision: int = PRECISION_EXACT,
+               clamp01: bool = False, seq_layout: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        dev = self.device
+        ref = code_t if code_t is not None else code_b
+        if ref is None:
+            raise ValueError('code_t and code_b are both None')
+        B = int(ref.shape[0])
+        code_t = None if code_t is None else code_t.to(device=dev, dtype=torch.int64).contiguous()
+        code_b = None if code_b is None else code_b.to(device=dev, dtype=torch.int64).contiguous()
+        r = self.s1.z_res
+        if seq_layout:
+            want_t, want_b = (B, (r // 2) ** 2), (B, (r // 2) ** 2, 4)
+        else:
+            want_t, want_b = (B, r // 2, r // 2), (B, r, r)
+        if code_t is not None and tuple(code_t.shape) != want_t:
+            raise ValueError(f'code_t: expected {want_t}, got {tuple(code_t.shape)}')
+        if code_b is not None and tuple(code_b.shape) != want_b:
+            raise ValueError(f'code_b: expected {want_b}, got {tuple(code_b.shape)}')
+        H = self.s1.resolution
+        if out is None:
+            out = torch.empty((B, self.s1.out_ch, H, H), dtype=torch.float32, device=dev)
+        fn = self.lib.hqt_decode_seq if seq_layout else self.lib.hqt_decode
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(fn(self.h, B, _ptr(code_t), _ptr(code_b), _ptr(out), int(clamp01), int(precision), C.c_void_p(stream)))
+        self._keep_dec = (code_t, code_b)
+        return out
+
+    # ------------------------------------------------------------------ timing (bench.py roofline numerator)
+    def timing(self, on: bool) -> None:
+        _lib.check(self.lib.hqt_timing_enable(self.h, int(on)))
+
+    def timing_reset(self) -> None:
+        _lib.check(self.lib.hqt_timing_reset(self.h))
+
+    def timing_report(self) -> Dict[str, Tuple[int, float]]:
+        out = {}
+        for i in range(self.lib.hqt_timing_slots(self.h)):
+            name = C.create_string_buffer(64)
+            n, ms = C.c_int64(), C.c_double()
+            _lib.check(self.lib.hqt_timing_get(self.h, i, name, 64, C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = (int(n.value), float(ms.value))
+        return out
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.hqt_workspace_bytes(self.h))

@@ -1,0 +1,151 @@
+/*
+ * hqt.h -- C ABI of libhqt.so, the MI355X (gfx950) HQ-Transformer sampling engine.
+ *
+ * The reference (kakaobrain/hqtransformer) has no FFI/plugin layer: its sampling path is ordinary
+ * nn.Module methods.  The boundary is therefore the Python call surface its drivers use (SURVEY.md
+ * §8b); hqtransformer_amd/ re-exposes that surface and binds the entry points below with ctypes.
+ * Each entry point names the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every tensor pointer is a DEVICE
+ * pointer owned by the caller unless stated otherwise.  Calls enqueue work on `stream` (a
+ * hipStream_t passed as void*; NULL = the null stream) and return without synchronising.  Every
+ * function returns 0 on success or a negative hqt_status; the message is available from
+ * hqt_last_error() (thread-local).  Nothing throws across the ABI.  A handle is bound to one device
+ * and must be driven by one host thread at a time.
+ */
+#ifndef HQT_H
+#define HQT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HQT_ABI_VERSION 1
+
+typedef enum {
+    HQT_OK = 0,
+    HQT_ERR_INVALID = -1,      /* bad argument / unsupported configuration   */
+    HQT_ERR_HIP = -2,          /* a HIP runtime call failed                  */
+    HQT_ERR_STATE = -3,        /* call order (e.g. sample before finalize)   */
+    HQT_ERR_UNKNOWN_WEIGHT = -4,
+    HQT_ERR_SHAPE = -5,
+    HQT_ERR_MISSING_WEIGHT = -6
+} hqt_status;
+
+/* conditioning of the top GPT -- hqvae/models/stage2/hierarchical_ar.py:64-78 */
+enum { HQT_COND_NONE = 0, HQT_COND_CLASS = 1, HQT_COND_TEXT = 2 };
+/* input embedding -- hierarchical_ar.py:83-113 ('transformer1' has zero embedding blocks) */
+enum { HQT_EMB_TRANSFORMER1 = 0, HQT_EMB_REDUCE = 1 };
+/* arithmetic of a call.  EXACT = fp32 weights/activations/accumulation (what the reference computes
+ * on its CPU path, where autocast is off); FAST = bf16 weights and MFMA, fp32 accumulation, fp32
+ * softmax/normalisation/sampler (the counterpart of the reference's use_fp16=True autocast path). */
+enum { HQT_PRECISION_EXACT = 0, HQT_PRECISION_FAST = 1 };
+enum { HQT_DTYPE_F32 = 0 };
+
+typedef struct hqt_handle hqt_handle;
+
+/* Model description.  Stage-2 fields restate the arguments of iHQGPT.__init__
+ * (hierarchical_ar.py:24-33) as ImageGPT2 passes them (hqvae/models/__init__.py:123-137); stage-1
+ * fields restate SimRQGAN2Generator / Decoder (hqvae/models/stage1/generator.py:179-259,
+ * hqvae/models/stage1/modules/layers.py:300-383).  Set has_stage2 / has_stage1 to 0 to build half. */
+typedef struct {
+    int32_t abi_version;            /* HQT_ABI_VERSION */
+    /* stage 2: 'hq-transformer/parallel', ratio_bot2top = 4 */
+    int32_t has_stage2;
+    int32_t embed_dim, n_layers, n_heads, n_layers_depth;
+    int32_t vocab_top, vocab_bot, vocab_txt;
+    int32_t ctx_len_img, ctx_len_txt, n_classes;
+    int32_t cond_type;              /* HQT_COND_*  */
+    int32_t embedding_type;         /* HQT_EMB_*   */
+    int32_t gelu_approx;            /* hparams.gelu_use_approx */
+    /* stage 1: 'simrqgan2', upsample = pixelshuffle(2), decoding_type = concat */
+    int32_t has_stage1;
+    int32_t s1_ch, s1_n_mult, s1_ch_mult[8];
+    int32_t s1_num_res_blocks;
+    int32_t s1_n_attn_res, s1_attn_res[4];
+    int32_t s1_resolution, s1_z_channels, s1_embed_dim, s1_n_embed, s1_out_ch;
+    int32_t s1_use_init_downsample, s1_use_mid_block, s1_use_attn;
+    /* sizing */
+    int32_t max_batch;              /* largest B of any later call; workspaces are sized once */
+    int32_t max_steps;              /* largest number of top positions per call (<= ctx_len_img) */
+} hqt_config;
+
+/* Sampling options = the keyword arguments of sampling_ihqgpt (hqvae/utils/sampling.py:164-177).
+ * top_k <= 0 means None (no cut-off), top_p <= 0 means None. */
+typedef struct {
+    int32_t precision;              /* HQT_PRECISION_*  (use_fp16=True -> FAST) */
+    int32_t n_steps;                /* max_seq_len: top positions to generate */
+    int32_t top_k_top, top_k_bot;
+    float top_p_top, top_p_bot;
+    float temperature_top, temperature_bot;       /* softmax_temperature[0], [1] */
+    uint64_t seed;                  /* Philox seed, used when noise == NULL */
+    int64_t sample_offset;          /* global index of row 0 (sharded batches draw the noise of the
+                                       global batch: Philox counters are keyed by global row) */
+    int32_t use_graph;              /* 1: replay the per-position launch sequence from a hipGraph */
+} hqt_sample_opts;
+
+/* hqt_create -- replaces ImageGPT2(config) construction (hqvae/models/__init__.py:92-174) for the
+ * tensors of the sampling path; allocates all device workspaces (KV cache, activations). */
+int hqt_create(const hqt_config* cfg, int device, hqt_handle** out);
+
+/* hqt_set_weight -- replaces load_state_dict (sampling_hqmodel.py:77-79): `name` is the reference
+ * state-dict key without the 'stage1.' / 'stage2.' prefix namespace collision ('stage2.' keys are
+ * passed as e.g. "stage2.blocks.0.attn.key.weight", stage-1 keys as "stage1.decoder.conv_in.weight").
+ * `data` may be a host or a device pointer to contiguous fp32 in the reference's own layout
+ * ([out,in] Linear, [O,I,kh,kw] Conv2d, [n_embed,dim] codebooks); it is copied before return. */
+int hqt_set_weight(hqt_handle* h, const char* name, const void* data, int dtype, const int64_t* shape, int ndim);
+
+/* hqt_finalize_weights -- checks every tensor arrived, builds the device layouts the kernels read
+ * (fused QKV, tap-major conv filters, bf16 MFMA-fragment packing for FAST). */
+int hqt_finalize_weights(hqt_handle* h);
+
+/* hqt_sample -- replaces sampling_ihqgpt + iHQGPT.sampling_step (hqvae/utils/sampling.py:164-237,
+ * hierarchical_ar.py:428-480, 482-563, 667-789) for a batch of B independent images.
+ *   cond        int64 [B] class ids (HQT_COND_CLASS), int64 [B, ctx_len_txt] token ids
+ *               (HQT_COND_TEXT), ignored/NULL (HQT_COND_NONE)
+ *   noise       fp32 [n_steps, 5, B, V] Exp(1) variates q, draw order top, bot0..bot3; the draw is
+ *               argmax(p / q) (== torch.multinomial(p, 1) for the q it draws).  NULL: Philox(seed).
+ *   force_top   optional int64 [B, n_steps]: the top code fed back instead of the drawn one
+ *               (given_top_code, hierarchical_ar.py:768-774); the draw is still written to out_top
+ *   force_bot   optional int64 [B, n_steps, 4]: same for the four bottom codes (teacher forcing)
+ *   logits_out  optional fp32 [n_steps, 5, B, V]: raw (pre-temperature) logits of every draw
+ *   out_top     int64 [B, n_steps]      codes_top
+ *   out_bot     int64 [B, n_steps, 4]   codes_bot, slot = 2*kh + kw */
+int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_sample_opts* opts, const float* noise,
+               const int64_t* force_top, const int64_t* force_bot, float* logits_out,
+               int64_t* out_top, int64_t* out_bot, void* stream);
+
+/* hqt_decode -- replaces SimRQGAN2Generator.decode_code (generator.py:323-367: codebook lookup
+ * quantizer.py:179-186, PixelShuffle, concat, post_quant_conv_b, Decoder.forward layers.py:385-410).
+ *   code_t      int64 [B, r/2, r/2] or NULL (that level contributes a zero quant, generator.py:328-358)
+ *   code_b      int64 [B, r, r] or NULL          (r = bottom grid = resolution / 2^n_levels)
+ *   out_pixels  fp32 [B, out_ch, H, W] NCHW; clamp01 != 0 fuses clamp(0.5 x + 0.5, 0, 1)
+ *               (measure_throughput/__main__.py:113) into the last kernel, else raw decoder output
+ * hqt_decode_seq takes the sampler's own outputs (codes_top [B, (r/2)^2], codes_bot [B, (r/2)^2, 4])
+ * and folds the two rearranges of sampling_hqmodel.py:119-120 into the lookup addressing. */
+int hqt_decode(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_b, float* out_pixels,
+               int clamp01, int precision, void* stream);
+int hqt_decode_seq(hqt_handle* h, int B, const int64_t* codes_top, const int64_t* codes_bot, float* out_pixels,
+                   int clamp01, int precision, void* stream);
+
+/* introspection */
+int hqt_abi_version(void);
+int64_t hqt_param_count(const hqt_handle* h, int stage);       /* stage 1 | 2: elements received */
+int64_t hqt_workspace_bytes(const hqt_handle* h);
+/* name of the kernel that dominates phase (0 = AR loop, 1 = decode) and its launch count / total
+ * device time in ms since hqt_timing_reset, measured with HIP events on the caller's stream when
+ * timing is enabled (bench.py's roofline numerator) */
+int hqt_timing_enable(hqt_handle* h, int on);
+int hqt_timing_reset(hqt_handle* h);
+int hqt_timing_get(hqt_handle* h, int slot, char* name, int name_len, int64_t* launches, double* total_ms);
+int hqt_timing_slots(const hqt_handle* h);
+
+int hqt_destroy(hqt_handle* h);
+const char* hqt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HQT_H */

@@ -1,0 +1,244 @@
+"""Parity of the HIP path (through the C ABI) against the reference-generated golden fixtures and
+against the CPU oracle on the same seeded inputs.  Runs on the MI355X box only (-m gpu).
+
+Bars (EXACT precision = what the reference computes on its CPU path):
+  * sampled code sequences: bit-exact under fixed noise;
+  * fp32 logits: |diff| <= 2e-4 (logits of std ~3 after up to 8 fp32 blocks, summation order differs);
+  * decoded pixels: |diff| <= 1e-4 (north_star's tolerance).
+FAST precision (bf16 weights/activations, fp32 accumulation) is gated by teacher-forced logits and
+pixel tolerances stated in each test, plus the code agreement rate.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from hqtransformer_amd import synth
+from hqtransformer_amd._lib import PRECISION_EXACT, PRECISION_FAST
+from hqtransformer_amd.engine import Engine
+from hqtransformer_amd.spec import Stage1Spec, Stage2Spec
+from oracle import hqt_oracle as O
+from tests.helpers import load, oracle_stage1, oracle_stage2, stage1_from_fixture, stage2_from_fixture
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 2e-4
+PIXEL_TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def engine_s2(spec, weights, max_batch, max_steps=None):
+    e = Engine(spec, None, dev(), max_batch, max_steps or spec.ctx_len_img)
+    e.load(stage2=weights)
+    e.finalize()
+    return e
+
+
+def engine_s1(spec, weights, max_batch):
+    e = Engine(None, spec, dev(), max_batch)
+    e.load(stage1=weights)
+    e.finalize()
+    return e
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope='module')
+def tiny_cls():
+    fx = load('g4_tiny_cls.npz')
+    spec, weights = stage2_from_fixture(fx)
+    return fx, spec, weights, engine_s2(spec, weights, 8)
+
+
+@pytest.mark.parametrize('si', [0, 1, 2])
+@pytest.mark.parametrize('graph', [False, True])
+def test_tiny_cls_codes_bit_exact_vs_reference_fixture(tiny_cls, si, graph):
+    fx, spec, weights, eng = tiny_cls
+    tk, tp, T = json.loads(str(fx['settings']))[si]
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = synth.exp_noise(int(fx['noise_seed']), n, B, spec.vocab_top)
+    ct, cb, lg = eng.sample(B, torch.full((B,), 7), n, precision=PRECISION_EXACT, top_k=tk, top_p=tp, temperature=T,
+                            noise=torch.from_numpy(noise), return_logits=True, use_graph=graph)
+    torch.cuda.synchronize()
+    scale = np.array([T[0]] + [T[1]] * 4, np.float32)[None, :, None, None]
+    err = np.abs(np_(lg)[fx['keep_steps']] / scale - fx[f'logits_{si}']).max()
+    assert err <= LOGIT_TOL, f'logit error {err}'
+    assert (np_(ct) == fx[f'codes_top_{si}']).all(), 'top codes differ from the reference'
+    assert (np_(cb) == fx[f'codes_bot_{si}']).all(), 'bottom codes differ from the reference'
+
+
+def test_tiny_cls_given_top_code(tiny_cls):
+    fx, spec, weights, eng = tiny_cls
+    B = int(fx['B'])
+    noise = synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:8]
+    ct, cb, lg = eng.sample(B, torch.full((B,), 3), 8, precision=PRECISION_EXACT, noise=torch.from_numpy(noise.copy()),
+                            force_top=torch.from_numpy(fx['given_top']), return_logits=True, use_graph=False)
+    assert (np_(cb) == fx['given_codes_bot']).all()
+    assert np.abs(np_(lg) - fx['given_logits']).max() <= LOGIT_TOL
+
+
+def test_tiny_reduce_uncond(tiny_cls):
+    fx = load('g3_tiny_reduce_uncond.npz')
+    spec, weights = stage2_from_fixture(fx)
+    eng = engine_s2(spec, weights, 4)
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = synth.exp_noise(int(fx['noise_seed']), n, B, spec.vocab_top)
+    k, p, T = int(fx['top_k']), float(fx['top_p']), [float(t) for t in fx['temps']]
+    ct, cb, lg = eng.sample(B, None, n, precision=PRECISION_EXACT, top_k=(k, k), top_p=(p, p), temperature=T,
+                            noise=torch.from_numpy(noise), return_logits=True)
+    scale = np.array([T[0]] + [T[1]] * 4, np.float32)[None, :, None, None]
+    assert np.abs(np_(lg)[fx['keep_steps']] / scale - fx['logits']).max() <= LOGIT_TOL
+    assert (np_(ct) == fx['codes_top']).all() and (np_(cb) == fx['codes_bot']).all()
+
+
+def test_tiny_txt_prefill():
+    fx = load('g3_tiny_txt.npz')
+    spec, weights = stage2_from_fixture(fx)
+    eng = engine_s2(spec, weights, 4)
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = synth.exp_noise(int(fx['noise_seed']), n, B, spec.vocab_top)
+    txt = synth.text_ids(int(fx['text_seed']), B, spec.ctx_len_txt, spec.vocab_txt)
+    for graph in (False, True):
+        ct, cb, lg = eng.sample(B, torch.from_numpy(txt), n, precision=PRECISION_EXACT, noise=torch.from_numpy(noise),
+                                return_logits=True, use_graph=graph)
+        assert np.abs(np_(lg)[fx['keep_steps']] - fx['logits']).max() <= LOGIT_TOL
+        assert (np_(ct) == fx['codes_top']).all() and (np_(cb) == fx['codes_bot']).all()
+
+
+def test_ragged_batches_and_b1_vs_oracle(tiny_cls):
+    """B = 1 (which the reference cannot run, hierarchical_ar.py:719) and an odd batch, against the oracle."""
+    fx, spec, weights, eng = tiny_cls
+    orc = O.OracleStage2(spec, weights)
+    for B, n in ((1, 6), (5, 5), (8, 4)):
+        noise = synth.exp_noise(100 + B, n, B, spec.vocab_top)
+        cond = np.arange(B) % spec.n_classes
+        want = orc.sample(cond, B, n, noise, (50, 20), (None, 0.9), (1.0, 0.8), return_logits=True)
+        got = eng.sample(B, torch.from_numpy(cond), n, precision=PRECISION_EXACT, top_k=(50, 20), top_p=(None, 0.9),
+                         temperature=(1.0, 0.8), noise=torch.from_numpy(noise), return_logits=True)
+        assert np.abs(np_(got[2]) - want[2]).max() <= LOGIT_TOL
+        assert (np_(got[0]) == want[0]).all() and (np_(got[1]) == want[1]).all()
+
+
+def test_philox_noise_is_shard_invariant(tiny_cls):
+    """Sharding property: rows [2,6) of a global batch of 8 drawn with sample_offset=2 equal
+    the same rows of the unsharded run (size-independent property, no oracle needed)."""
+    fx, spec, weights, eng = tiny_cls
+    cond = torch.arange(8) % spec.n_classes
+    full = eng.sample(8, cond, 10, precision=PRECISION_EXACT, seed=1234, top_k=(100, 100))
+    part = eng.sample(4, cond[2:6], 10, precision=PRECISION_EXACT, seed=1234, sample_offset=2, top_k=(100, 100))
+    assert (np_(full[0])[2:6] == np_(part[0])).all() and (np_(full[1])[2:6] == np_(part[1])).all()
+    again = eng.sample(8, cond, 10, precision=PRECISION_EXACT, seed=1234, top_k=(100, 100))
+    assert (np_(full[0]) == np_(again[0])).all()                      # deterministic
+    other = eng.sample(8, cond, 10, precision=PRECISION_EXACT, seed=99, top_k=(100, 100))
+    assert (np_(full[0]) != np_(other[0])).any()
+    assert np_(full[0]).min() >= 0 and np_(full[0]).max() < spec.vocab_top
+
+
+def test_philox_draws_follow_the_softmax(tiny_cls):
+    """Statistical property of the in-kernel Exp(1) noise: with B identical rows the empirical top-code
+    histogram of step 0 must match softmax(logits) (chi-square-ish bound)."""
+    fx, spec, weights, eng = tiny_cls
+    B = 8
+    counts = np.zeros(spec.vocab_top)
+    logits = None
+    for rep in range(64):
+        ct, cb, lg = eng.sample(B, torch.full((B,), 2), 1, precision=PRECISION_EXACT, seed=rep, return_logits=True)
+        counts += np.bincount(np_(ct)[:, 0], minlength=spec.vocab_top)
+        logits = np_(lg)[0, 0, 0]
+    p = O.softmax(logits[None])[0]
+    n = counts.sum()
+    top = np.argsort(-p)[:8]
+    assert np.abs(counts[top] / n - p[top]).max() < 5 * np.sqrt(p[top].max() / n) + 0.01
+
+
+def test_fast_precision_teacher_forced(tiny_cls):
+    """FAST (bf16) arithmetic cannot be bit-exact against an fp32 reference; it is gated by teacher-forced
+    logits (|diff| <= 0.15 on logits of std ~3, i.e. a few bf16 ulps through 8 blocks) and by agreement of
+    the drawn codes under identical noise (>= 90 %)."""
+    fx, spec, weights, eng = tiny_cls
+    B, n = int(fx['B']), 16
+    noise = synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:n]
+    ft = torch.from_numpy(fx['codes_top_0'][:, :n].copy())
+    fb = torch.from_numpy(fx['codes_bot_0'][:, :n].copy())
+    for graph in (False, True):
+        ct, cb, lg = eng.sample(B, torch.full((B,), 7), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise),
+                                force_top=ft, force_bot=fb, return_logits=True, use_graph=graph)
+        ex = eng.sample(B, torch.full((B,), 7), n, precision=PRECISION_EXACT, noise=torch.from_numpy(noise),
+                        force_top=ft, force_bot=fb, return_logits=True, use_graph=False)
+        err = (lg - ex[2]).abs().max().item()
+        assert err <= 0.15, f'FAST logits differ from EXACT by {err}'
+        agree = ((ct == ex[0]).float().mean().item() + (cb == ex[1]).float().mean().item()) / 2
+        assert agree >= 0.9, f'code agreement {agree}'
+
+
+# ----------------------------------------------------------------------------------------- stage 1
+def test_decode_64_exact_vs_reference_fixture():
+    fx = load('g5_decode_64.npz')
+    spec, weights = stage1_from_fixture(fx)
+    eng = engine_s1(spec, weights, 2)
+    ct, cb = torch.from_numpy(fx['code_t']), torch.from_numpy(fx['code_b'])
+    px = np_(eng.decode(ct, cb, precision=PRECISION_EXACT))
+    assert np.abs(px - fx['pixels']).max() <= PIXEL_TOL
+    assert np.abs(np_(eng.decode(ct[:1], None, precision=PRECISION_EXACT)) - fx['pixels_top_only']).max() <= PIXEL_TOL
+    assert np.abs(np_(eng.decode(None, cb[:1], precision=PRECISION_EXACT)) - fx['pixels_bot_only']).max() <= PIXEL_TOL
+    clamped = np_(eng.decode(ct, cb, precision=PRECISION_EXACT, clamp01=True))
+    np.testing.assert_allclose(clamped, O.postprocess(fx['pixels']), atol=PIXEL_TOL)
+    # sampler layout + folded rearranges (sampling_hqmodel.py:119-120)
+    seq_t = ct.reshape(2, 64)
+    seq_b = cb.reshape(2, 8, 2, 8, 2).permute(0, 1, 3, 2, 4).reshape(2, 64, 4)
+    px_seq = np_(eng.decode(seq_t, seq_b, precision=PRECISION_EXACT, seq_layout=True))
+    assert (px_seq == px).all()
+
+
+def test_decode_256_exact_vs_reference_fixture():
+    fx = load('g5_decode_256.npz')
+    spec, weights = stage1_from_fixture(fx)
+    eng = engine_s1(spec, weights, 1)
+    px = np_(eng.decode(torch.from_numpy(fx['code_t']), torch.from_numpy(fx['code_b']), precision=PRECISION_EXACT))
+    assert np.abs(px - fx['pixels']).max() <= PIXEL_TOL
+
+
+def test_decode_fast_tolerance():
+    """FAST decode (bf16 activations and filters, fp32 accumulation and GroupNorm statistics): pixels of
+    range ~[-3, 3] within 6e-2 of the fp32 reference, mean abs error within 1e-2."""
+    for name in ('g5_decode_64.npz', 'g5_decode_256.npz'):
+        fx = load(name)
+        spec, weights = stage1_from_fixture(fx)
+        eng = engine_s1(spec, weights, 2)
+        px = np_(eng.decode(torch.from_numpy(fx['code_t']), torch.from_numpy(fx['code_b']), precision=PRECISION_FAST))
+        d = np.abs(px - fx['pixels'])
+        assert d.max() <= 6e-2 and d.mean() <= 1e-2, (name, d.max(), d.mean())
+
+
+def test_decode_batch_chunking_and_ragged():
+    """More images than one decode chunk, decoded in one call, equal the per-image decodes."""
+    fx = load('g5_decode_64.npz')
+    spec, weights = stage1_from_fixture(fx)
+    eng = engine_s1(spec, weights, 3)
+    r = np.random.default_rng(5)
+    ct = torch.from_numpy(r.integers(0, spec.n_embed, (7, 8, 8)))
+    cb = torch.from_numpy(r.integers(0, spec.n_embed, (7, 16, 16)))
+    allpx = np_(eng.decode(ct, cb, precision=PRECISION_EXACT))
+    for i in (0, 3, 6):
+        one = np_(eng.decode(ct[i:i + 1], cb[i:i + 1], precision=PRECISION_EXACT))
+        assert (one[0] == allpx[i]).all()
+    orc = O.OracleStage1(spec, weights)
+    assert np.abs(orc.decode_code(ct[:2].numpy(), cb[:2].numpy()) - allpx[:2]).max() <= PIXEL_TOL
+
+
+def test_error_reporting(tiny_cls):
+    from hqtransformer_amd._lib import HqtError
+    fx, spec, weights, eng = tiny_cls
+    with pytest.raises(HqtError):
+        eng.sample(9, torch.zeros(9, dtype=torch.int64), 4)           # B > max_batch
+    with pytest.raises(HqtError):
+        eng.sample(2, torch.zeros(2, dtype=torch.int64), 65)          # n_steps > ctx_len_img
+    e2 = Engine(spec, None, dev(), 2)
+    with pytest.raises(HqtError):
+        e2.finalize()                                                 # missing weights
