@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of 256x256 class-conditional HQ-Transformer sampling on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch per GPU: the 64-position hierarchical AR loop
+(`sampling_ihqgpt`) followed by the HQ-VAE decode of the sampled code grids and clamp(0.5x+0.5) -- exactly
+what one iteration of the reference's `measure_throughput` loop times (measure_throughput/__main__.py:88-113).
+Workload = BASELINE.json configs[1]: ImageNet-256 class-conditional HQ-VAE + 12-layer HQ-Transformer,
+batch 64 per GPU, synthetic (random-init weights, as the reference harness itself uses; random class per
+step; top_k = top_p = None, temperatures [1, 1]).  Weak scaling: every rank samples its own 64 images,
+weights replicated, the only collective is the gather of finished pixels to rank 0 (RCCL over xGMI).
+
+The JSON line also carries `roofline` (dominant kernel family, measured live with HIP events on the
+launch stream by libhqt's per-launch timers in a separate un-graphed pass) and `cpu_baseline` (the numpy
+oracle = a port of the reference's CPU path, timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hqtransformer_amd import synth  # noqa: E402
+from hqtransformer_amd.config import load_config  # noqa: E402
+from hqtransformer_amd.models import ImageGPT2  # noqa: E402
+from hqtransformer_amd.sampling import sampling_ihqgpt  # noqa: E402
+from hqtransformer_amd.spec import decoder_plan, work_per_image  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=5)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--config', default=os.path.join(ROOT, 'configs', 'imagenet-12l.yaml'))
+    p.add_argument('--batch', type=int, default=64, help='images per GPU per step')
+    p.add_argument('--precision', choices=['fast', 'exact'], default='fast')
+    p.add_argument('--gather', choices=['pixels', 'codes', 'none'], default='pixels')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-roofline', action='store_true')
+    p.add_argument('--no-graph', action='store_true')
+    return p.parse_args()
+
+
+def cpu_baseline(cfg, s2, s1, batch):
+    """Reference CPU path as restated by the oracle (fp32 numpy/OpenBLAS on all host cores), bounded sample:
+    2 top positions of the AR loop at the bench batch + the decode of 1 image, scaled to images/s with the
+    reference harness's accounting (64 positions per image batch, decode per image)."""
+    from oracle.hqt_oracle import OracleStage1, OracleStage2
+    cores = os.cpu_count() or 1
+    w2 = synth.stage2_weights(s2, 0, 'bench')
+    w1 = synth.stage1_weights(s1, 1, 'bench')
+    orc2, orc1 = OracleStage2(s2, w2), OracleStage1(s1, w1)
+    n_pos = 2
+    noise = synth.exp_noise(0, n_pos, batch, s2.vocab_top)
+    cond = synth.class_ids(0, batch, max(s2.n_classes, 1))
+    t0 = time.perf_counter()
+    ct, cb = orc2.sample(cond, batch, n_pos, noise)
+    t_ar = (time.perf_counter() - t0) / n_pos
+    r = s1.z_res
+    rng = np.random.default_rng(0)
+    code_t = rng.integers(0, s1.n_embed, (1, r // 2, r // 2))
+    code_b = rng.integers(0, s1.n_embed, (1, r, r))
+    t0 = time.perf_counter()
+    orc1.decode_code(code_t, code_b)
+    t_dec = time.perf_counter() - t0
+    n_positions = (r // 2) ** 2
+    per_image = t_ar * n_positions / batch + t_dec
+    return {'value': round(1.0 / per_image, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_pos} of {n_positions} AR positions at batch {batch} ({t_ar:.2f} s/position) + decode of 1 image '
+                      f'({t_dec:.2f} s), fp32 numpy/OpenBLAS oracle, extrapolated per image'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg = load_config(args.config)
+    model = ImageGPT2(cfg, seed=0).to(dev).eval()
+    s2, s1 = model.stage2.spec, model.stage1.spec
+    B = args.batch
+    n_pos = (s1.z_res // 2) ** 2
+    fast = args.precision == 'fast'
+    classes = synth.class_ids(1000 + rank, args.steps + args.warmup + 4, max(s2.n_classes, 1))
+    H = s1.resolution
+    gathered = None
+    if dist is not None and args.gather == 'pixels' and rank == 0:
+        gathered = [torch.empty((B, s1.out_ch, H, H), dtype=torch.float32, device=dev) for _ in range(world)]
+
+    def step(i, graph=True):
+        ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), top_k_top=None, top_p_top=None,
+                                 top_k_bot=None, top_p_bot=None, softmax_temperature=[1.0, 1.0], use_fp16=fast,
+                                 is_tqdm=False, max_seq_len=n_pos, model_stage1=None, seed=1 + i,
+                                 sample_offset=rank * B, use_graph=graph and not args.no_graph)
+        px = model.stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
+        if dist is not None and args.gather == 'pixels':
+            dist.gather(px, gathered, dst=0)
+        elif dist is not None and args.gather == 'codes':
+            dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+        return ct, cb, px
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        i = args.warmup + k
+        ev[3 * k].record()
+        ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), softmax_temperature=[1.0, 1.0],
+                                 use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i, sample_offset=rank * B,
+                                 use_graph=not args.no_graph)
+        ev[3 * k + 1].record()
+        px = model.stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
+        ev[3 * k + 2].record()
+        if dist is not None and args.gather == 'pixels':
+            dist.gather(px, gathered, dst=0)
+        elif dist is not None and args.gather == 'codes':
+            dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ar_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)) / args.steps
+    dec_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)) / args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        work = work_per_image(s2, s1, n_pos)
+        value = world * B * args.steps / elapsed
+        out = {
+            'metric': 'images/sec (256x256 class-cond sampling)', 'value': round(value, 2), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if fast else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'imagenet256-classcond hq-vae(8x8+16x16)+hq-transformer {s2.n_layers}L/{s2.embed_dim}d, '
+                                   f'batch {B}/GPU, {n_pos} top positions, top_k=top_p=None, T=[1,1]',
+                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
+                       'precision': 'FAST: bf16 weights+MFMA, fp32 accumulate' if fast else 'EXACT: fp32',
+                       'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph},
+            'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
+        }
+
+    # ---- roofline: per-launch HIP-event timers inside libhqt, un-graphed pass, rank 0 only
+    if rank == 0 and not args.no_roofline:
+        e2, e1 = model.stage2.engine(B, n_pos), model.stage1.engine(B)
+        for e in (e2, e1):
+            e.timing(True)
+            e.timing_reset()
+        step(0, graph=False)
+        torch.cuda.synchronize(dev)
+        rep = {}
+        for e in (e2, e1):
+            for k, v in e.timing_report().items():
+                rep[k] = (rep.get(k, (0, 0.0))[0] + v[0], rep.get(k, (0, 0.0))[1] + v[1])
+            e.timing(False)
+        gemm = {k: v for k, v in rep.items() if k.startswith('gemm_')}
+        conv = {k: v for k, v in rep.items() if k in ('conv3x3', 'conv1x1', 'conv_out', 'attn_gemm')}
+        gemm_ms = sum(v[1] for v in gemm.values())
+        conv_ms = sum(v[1] for v in conv.values())
+        wbytes = (2 if fast else 4) / 2 * work['ar_weight_bytes_per_pos'] * n_pos           # per batch, all AR GEMM launches
+        cflops = work['dec_flops'] * B
+        fam = []
+        if gemm_ms > 0:
+            n_l = sum(v[0] for v in gemm.values())
+            ach = wbytes / (gemm_ms * 1e-3) / 1e9
+            fam.append({'kernel': 'AR weight-streaming GEMM (qkv/proj/fc1/fc2/heads)', 'bound': 'hbm', 'achieved': round(ach, 1),
+                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3), 'total_ms': round(gemm_ms, 3),
+                        'algorithmic_bytes_per_launch': round(wbytes / n_l)})
+        if conv_ms > 0:
+            n_l = sum(v[0] for v in conv.values())
+            ach = cflops / (conv_ms * 1e-3) / 1e12
+            peak = MFMA_BF16_PEAK_TFLOPS if fast else F32_PEAK_TFLOPS
+            fam.append({'kernel': 'HQ-VAE decoder implicit-GEMM conv', 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
+                        'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None, 'launches': n_l,
+                        'avg_launch_us': round(1000 * conv_ms / n_l, 3), 'total_ms': round(conv_ms, 3),
+                        'algorithmic_flops_per_launch': round(cflops / n_l)})
+        fam.sort(key=lambda f: -f['total_ms'])
+        if fam:
+            out['roofline'] = fam[0]
+            out['roofline_other'] = fam[1:]
+        out['kernel_ms_per_batch'] = {k: [v[0], round(v[1], 3)] for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg, s2, s1, B)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's model surface for the sampling path.
+
+``ImageGPT2(config)`` exposes ``.stage1`` / ``.stage2`` with the attributes and methods the reference's
+drivers touch (``measure_throughput/__main__.py:51-113``, ``sampling_hqmodel.py:64-121,156-225``,
+``hqvae/utils/sampling.py:183-192``): ``eval()``, ``to(device)``, ``load_state_dict(sd, strict=True)``,
+``stage2.parameters()``, ``stage2.use_cls_cond / use_txt_cond / idx_pred / sos / tok_emb_txt / pos_emb_txt``,
+``stage1.decode_code(code_t, code_b)``.  The objects hold fp32 master weights on the host and one libhqt
+handle per stage on the GPU; every tensor operation runs in libhqt.so.  There is no CPU compute path:
+using a model that has not been moved to a GPU raises.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Iterator, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+from ._lib import PRECISION_EXACT, PRECISION_FAST
+from .engine import Engine
+from .spec import (COND_CLS, COND_TXT, STAGE2_UNUSED, Stage1Spec, Stage2Spec, stage1_is_ignored, stage1_param_shapes,
+                   stage1_spec_from_config, stage2_param_shapes, stage2_spec_from_config)
+
+
+class _Table:
+    """Stand-in for an nn.Embedding the drivers only inspect (``.weight.shape``)."""
+
+    def __init__(self, weight: torch.Tensor):
+        self.weight = weight
+
+
+class _Stage:
+    prefix = ''
+
+    def __init__(self, shapes: 'OrderedDict[str, tuple]', init: Dict[str, np.ndarray]):
+        self._shapes = shapes
+        self._w: 'OrderedDict[str, torch.Tensor]' = OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in init.items())
+        self._device = torch.device('cpu')
+        self._engine: Optional[Engine] = None
+        self._dirty = True
+
+    # -- nn.Module-like surface
+    def parameters(self) -> Iterator[torch.Tensor]:
+        return iter(self._w.values())
+
+    def state_dict(self) -> 'OrderedDict[str, torch.Tensor]':
+        return OrderedDict(self._w)
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, **_):
+        if device is not None:
+            self._device = torch.device(device)
+            if self._device.type == 'cuda' and self._device.index is None:
+                self._device = torch.device('cuda', torch.cuda.current_device())
+            self._drop_engine()
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device('cuda', device if device is not None else torch.cuda.current_device()))
+
+    def _drop_engine(self):
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = None
+
+    def _ignored(self, key: str) -> bool:
+        return False
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Same contract as nn.Module.load_state_dict (``sampling_hqmodel.py:77-79``): with strict=True a
+        missing or unexpected key, or a shape mismatch, raises RuntimeError."""
+        missing = [k for k in self._shapes if k not in sd]
+        unexpected = [k for k in sd if k not in self._shapes and not self._ignored(k)]
+        errors = []
+        for k, shp in self._shapes.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shp):
+                errors.append(f'size mismatch for {k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(shp)}')
+        if errors or (strict and (missing or unexpected)):
+            raise RuntimeError(f'Error(s) in loading state_dict: missing={missing} unexpected={unexpected} ' + '; '.join(errors))
+        for k in self._shapes:
+            if k in sd:
+                self._w[k] = torch.as_tensor(sd[k]).detach().to('cpu', torch.float32).contiguous().clone()
+        self._drop_engine()
+        return missing, unexpected
+
+    def _need_gpu(self):
+        if self._device.type != 'cuda':
+            raise _lib.HqtLibraryError('the model is on the CPU: call .to("cuda") first (hqtransformer_amd has no CPU compute path)')
+
+
+class HQTransformerStage2(_Stage):
+    """Counterpart of ``iHQGPT`` (``hqvae/models/stage2/hierarchical_ar.py:23-216``) for model_type 'parallel'."""
+
+    def __init__(self, spec: Stage2Spec, seed: int = 0):
+        super().__init__(stage2_param_shapes(spec), synth.stage2_weights(spec, seed, 'bench'))
+        self.spec = spec
+        self.use_cls_cond = spec.cond == COND_CLS
+        self.use_txt_cond = spec.cond == COND_TXT
+        self.idx_pred = spec.idx_pred
+        self.ctx_len_img = spec.ctx_len_img
+        self.n_layers = spec.n_layers
+        self.n_layers_depth = spec.n_layers_depth
+        self.model_type = 'parallel'
+
+    # attributes sampling.py:183-192 and the notebook read
+    @property
+    def sos(self):
+        return _Table(self._w['sos.weight']) if self.use_cls_cond else self._w.get('sos')
+
+    @property
+    def tok_emb_txt(self):
+        return _Table(self._w['tok_emb_txt.weight'])
+
+    @property
+    def pos_emb_txt(self):
+        return _Table(self._w['pos_emb_txt.weight'])
+
+    def engine(self, batch: int, n_steps: int) -> Engine:
+        self._need_gpu()
+        e = self._engine
+        if e is None or batch > e.max_batch or n_steps > e.max_steps:
+            self._drop_engine()
+            e = Engine(self.spec, None, self._device, max(batch, e.max_batch if e else 0), self.spec.ctx_len_img)
+            e.load(stage2={k: v for k, v in self._w.items() if k not in STAGE2_UNUSED})
+            e.finalize()
+            self._engine = e
+        return e
+
+
+class HQVAEStage1(_Stage):
+    """Counterpart of ``SimRQGAN2Generator`` (``hqvae/models/stage1/generator.py:176-395``), decode side only."""
+
+    def __init__(self, spec: Stage1Spec, seed: int = 0):
+        super().__init__(stage1_param_shapes(spec), synth.stage1_weights(spec, seed, 'bench'))
+        self.spec = spec
+        self.precision = 'exact'      # the reference decodes outside autocast, i.e. in fp32 (measure_throughput:108-111)
+        self.bottom_window = 2
+
+    def _ignored(self, key: str) -> bool:
+        return stage1_is_ignored(key)
+
+    def engine(self, batch: int) -> Engine:
+        self._need_gpu()
+        e = self._engine
+        if e is None or batch > e.max_batch:
+            self._drop_engine()
+            e = Engine(None, self.spec, self._device, max(batch, e.max_batch if e else 0))
+            e.load(stage1=self._w)
+            e.finalize()
+            self._engine = e
+        return e
+
+    def decode_code(self, code_t: Optional[torch.Tensor], code_b: Optional[torch.Tensor], precision: Optional[str] = None,
+                    clamp01: bool = False) -> torch.Tensor:
+        """``SimRQGAN2Generator.decode_code`` (generator.py:323-367): int64 code grids -> fp32 [B, 3, H, W],
+        unclamped; either level may be None (zero quant).  ``precision`` 'exact' (fp32, the reference's
+        arithmetic for this call) or 'fast' (bf16 MFMA); defaults to ``self.precision``."""
+        assert code_t is not None or code_b is not None
+        ref = code_t if code_t is not None else code_b
+        prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
+        return self.engine(int(ref.shape[0])).decode(code_t, code_b, precision=prec, clamp01=clamp01)
+
+    def decode_sequences(self, codes_top: torch.Tensor, codes_bot: torch.Tensor, precision: Optional[str] = None,
+                         clamp01: bool = False) -> torch.Tensor:
+        """Decode the sampler's own outputs ([B, HW], [B, HW, 4]); the two rearranges of
+        sampling_hqmodel.py:119-120 are folded into the codebook-gather addressing."""
+        prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
+        return self.engine(int(codes_top.shape[0])).decode(codes_top, codes_bot, precision=prec, clamp01=clamp01, seq_layout=True)
+
+
+class ImageGPT2:
+    """Counterpart of ``hqvae.models.ImageGPT2`` (``hqvae/models/__init__.py:92-174``): builds stage 1 and
+    stage 2 from a merged config with random-init weights (the reference's harness never loads a checkpoint,
+    ``measure_throughput/__main__.py:25-31``)."""
+
+    def __init__(self, config, seed: Optional[int] = None):
+        seed = int(torch.initial_seed() % (2 ** 31)) if seed is None else int(seed)
+        self.config = config
+        self.stage1 = HQVAEStage1(stage1_spec_from_config(config), seed + 1)
+        self.stage2 = HQTransformerStage2(stage2_spec_from_config(config), seed)
+        self.use_cls_cond = config.stage2.use_cls_cond
+        self.use_txt_cond = config.stage2.use_txt_cond
+        self.type = config.stage2.type
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, **kw):
+        self.stage1.to(device)
+        self.stage2.to(device)
+        return self
+
+    def cuda(self, device=None):
+        self.stage1.cuda(device)
+        self.stage2.cuda(device)
+        return self
+
+    def parameters(self) -> Iterator[torch.Tensor]:
+        yield from self.stage1.parameters()
+        yield from self.stage2.parameters()
+
+    def state_dict(self) -> 'OrderedDict[str, torch.Tensor]':
+        out = OrderedDict(('stage1.' + k, v) for k, v in self.stage1.state_dict().items())
+        out.update(('stage2.' + k, v) for k, v in self.stage2.state_dict().items())
+        return out
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Keys carry the ``stage1.`` / ``stage2.`` prefixes of the reference's checkpoints
+        (``sampling_hqmodel.py:77-79``).  Encoder-side stage-1 tensors are accepted and ignored."""
+        s1 = {k[len('stage1.'):]: v for k, v in sd.items() if k.startswith('stage1.')}
+        s2 = {k[len('stage2.'):]: v for k, v in sd.items() if k.startswith('stage2.')}
+        other = [k for k in sd if not k.startswith(('stage1.', 'stage2.'))]
+        if strict and other:
+            raise RuntimeError(f'Error(s) in loading state_dict: unexpected={other}')
+        m1, u1 = self.stage1.load_state_dict(s1, strict)
+        m2, u2 = self.stage2.load_state_dict(s2, strict)
+        return ['stage1.' + k for k in m1] + ['stage2.' + k for k in m2], ['stage1.' + k for k in u1] + ['stage2.' + k for k in u2] + other

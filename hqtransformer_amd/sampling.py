@@ -1,0 +1,90 @@
+"""Counterpart of ``hqvae/utils/sampling.py`` for the HQ-Transformer path.
+
+``sampling_ihqgpt`` keeps the reference's signature and return convention (sampling.py:164-237) and runs
+the whole 64-position loop inside libhqt.so (KV cache, depth head, fused sampler, next-step embedding).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from ._lib import PRECISION_EXACT, PRECISION_FAST
+
+
+def _seed_from_torch() -> int:
+    """The reference consumes torch's global generator through ``torch.multinomial``; the Philox seed of the
+    in-kernel Exp(1) noise is drawn from that same generator so ``set_seed`` keeps runs reproducible."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+@torch.no_grad()
+def sampling_ihqgpt(model,
+                    num_candidates: int,
+                    cond,
+                    top_k_top: Optional[float] = None,
+                    top_p_top: Optional[float] = None,
+                    top_k_bot: Optional[float] = None,
+                    top_p_bot: Optional[float] = None,
+                    softmax_temperature: List[float] = [1.0, 1.0],
+                    is_tqdm: bool = True,
+                    use_fp16: bool = True,
+                    max_seq_len: int = 256,
+                    model_stage1=None,
+                    given_top_code: Optional[torch.LongTensor] = None,
+                    noise: Optional[torch.Tensor] = None,
+                    sample_offset: int = 0,
+                    seed: Optional[int] = None,
+                    use_graph: bool = True):
+    """Returns ``(codes_top int64 [B, max_seq_len], codes_bot int64 [B, max_seq_len, 4])`` on the model's GPU.
+
+    ``model`` is ``ImageGPT2.stage2``.  ``cond``: python int (class id, repeated for every candidate), an
+    int64 tensor [B] of class ids, an int64 tensor [B, ctx_len_txt] (text; B replaces num_candidates,
+    sampling.py:187-190) or anything (unconditional).  ``use_fp16=True`` -> FAST (bf16 MFMA) arithmetic,
+    ``False`` -> EXACT fp32 (what the reference computes on its CPU path).  ``is_tqdm`` and ``model_stage1``
+    are accepted and ignored (the latter only feeds a dead branch, hierarchical_ar.py:697-699).
+    Extensions: ``noise`` fp32 [max_seq_len, 5, B, V] Exp(1) variates (draw = argmax(p/q), the multinomial
+    identity) for bit-reproducible runs; ``sample_offset``/``seed`` for sharded batches.
+    """
+    spec = model.spec
+    if model.use_txt_cond:
+        cond = torch.as_tensor(cond)
+        if cond.dim() != 2:
+            raise ValueError('text conditioning expects cond of shape [B, ctx_len_txt]')
+        B = int(cond.shape[0])
+    else:
+        B = int(num_candidates)
+        if model.use_cls_cond:
+            if isinstance(cond, int):
+                cond = torch.full((B,), int(cond), dtype=torch.int64)
+            else:
+                cond = torch.as_tensor(cond).reshape(-1)
+                if cond.numel() == 1:
+                    cond = cond.repeat(B)
+            if int(cond.min()) < 0 or int(cond.max()) >= spec.n_classes:
+                raise IndexError('index out of range in self')          # what nn.Embedding raises in the reference
+        else:
+            cond = None
+    force_top = None
+    if given_top_code is not None:
+        force_top = torch.as_tensor(given_top_code)
+        if force_top.dim() == 1:
+            force_top = force_top.unsqueeze(0)
+        if force_top.shape[0] != B:
+            force_top = force_top.repeat(B, 1)
+        force_top = force_top[:, :max_seq_len]
+    eng = model.engine(B, max_seq_len)
+    if seed is None and noise is None:
+        seed = _seed_from_torch()
+    return eng.sample(B, cond, max_seq_len, precision=PRECISION_FAST if use_fp16 else PRECISION_EXACT,
+                      top_k=(top_k_top, top_k_bot), top_p=(top_p_top, top_p_bot), temperature=softmax_temperature,
+                      noise=noise, seed=seed or 0, sample_offset=sample_offset, force_top=force_top, use_graph=use_graph)
+
+
+def rearrange_codes(codes_top: torch.Tensor, codes_bot: torch.Tensor, top_resolution: int):
+    """'B (H W) -> B H W' and 'B (H W) (kerH kerW) -> B (H kerH) (W kerW)' with kerH = kerW = 2
+    (``sampling_hqmodel.py:119-120``, ``measure_throughput/__main__.py:106-107``) as pure views."""
+    B, H = codes_top.shape[0], top_resolution
+    ct = codes_top.reshape(B, H, H)
+    cb = codes_bot.reshape(B, H, H, 2, 2).permute(0, 1, 3, 2, 4).reshape(B, 2 * H, 2 * H)
+    return ct, cb

@@ -206,14 +206,14 @@ def test_decode_256_exact_vs_reference_fixture():
 
 def test_decode_fast_tolerance():
     """FAST decode (bf16 activations and filters, fp32 accumulation and GroupNorm statistics): pixels of
-    range ~[-3, 3] within 6e-2 of the fp32 reference, mean abs error within 1e-2."""
+    range ~[-5, 5] within 0.1 of the fp32 reference (2 % of the range), mean abs error within 1e-2."""
     for name in ('g5_decode_64.npz', 'g5_decode_256.npz'):
         fx = load(name)
         spec, weights = stage1_from_fixture(fx)
         eng = engine_s1(spec, weights, 2)
         px = np_(eng.decode(torch.from_numpy(fx['code_t']), torch.from_numpy(fx['code_b']), precision=PRECISION_FAST))
         d = np.abs(px - fx['pixels'])
-        assert d.max() <= 6e-2 and d.mean() <= 1e-2, (name, d.max(), d.mean())
+        assert d.max() <= 0.1 and d.mean() <= 1e-2, (name, d.max(), d.mean())
 
 
 def test_decode_batch_chunking_and_ragged():
