@@ -13,7 +13,7 @@ from typing import List, Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip']
+SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'mfma_gemm.hip']
 ABI_VERSION = 1
 
 PRECISION_EXACT, PRECISION_FAST = 0, 1

@@ -20,7 +20,16 @@ __device__ __host__ inline bf16_t f32_to_bf16(float f) {
 }
 
 enum { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_SIGMOID = 2 };
-enum { STORE_ROWS = 0, STORE_NCHW = 1, STORE_QKV = 2 };
+enum { STORE_ROWS = 0, STORE_NCHW = 1, STORE_QKV = 2, STORE_PACKED = 3 };
+
+// MFMA-fragment-packed activation layout of the AR loop's GEMM A operands (FAST precision):
+// element (row m, column k) of an [Mpad = 32*MB, K] matrix lives at packed_off(m, k, MB), i.e.
+// [k/16][m/32][lane = (k%16)/8*32 + m%32][k%8] -- one 1-KiB wave load is the B-operand fragment of
+// v_mfma_f32_32x32x16_bf16 for (k-step, m-block).
+__device__ __host__ inline long long packed_off(int m, int k, int MB) {
+    return ((long long)(k >> 4) * MB + (m >> 5)) * 512 + ((((k >> 3) & 1) << 5) + (m & 31)) * 8 + (k & 7);
+}
+__device__ __host__ inline int packed_mb(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 128 ? 4 : (M <= 256 ? 8 : 0))); }
 
 // One NT GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]  (+bias, act, +residual) with
 //   * an optional implicit-GEMM A operand: 1x1 / 3x3 'same' convolution over an NHWC tensor, with
@@ -35,6 +44,7 @@ struct GemmArgs {
     int a_rows_per_group;    // plain A row remap: a_row = (m / rpg) * a_group_stride + m % rpg + a_row_offset
     int a_group_stride;
     int a_row_offset;
+    int a_packed_mb;         // > 0: A is in the packed_off() layout with this many 32-row blocks
     int conv_taps;           // 0 = plain, 1 = 1x1, 9 = 3x3
     int H, W, Cin;           // output spatial size and input channels (conv)
     int upsample;            // 1: input is (H/2, W/2), nearest x2 before the conv
@@ -67,6 +77,8 @@ struct GemmArgs {
     void* C2;
     void* C3;
     int qkv_D;
+    int c_packed_mb;         // STORE_PACKED (and the q part of STORE_QKV stays row-major)
+    const void* zero_page;   // >= 16 zero bytes in device memory (source of padded im2col taps for LDS-DMA loads)
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position

@@ -88,11 +88,14 @@ struct hqt_handle {
     void *kcache = nullptr, *vcache = nullptr, *dk = nullptr, *dv = nullptr;
     float* splitk = nullptr;                  // split-K partial slabs of the streaming GEMM
     size_t splitk_elems = 0;
+    struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
     StepState* state = nullptr;
     // ---- stage 1
     std::vector<DecLayer> dec;
     Lin post_quant;
-    void* act[3] = {nullptr, nullptr, nullptr};
+    void* act[4] = {nullptr, nullptr, nullptr, nullptr};   // 3 rotating activation buffers + the normalised/activated copy (FAST)
+    double* gn_partial = nullptr;
+    void* zero_page = nullptr;
     size_t act_elems = 0;
     int dec_chunk = 0;
     void *aq = nullptr, *ak = nullptr, *av = nullptr, *ao = nullptr, *as = nullptr, *quant = nullptr;
@@ -212,7 +215,7 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         const size_t D = c.embed_dim;
         const int Tp = c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1;    // rows of the widest body pass
         h->Tmax = (c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 0) + c.max_steps;
-        const size_t rows = B * (size_t)std::max(Tp, 4);
+        const size_t rows = (B * (size_t)std::max(Tp, 4) + 31) / 32 * 32;
         CHK(dev_alloc(h.get(), (void**)&h->x, rows * D * 4, true));
         CHK(dev_alloc(h.get(), (void**)&h->xd, B * 4 * D * 4, true));
         CHK(dev_alloc(h.get(), &h->hbuf, rows * D * 4, true));
@@ -245,6 +248,14 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         h->dec_chunk = std::min<int>(c.max_batch, 64);
         h->act_elems = per_img * h->dec_chunk;
         for (int i = 0; i < 3; ++i) CHK(dev_alloc(h.get(), &h->act[i], h->act_elems * 4, true));
+        CHK(dev_alloc(h.get(), &h->act[3], h->act_elems * 2, true));
+        CHK(dev_alloc(h.get(), &h->zero_page, 256, true));
+        HIPCHK(hipMemset(h->zero_page, 0, 256));
+        {
+            size_t pe = 0;
+            for (auto& l : h->dec) pe = std::max(pe, gn_stats_fast_partial_elems(h->dec_chunk, l.res * l.res, l.cin, 32));
+            CHK(dev_alloc(h.get(), (void**)&h->gn_partial, pe * sizeof(double), true));
+        }
         const int r = h->dec.front().res;
         size_t attn_c = 0;
         for (auto& l : h->dec) if (l.kind == 2) attn_c = std::max(attn_c, (size_t)l.cin * l.res * l.res);
@@ -435,6 +446,7 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
             }
         }
     }
+    HIPCHK(stream_gemm_configure());
     HIPCHK(hipDeviceSynchronize());
     h->finalized = true;
     return HQT_OK;
@@ -449,15 +461,19 @@ struct Mode {
 
 // y = x W^T (+b)(act)(+resid): picks the MFMA kernels in FAST mode when the shape allows
 static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, int a_dt, int c_dt, hipStream_t st,
-                      const char* tag) {
+                      const char* tag, bool defer_residual = false) {
     g.N = l.N; g.K = l.K; g.ldb = l.K;
     g.bias = l.b32;
+    g.zero_page = h->zero_page;
     if (g.alpha == 0.0f) g.alpha = 1.0f;
     if (g.lda == 0) g.lda = l.K;
     Timed t(h, tag, st);
     if (md.fast) {
         if (l.wpk && !g.conv_taps && stream_gemm_ok(g, a_dt, c_dt)) {
-            HIPCHK(launch_stream_gemm(g, l.wpk, a_dt, c_dt, h->splitk, h->splitk_elems, st));
+            int S = defer_residual ? stream_gemm_splitk(g) : 1;
+            if ((size_t)S * 32 * g.a_packed_mb * g.N > h->splitk_elems) S = 1;
+            HIPCHK(launch_stream_gemm(g, l.wpk, a_dt, c_dt, S, h->splitk, st));
+            if (S > 1) { h->pend.slabs = h->splitk; h->pend.S = S; h->pend.rows = 32 * g.a_packed_mb; h->pend.bias = l.b32; }
             return HQT_OK;
         }
         g.Bw = l.w16;
@@ -485,41 +501,45 @@ struct SampleCtx {
 
 static const float* W(hqt_handle* h, const char* name) { return h->w[std::string("stage2.") + name].d; }
 
+static int run_ln(hqt_handle* h, hipStream_t st, float* x, const float* g, const float* b, const float* add, void* y, int M,
+                  int D, int in_rpg, int in_off, int out_dt, int out_pk) {
+    Timed t(h, "layernorm", st);
+    LNArgs ln{x, g, b, add, y, M, D, in_rpg, in_off, 1e-5f, out_dt, out_pk, h->pend.slabs, h->pend.S, h->pend.rows, h->pend.bias};
+    h->pend.slabs = nullptr; h->pend.S = 0;
+    HIPCHK(launch_layernorm(ln, st));
+    return HQT_OK;
+}
+
 // One transformer block over M = B*Tq rows (stage2/layers.py:324-328,371-375)
 static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float* x, int Tq, void* kc, void* vc, int Tcache,
                      int t_base, const int* t_base_dev, int causal) {
     const int D = h->cfg.embed_dim, M = c.B * Tq;
     const int adt = c.md.act_dt();
-    {
-        Timed t(h, "layernorm", c.st);
-        LNArgs ln{x, bw.ln1_g, bw.ln1_b, nullptr, h->hbuf, M, D, 1, 0, 1e-5f, adt};
-        HIPCHK(launch_layernorm(ln, c.st));
-    }
+    // FAST: GEMM A operands travel in the MFMA-fragment-packed layout when the streaming GEMM serves them
+    const int pk = (c.md.fast && M <= 256 && bw.qkv.wpk && bw.proj.wpk && bw.fc1.wpk && bw.fc2.wpk) ? packed_mb(M) : 0;
+    CHK(run_ln(h, c.st, x, bw.ln1_g, bw.ln1_b, nullptr, h->hbuf, M, D, 1, 0, adt, pk));
     GemmArgs g{};
-    g.A = h->hbuf; g.M = M; g.batch = 1;
+    g.A = h->hbuf; g.M = M; g.batch = 1; g.a_packed_mb = pk;
     g.C = h->qbuf; g.C2 = kc; g.C3 = vc; g.ldc = D; g.qkv_D = D; g.store = STORE_QKV;
     g.rows_per_group = Tq; g.group_stride = Tcache; g.row_offset = t_base; g.row_offset_dev = t_base_dev;
     CHK(run_linear(h, c.md, g, bw.qkv, adt, adt, c.st, "gemm_qkv"));
     {
         Timed t(h, "attention", c.st);
-        AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, adt};
+        AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, adt, pk};
         HIPCHK(launch_attention(a, c.st));
     }
     g = GemmArgs{};
-    g.A = h->abuf; g.M = M; g.batch = 1; g.C = x; g.ldc = D; g.resid = x; g.store = STORE_ROWS;
-    CHK(run_linear(h, c.md, g, bw.proj, adt, DT_F32, c.st, "gemm_proj"));
-    {
-        Timed t(h, "layernorm", c.st);
-        LNArgs ln{x, bw.ln2_g, bw.ln2_b, nullptr, h->hbuf, M, D, 1, 0, 1e-5f, adt};
-        HIPCHK(launch_layernorm(ln, c.st));
-    }
+    g.A = h->abuf; g.M = M; g.batch = 1; g.a_packed_mb = pk; g.C = x; g.ldc = D; g.resid = x; g.store = STORE_ROWS;
+    CHK(run_linear(h, c.md, g, bw.proj, adt, DT_F32, c.st, "gemm_proj", true));
+    CHK(run_ln(h, c.st, x, bw.ln2_g, bw.ln2_b, nullptr, h->hbuf, M, D, 1, 0, adt, pk));
     g = GemmArgs{};
-    g.A = h->hbuf; g.M = M; g.batch = 1; g.C = h->mbuf; g.ldc = 4 * D; g.store = STORE_ROWS;
+    g.A = h->hbuf; g.M = M; g.batch = 1; g.a_packed_mb = pk; g.C = h->mbuf; g.ldc = 4 * D;
+    g.store = pk ? STORE_PACKED : STORE_ROWS; g.c_packed_mb = pk;
     g.act = h->cfg.gelu_approx ? ACT_GELU_SIGMOID : ACT_GELU_ERF;
     CHK(run_linear(h, c.md, g, bw.fc1, adt, adt, c.st, "gemm_fc1"));
     g = GemmArgs{};
-    g.A = h->mbuf; g.M = M; g.batch = 1; g.C = x; g.ldc = D; g.resid = x; g.store = STORE_ROWS;
-    CHK(run_linear(h, c.md, g, bw.fc2, adt, DT_F32, c.st, "gemm_fc2"));
+    g.A = h->mbuf; g.M = M; g.batch = 1; g.a_packed_mb = pk; g.C = x; g.ldc = D; g.resid = x; g.store = STORE_ROWS;
+    CHK(run_linear(h, c.md, g, bw.fc2, adt, DT_F32, c.st, "gemm_fc2", true));
     return HQT_OK;
 }
 
@@ -533,22 +553,17 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     for (int l = 0; l < cf.n_layers; ++l)
         CHK(run_block(h, c, h->body[l], h->x, Tq_body, (char*)h->kcache + l * kv_layer, (char*)h->vcache + l * kv_layer,
                       h->Tmax, body_t_base, body_tbase_from_state ? &h->state->t_base : nullptr, 1));
-    {   // ln_f on the last token of each sample, + sos_depth (hierarchical_ar.py:561,684-686)
-        Timed t(h, "layernorm", c.st);
-        LNArgs ln{h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, 1e-5f, DT_F32};
-        HIPCHK(launch_layernorm(ln, c.st));
-    }
+    // ln_f on the last token of each sample, + sos_depth (hierarchical_ar.py:561,684-686)
+    CHK(run_ln(h, c.st, h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, DT_F32, 0));
     const size_t dkv_layer = (size_t)cf.max_batch * 5 * D * esz;
+    const int pk1 = (c.md.fast && B <= 256 && h->head_top.wpk) ? packed_mb(B) : 0;
+    const int pk4 = (c.md.fast && 4 * B <= 256 && h->head_bot.wpk) ? packed_mb(4 * B) : 0;
     // ---- depth sub-step 0: top code
     for (int l = 0; l < cf.n_layers_depth; ++l)
         CHK(run_block(h, c, h->depth[l], h->xd, 1, (char*)h->dk + l * dkv_layer, (char*)h->dv + l * dkv_layer, 5, 0, nullptr, 0));
-    {
-        Timed t(h, "layernorm", c.st);
-        LNArgs ln{h->xd, W(h, "ln_top.weight"), W(h, "ln_top.bias"), nullptr, h->hbuf, B, D, 1, 0, 1e-5f, adt};
-        HIPCHK(launch_layernorm(ln, c.st));
-    }
+    CHK(run_ln(h, c.st, h->xd, W(h, "ln_top.weight"), W(h, "ln_top.bias"), nullptr, h->hbuf, B, D, 1, 0, adt, pk1));
     GemmArgs g{};
-    g.A = h->hbuf; g.M = B; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
+    g.A = h->hbuf; g.M = B; g.batch = 1; g.a_packed_mb = pk1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
     CHK(run_linear(h, c.md, g, h->head_top, adt, DT_F32, c.st, "gemm_head"));
     {
         Timed t(h, "sampler", c.st);
@@ -564,13 +579,9 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     }
     for (int l = 0; l < cf.n_layers_depth; ++l)
         CHK(run_block(h, c, h->depth[l], h->xd, 4, (char*)h->dk + l * dkv_layer, (char*)h->dv + l * dkv_layer, 5, 1, nullptr, 0));
-    {
-        Timed t(h, "layernorm", c.st);
-        LNArgs ln{h->xd, W(h, "ln_bot.weight"), W(h, "ln_bot.bias"), nullptr, h->hbuf, 4 * B, D, 1, 0, 1e-5f, adt};
-        HIPCHK(launch_layernorm(ln, c.st));
-    }
+    CHK(run_ln(h, c.st, h->xd, W(h, "ln_bot.weight"), W(h, "ln_bot.bias"), nullptr, h->hbuf, 4 * B, D, 1, 0, adt, pk4));
     g = GemmArgs{};
-    g.A = h->hbuf; g.M = 4 * B; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
+    g.A = h->hbuf; g.M = 4 * B; g.batch = 1; g.a_packed_mb = pk4; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
     CHK(run_linear(h, c.md, g, h->head_bot, adt, DT_F32, c.st, "gemm_head"));
     {
         Timed t(h, "sampler", c.st);
@@ -692,10 +703,26 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
     void* cur = h->act[0];
     void* t1 = h->act[1];
     void* t2 = h->act[2];
+    void* tn = h->act[3];
     {
         GemmArgs g = conv_args(h->quant, n, r, 2 * E, 1, 0, cur, cf.s1_z_channels);
         CHK(run_linear(h, md, g, h->post_quant, adt, adt, st, "conv1x1"));
     }
+    // GroupNorm(+swish) in front of a conv.  EXACT: statistics pass, then the normalisation is applied inside
+    // the conv's operand loader.  FAST: statistics pass + one bandwidth-bound apply pass into `tn`, so the MFMA
+    // conv reads a plain bf16 tensor.  Returns the tensor the conv must read and fills the loader's GN fields.
+    auto norm = [&](const void* src, int C, int hw, float* stats, const float* gamma, const float* beta, int swish,
+                    GemmArgs* g) -> int {
+        if (md.fast) {
+            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats_fast(src, stats, h->gn_partial, n, hw, C, 32, 1e-6f, st)); }
+            { Timed t(h, "gn_apply", st); HIPCHK(launch_gn_apply(src, tn, stats, gamma, beta, n, hw, C, 32, swish, st)); }
+            g->A = tn;
+        } else {
+            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(src, adt, stats, n, hw, C, 32, 1e-6f, st)); }
+            with_gn(*g, stats, gamma, beta, swish);
+        }
+        return HQT_OK;
+    };
     for (auto& l : h->dec) {
         const int res = l.res, hw = res * res;
         if (l.kind == 0 || l.kind == 3) {
@@ -704,66 +731,61 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
             CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
             std::swap(cur, t1);
         } else if (l.kind == 1) {               // ResnetBlock (stage1/modules/layers.py:115-133)
-            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(cur, adt, gn1, n, hw, l.cin, 32, 1e-6f, st)); }
             GemmArgs g = conv_args(cur, n, res, l.cin, 9, 0, t1, l.cout);
-            with_gn(g, gn1, l.n1_g, l.n1_b, 1);
+            CHK(norm(cur, l.cin, hw, gn1, l.n1_g, l.n1_b, 1, &g));
             CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
-            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(t1, adt, gn2, n, hw, l.cout, 32, 1e-6f, st)); }
             const void* shortcut = cur;
             void* outbuf = t2;
             if (l.cin != l.cout) {
-                GemmArgs s = conv_args(cur, n, res, l.cin, 1, 0, t2, l.cout);
-                CHK(run_linear(h, md, s, l.nin, adt, adt, st, "conv1x1"));
+                GemmArgs sc = conv_args(cur, n, res, l.cin, 1, 0, t2, l.cout);
+                CHK(run_linear(h, md, sc, l.nin, adt, adt, st, "conv1x1"));
                 shortcut = t2;
                 outbuf = cur;                   // x is dead once the shortcut is computed
             }
             g = conv_args(t1, n, res, l.cout, 9, 0, outbuf, l.cout);
-            with_gn(g, gn2, l.n2_g, l.n2_b, 1);
+            CHK(norm(t1, l.cout, hw, gn2, l.n2_g, l.n2_b, 1, &g));
             g.resid = shortcut;
             CHK(run_linear(h, md, g, l.conv2, adt, adt, st, "conv3x3"));
             if (outbuf == t2) std::swap(cur, t2);
         } else if (l.kind == 2) {               // AttnBlock (stage1/modules/layers.py:163-186)
             const int C = l.cin;
-            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(cur, adt, gn1, n, hw, C, 32, 1e-6f, st)); }
             GemmArgs g = conv_args(cur, n, res, C, 1, 0, h->aq, C);
-            with_gn(g, gn1, l.n1_g, l.n1_b, 0);
+            CHK(norm(cur, C, hw, gn1, l.n1_g, l.n1_b, 0, &g));
+            const GemmArgs normed = g;           // same normalised input for q, k, v
             CHK(run_linear(h, md, g, l.q, adt, adt, st, "conv1x1"));
-            g = conv_args(cur, n, res, C, 1, 0, h->ak, C);
-            with_gn(g, gn1, l.n1_g, l.n1_b, 0);
+            g = normed; g.C = h->ak;
             CHK(run_linear(h, md, g, l.k, adt, adt, st, "conv1x1"));
-            g = conv_args(cur, n, res, C, 1, 0, h->av, C);
-            with_gn(g, gn1, l.n1_g, l.n1_b, 0);
+            g = normed; g.C = h->av;
             g.store = STORE_NCHW; g.rows_per_image = hw;                 // V^T per image: [C][hw]
             CHK(run_linear(h, md, g, l.v, adt, adt, st, "conv1x1"));
             {   // S[i, j] = q_i . k_j * C^-0.5
                 Timed t(h, "attn_gemm", st);
-                GemmArgs s{};
-                s.A = h->aq; s.lda = C; s.a_batch_stride = (long long)hw * C;
-                s.Bw = h->ak; s.ldb = C; s.b_batch_stride = (long long)hw * C;
-                s.C = h->as; s.ldc = hw; s.c_batch_stride = (long long)hw * hw;
-                s.M = hw; s.N = hw; s.K = C; s.batch = n; s.alpha = 1.0f / sqrtf((float)C); s.store = STORE_ROWS;
-                if (md.fast && mfma_gemm_ok(s, adt, adt, adt)) HIPCHK(launch_mfma_gemm(s, adt, adt, adt, st));
-                else HIPCHK(launch_gemm_generic(s, adt, adt, adt, st));
+                GemmArgs sg{};
+                sg.A = h->aq; sg.lda = C; sg.a_batch_stride = (long long)hw * C;
+                sg.Bw = h->ak; sg.ldb = C; sg.b_batch_stride = (long long)hw * C;
+                sg.C = h->as; sg.ldc = hw; sg.c_batch_stride = (long long)hw * hw;
+                sg.M = hw; sg.N = hw; sg.K = C; sg.batch = n; sg.alpha = 1.0f / sqrtf((float)C); sg.store = STORE_ROWS;
+                if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
+                else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
             }
             { Timed t(h, "softmax", st); HIPCHK(launch_softmax_rows(h->as, adt, n * hw, hw, st)); }
             {   // o[i, c] = sum_j w[i, j] v[c, j]
                 Timed t(h, "attn_gemm", st);
-                GemmArgs s{};
-                s.A = h->as; s.lda = hw; s.a_batch_stride = (long long)hw * hw;
-                s.Bw = h->av; s.ldb = hw; s.b_batch_stride = (long long)hw * C;
-                s.C = h->ao; s.ldc = C; s.c_batch_stride = (long long)hw * C;
-                s.M = hw; s.N = C; s.K = hw; s.batch = n; s.alpha = 1.0f; s.store = STORE_ROWS;
-                if (md.fast && mfma_gemm_ok(s, adt, adt, adt)) HIPCHK(launch_mfma_gemm(s, adt, adt, adt, st));
-                else HIPCHK(launch_gemm_generic(s, adt, adt, adt, st));
+                GemmArgs sg{};
+                sg.A = h->as; sg.lda = hw; sg.a_batch_stride = (long long)hw * hw;
+                sg.Bw = h->av; sg.ldb = hw; sg.b_batch_stride = (long long)hw * C;
+                sg.C = h->ao; sg.ldc = C; sg.c_batch_stride = (long long)hw * C;
+                sg.M = hw; sg.N = C; sg.K = hw; sg.batch = n; sg.alpha = 1.0f; sg.store = STORE_ROWS;
+                if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
+                else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
             }
             g = conv_args(h->ao, n, res, C, 1, 0, t1, C);
             g.resid = cur;
             CHK(run_linear(h, md, g, l.proj, adt, adt, st, "conv1x1"));
             std::swap(cur, t1);
         } else {                                // norm_out -> swish -> conv_out, NCHW fp32 (+clamp)
-            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(cur, adt, gn1, n, hw, l.cin, 32, 1e-6f, st)); }
             GemmArgs g = conv_args(cur, n, res, l.cin, 9, 0, out, l.cout);
-            with_gn(g, gn1, l.n1_g, l.n1_b, 1);
+            CHK(norm(cur, l.cin, hw, gn1, l.n1_g, l.n1_b, 1, &g));
             g.store = STORE_NCHW; g.rows_per_image = hw; g.clamp01 = clamp01;
             CHK(run_linear(h, md, g, l.conv1, adt, DT_F32, st, "conv_out"));
         }

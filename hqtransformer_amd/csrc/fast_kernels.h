@@ -12,8 +12,11 @@ hipError_t launch_repack_conv(const float* src, float* dst, int O, int I, int ta
 bool stream_gemm_supported(int N, int K);
 hipError_t launch_pack_stream_weights(const float* w32, bf16_t* packed, int N, int K, hipStream_t st);
 bool stream_gemm_ok(const GemmArgs& g, int a_dt, int c_dt);
-hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, float* splitk, size_t splitk_elems,
-                              hipStream_t st);
+hipError_t stream_gemm_configure();     // raise dynamic-LDS limits once (call outside stream capture)
+// S = stream_gemm_splitk(g) (> 1 only when the caller can defer bias + residual to the next LayerNorm):
+// slabs [S][32 * a_packed_mb][N] fp32 receive the partial sums and no epilogue runs.
+int stream_gemm_splitk(const GemmArgs& g);
+hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, int S, float* slabs, hipStream_t st);
 
 // ---- tiled MFMA GEMM / implicit-GEMM conv (decoder, text prefill)
 bool mfma_gemm_ok(const GemmArgs& g, int a_dt, int b_dt, int c_dt);

@@ -1,6 +1,15 @@
+// FAST-precision kernels (bf16 operands, fp32 accumulation on the gfx950 matrix cores).
 #include "fast_kernels.h"
 #include "gemm_generic.h"
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// ---------------------------------------------------------------------------------------------
+// finalize-time repacks
+// ---------------------------------------------------------------------------------------------
 __global__ void f32_to_bf16_kernel(const float* src, bf16_t* dst, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i] = f32_to_bf16(src[i]);
@@ -27,9 +36,214 @@ hipError_t launch_repack_conv(const float* src, float* dst, int O, int I, int ta
     return hipGetLastError();
 }
 
-bool stream_gemm_supported(int, int) { return false; }
-hipError_t launch_pack_stream_weights(const float*, bf16_t*, int, int, hipStream_t) { return hipErrorNotSupported; }
-bool stream_gemm_ok(const GemmArgs&, int, int) { return false; }
-hipError_t launch_stream_gemm(const GemmArgs&, const bf16_t*, int, int, float*, size_t, hipStream_t) { return hipErrorNotSupported; }
-bool mfma_gemm_ok(const GemmArgs&, int, int, int) { return false; }
-hipError_t launch_mfma_gemm(const GemmArgs&, int, int, int, hipStream_t) { return hipErrorNotSupported; }
+// ---------------------------------------------------------------------------------------------
+// K2/K4/K5: weight-streaming GEMM of the AR loop.
+//
+//   y[M, N] = x[M, K] W[N, K]^T,   M = B or 4B <= 256 rows, W streamed from HBM exactly once.
+//
+// Weights are packed at finalize into 1-KiB chunks, chunk (n-tile nt of 32 rows, k-step ks of 16) =
+// the A-operand fragment of v_mfma_f32_32x32x16_bf16: lane l holds W[32 nt + (l & 31)][16 ks + 8 (l >> 5) + j],
+// j = 0..7.  Chunks of one n-tile are contiguous along k, so a wave streams a contiguous run with
+// one fully coalesced global_load_dwordx4 per chunk, straight into VGPRs (no LDS round trip: each
+// weight byte is used by exactly one wave).  Activations arrive in the packed_off() layout (written
+// by the producing LayerNorm / attention / GELU epilogue), so the B-operand fragments of the 32-row
+// m-blocks are 1-KiB coalesced loads as well, served by L2.
+//
+// One workgroup = one n-tile x all of K; its NW waves split K into contiguous runs, accumulate
+// [32 n x 32 MB m] in registers, reduce through LDS, and all threads run the fused epilogue
+// (bias, GELU, residual, KV-cache append / QKV split, packed store for the next GEMM).
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_stream_weights_kernel(const float* w, bf16_t* out, int N, int K) {
+    const size_t total = (size_t)N * K;
+    const int KS = K / 16;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        const size_t chunk = i >> 9;
+        const int ks = (int)(chunk % KS);
+        const int nt = (int)(chunk / KS);
+        const int n = nt * 32 + (lane & 31);
+        const int k = ks * 16 + 8 * (lane >> 5) + j;
+        out[i] = f32_to_bf16(w[(size_t)n * K + k]);
+    }
+}
+bool stream_gemm_supported(int N, int K) { return N % 32 == 0 && K % 16 == 0; }
+hipError_t launch_pack_stream_weights(const float* w32, bf16_t* packed, int N, int K, hipStream_t st) {
+    const size_t n = (size_t)N * K;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+    pack_stream_weights_kernel<<<grid, 256, 0, st>>>(w32, packed, N, K);
+    return hipGetLastError();
+}
+
+// Tile of one workgroup: (32 NT) weight rows x (32 MBW) activation rows x K / gridDim.z; the NW waves
+// split that K range into contiguous runs.  gridDim = (N / (32 NT), MB_total / MBW, S).  With S > 1
+// (cross-workgroup split-K) the fp32 partial tile goes to slab z of `slabs` ([S][Mpad][N]) and the
+// epilogue runs in the consumer (LayerNorm combine); with S == 1 the fused epilogue runs here.
+template <int MBW, int NT, int NW, int U, typename TC, int ABL = 0>   // ABL: ablation switches of tools/micro/bench_stream
+__global__ __launch_bounds__(NW * 64) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);                  // [NW][NT*32 n][MBW*32 m] as [NT][MBW][m32][n32]
+    constexpr int TILE = NT * MBW * 1024;
+    long long stamp[6];
+    if (ABL == 9) { stamp[0] = wall_clock64(); stamp[1] = clock64(); }
+    const int ntile0 = blockIdx.x * NT;
+    const int mb0 = blockIdx.y * MBW;
+    const int MB = g.a_packed_mb;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int KS = g.K >> 4;
+    const int S = gridDim.z;
+    const int kz0 = (int)(((long long)KS * blockIdx.z) / S), kz1 = (int)(((long long)KS * (blockIdx.z + 1)) / S);
+    const int per = (kz1 - kz0 + NW - 1) / NW;
+    const int ks0 = kz0 + wave * per;
+    const int cnt = max(0, min(kz1, ks0 + per) - ks0);
+    const u32x4* wp = wpk + ((size_t)ntile0 * KS + ks0) * 64 + lane;          // + t * KS * 64 per n-tile
+    const u32x4* xp = reinterpret_cast<const u32x4*>(g.A) + ((size_t)ks0 * MB + mb0) * 64 + lane;
+
+    f32x16 acc[NT][MBW];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][mb][r] = 0.0f;
+
+    // Loads are issued unconditionally (indices clamped, never predicated): a load inside a branch
+    // gets its own s_waitcnt and the whole run degenerates into serial round trips.
+    u32x4 wbuf[U][NT];
+    u32x4 xbuf[U][MBW];
+    int ks = 0;
+    for (; ks + U <= cnt; ks += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wbuf[u][t] = __builtin_nontemporal_load(wp + ((size_t)t * KS + (ABL == 2 ? 0 : ks + u)) * 64);
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) xbuf[u][mb] = xp[((size_t)(ABL == 1 ? 0 : ks + u) * MB + mb) * 64];
+        }
+        // keep every load of the run in flight before the first MFMA: without this fence the
+        // scheduler re-rolls the block into 2-4 loads per wait to save VGPRs (12+ serial round trips)
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL == 9) { stamp[2] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, wbuf[u][t]);
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb)
+                    acc[t][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, xbuf[u][mb]), acc[t][mb], 0, 0, 0);
+            }
+    }
+    if (ks < cnt) {                                   // ragged tail (tiny K only)
+        const int rem = cnt - ks;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = ks + min(u, rem - 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wbuf[u][t] = __builtin_nontemporal_load(wp + ((size_t)t * KS + kk) * 64);
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) xbuf[u][mb] = xp[((size_t)kk * MB + mb) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (u < rem) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 wf = __builtin_bit_cast(bf16x8, wbuf[u][t]);
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb)
+                        acc[t][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, xbuf[u][mb]), acc[t][mb], 0, 0, 0);
+                }
+            }
+    }
+    if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); stamp[3] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+    // ---- cross-wave reduction through LDS; C/D map: col = lane & 31 -> m, row = (r&3) + 8 (r>>2) + 4 (lane>>5) -> n
+    {
+        float* my = red + (size_t)wave * TILE;
+        const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 v = {acc[t][mb][4 * gq], acc[t][mb][4 * gq + 1], acc[t][mb][4 * gq + 2], acc[t][mb][4 * gq + 3]};
+                    *reinterpret_cast<f32x4*>(my + ((t * MBW + mb) * 32 + c) * 32 + 8 * gq + 4 * h) = v;
+                }
+    }
+    __syncthreads();
+    if (ABL == 9) stamp[4] = clock64();
+    if (ABL == 3) {
+        if (threadIdx.x == 0) reinterpret_cast<float*>(g.C)[blockIdx.x] = red[0] + red[TILE];
+        return;
+    }
+    for (int o = threadIdx.x; o < TILE; o += NW * 64) {
+        const int n = o & 31, ml = (o >> 5) & 31, blk = o >> 10;
+        const int mb = blk % MBW, t = blk / MBW;
+        const int m = (mb0 + mb) * 32 + ml;
+        if (m >= g.M) continue;
+        float s = red[o];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[(size_t)w * TILE + o];
+        const int ncol = (ntile0 + t) * 32 + n;
+        if (S > 1 && ABL != 9) slabs[((size_t)blockIdx.z * (MB * 32) + m) * g.N + ncol] = s;
+        else gemm_store<TC>(g, 0, m, ncol, s);
+    }
+    if (ABL == 9) {
+        stamp[5] = clock64();
+        if (lane == 0) {
+            long long* dbg = reinterpret_cast<long long*>(slabs) + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * NW + wave) * 8;
+            dbg[0] = stamp[0]; dbg[1] = stamp[2] - stamp[1]; dbg[2] = stamp[3] - stamp[1]; dbg[3] = stamp[4] - stamp[1]; dbg[4] = stamp[5] - stamp[1];
+            dbg[5] = wall_clock64();
+        }
+    }
+}
+
+bool stream_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
+    (void)c_dt;
+    return g.a_packed_mb > 0 && a_dt == DT_BF16 && !g.conv_taps && g.M <= 256 && g.batch <= 1 && g.N % 64 == 0 &&
+           g.K % 16 == 0 && g.a_packed_mb == packed_mb(g.M);
+}
+
+template <int MBW, int NT, int NW, int U, typename TC>
+static hipError_t launch_stream_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
+    const size_t smem = (size_t)NW * NT * MBW * 4096;
+    const dim3 grid(g.N / (32 * NT), g.a_packed_mb / MBW, S);
+    stream_gemm_kernel<MBW, NT, NW, U, TC><<<grid, NW * 64, smem, st>>>(g, reinterpret_cast<const u32x4*>(wpk), slabs);
+    return hipGetLastError();
+}
+// configuration table (tools/micro/bench_stream on MI355X): per-CU L2->L1 bandwidth (~40 GB/s) bounds these
+// kernels, so the decomposition maximises the number of busy CUs; narrow-N GEMMs split K across
+// workgroups (S > 1) and leave the fp32 partial slabs to the next LayerNorm.
+#define STREAM_CASES(X, TC) \
+    X(1, 1, 8, 12, TC) X(2, 1, 8, 12, TC)
+int stream_gemm_splitk(const GemmArgs& g) {
+    const int KS = g.K / 16;
+    const int wgs = (g.N / 32) * g.a_packed_mb;            // with MBW = 1
+    if (g.a_packed_mb > 2 || wgs >= 128) return 1;
+    for (int S = 4; S >= 2; S >>= 1)
+        if (wgs * S <= 256 && KS % (S * 8) == 0) return S;
+    return 1;
+}
+template <typename TC>
+static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
+    const int wgs2 = (g.N / 32) * (g.a_packed_mb / 2);
+    if (S == 1 && g.a_packed_mb == 2 && wgs2 >= 128) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);
+    return launch_stream_t<1, 1, 8, 12, TC>(g, wpk, S, slabs, st);
+}
+hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, int S, float* slabs, hipStream_t st) {
+    (void)a_dt;
+    return c_dt == DT_BF16 ? launch_stream_c<bf16_t>(g, wpk, S, slabs, st) : launch_stream_c<float>(g, wpk, S, slabs, st);
+}
+// every instantiation raises its dynamic-LDS limit once, outside stream capture
+hipError_t stream_gemm_configure() {
+    hipError_t e;
+#define CFG(MBW, NT, NW, U, TC)                                                                                    \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, TC>),                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NW * NT * MBW * 4096));      \
+    if (e != hipSuccess) return e;
+    STREAM_CASES(CFG, bf16_t)
+    STREAM_CASES(CFG, float)
+#undef CFG
+    return hipSuccess;
+}

@@ -92,6 +92,10 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int bz, int m, int
         st1<TC>(reinterpret_cast<TC*>(g.C) + ((long long)img * g.N + n) * g.rows_per_image + pix, v);
         return;
     }
+    if (g.store == STORE_PACKED) {
+        st1<TC>(reinterpret_cast<TC*>(g.C) + packed_off(m, n, g.c_packed_mb), v);
+        return;
+    }
     int orow = m;
     if (g.rows_per_group > 0) {
         orow = (m / g.rows_per_group) * g.group_stride + m % g.rows_per_group + g.row_offset;

@@ -33,7 +33,7 @@ hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepS
                               const float* pos, float* x, int B, int D, hipStream_t st);
 
 struct LNArgs {
-    const float* x;              // [rows_in, D]
+    float* x;                    // [rows_in, D]; rewritten in place when split-K slabs are folded in
     const float* gamma;
     const float* beta;
     const float* add;            // optional [D] vector added after the affine (sos_depth)
@@ -43,6 +43,12 @@ struct LNArgs {
     int in_row_offset;
     float eps;
     int out_dtype;               // DT_*
+    int out_packed_mb;           // > 0: write y in the packed_off() layout (bf16 only)
+    // pending split-K residual of the previous GEMM: x[m] += slab_bias + sum_s slabs[s][m][:] before normalising
+    const float* slabs;          // [n_slabs][slab_rows][D] fp32 or NULL
+    int n_slabs;
+    int slab_rows;
+    const float* slab_bias;      // [D] or NULL
 };
 hipError_t launch_layernorm(const LNArgs& a, hipStream_t st);
 
@@ -56,6 +62,7 @@ struct AttnArgs {
     const int* t_base_dev;       // optional device int added to t_base
     int causal;                  // 1: query i sees keys [0, t_base + i]; 0: all t_base + Tq keys
     int dtype;                   // DT_* of q / cache / out
+    int out_packed_mb;           // > 0: write out in the packed_off() layout
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
 
@@ -102,3 +109,12 @@ hipError_t launch_gn_stats(const void* x, int dtype, float* stats, int B, int HW
 
 // in-place softmax over the last axis of fp32 [rows, n]
 hipError_t launch_softmax_rows(void* x, int dtype, int rows, int n, hipStream_t st);
+
+// FAST decoder: y = swish?(GroupNorm(x)) as its own bandwidth-bound pass (bf16 NHWC -> bf16 NHWC), so the
+// convolution's operand loader stays a plain im2col gather.  stats: [B][groups][2] (mean, rstd).
+hipError_t launch_gn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, int B, int HW,
+                           int C, int groups, int swish, hipStream_t st);
+// FAST decoder GroupNorm statistics: coalesced partial sums per (image, pixel chunk), then a finalize pass
+hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, int B, int HW, int C, int groups, float eps,
+                                hipStream_t st);
+size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups);

@@ -109,19 +109,58 @@ template <typename TO>
 __global__ __launch_bounds__(256) void layernorm_kernel(LNArgs a) {
     __shared__ float red[4];
     const int m = blockIdx.x, D = a.D;
-    const float* x = a.x + ((long long)m * a.in_rows_per_group + a.in_row_offset) * D;
+    float* x = a.x + ((long long)m * a.in_rows_per_group + a.in_row_offset) * D;
+    // each thread keeps its (up to 8) elements in registers: one global read of the row
+    float v[8];
     float s = 0.0f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) s += x[d];
-    const float mean = block_reduce(s, OpAdd(), red) / (float)D;
-    float v = 0.0f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) { const float t = x[d] - mean; v += t * t; }
-    const float var = block_reduce(v, OpAdd(), red) / (float)D;
-    const float rstd = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int d = threadIdx.x + i * 256;
+        v[i] = 0.0f;
+        if (d < D) {
+            float t = x[d];
+            if (a.n_slabs > 0) {              // fold in the split-K partial sums (+bias) of the previous GEMM
+                if (a.slab_bias) t += a.slab_bias[d];
+                for (int sl = 0; sl < a.n_slabs; ++sl) t += a.slabs[((long long)sl * a.slab_rows + m) * D + d];
+                x[d] = t;
+            }
+            v[i] = t;
+            s += t;
+        }
+    }
+    float mean, rstd;
+    if (D <= 2048) {
+        mean = block_reduce(s, OpAdd(), red) / (float)D;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int d = threadIdx.x + i * 256; if (d < D) { const float t = v[i] - mean; q += t * t; } }
+        rstd = 1.0f / sqrtf(block_reduce(q, OpAdd(), red) / (float)D + a.eps);
+    } else {                                   // wide rows: re-read
+        for (int d = threadIdx.x + 2048; d < D; d += 256) s += x[d];
+        mean = block_reduce(s, OpAdd(), red) / (float)D;
+        float q = 0.0f;
+        for (int d = threadIdx.x; d < D; d += 256) { const float t = x[d] - mean; q += t * t; }
+        rstd = 1.0f / sqrtf(block_reduce(q, OpAdd(), red) / (float)D + a.eps);
+    }
     TO* y = reinterpret_cast<TO*>(a.y) + (long long)m * D;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float t = (x[d] - mean) * rstd * a.gamma[d] + a.beta[d];
-        if (a.add) t += a.add[d];
-        st1<TO>(y + d, t);
+    if (D <= 2048) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = threadIdx.x + i * 256;
+            if (d < D) {
+                float t = (v[i] - mean) * rstd * a.gamma[d] + a.beta[d];
+                if (a.add) t += a.add[d];
+                if (a.out_packed_mb) st1<TO>(reinterpret_cast<TO*>(a.y) + packed_off(m, d, a.out_packed_mb), t);
+                else st1<TO>(y + d, t);
+            }
+        }
+    } else {
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float t = (x[d] - mean) * rstd * a.gamma[d] + a.beta[d];
+            if (a.add) t += a.add[d];
+            if (a.out_packed_mb) st1<TO>(reinterpret_cast<TO*>(a.y) + packed_off(m, d, a.out_packed_mb), t);
+            else st1<TO>(y + d, t);
+        }
     }
 }
 hipError_t launch_layernorm(const LNArgs& a, hipStream_t st) {
@@ -177,7 +216,8 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
     for (int d = lane; d < hs; d += 64) {
         float acc = 0.0f;
         for (int j = 0; j < nkeys; ++j) acc = fmaf(ps[j], ld1<T>(vc + (long long)j * D + d), acc);
-        st1<T>(o + d, acc);
+        if (a.out_packed_mb) st1<T>(reinterpret_cast<T*>(a.out) + packed_off(b * a.Tq + qi, h * hs + d, a.out_packed_mb), acc);
+        else st1<T>(o + d, acc);
     }
 }
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
@@ -471,6 +511,117 @@ hipError_t launch_gn_stats(const void* x, int dtype, float* stats, int B, int HW
                            hipStream_t st) {
     if (dtype == DT_BF16) gn_stats_kernel<bf16_t><<<B * groups, 256, 0, st>>>((const bf16_t*)x, stats, HW, C, groups, eps);
     else gn_stats_kernel<float><<<B * groups, 256, 0, st>>>((const float*)x, stats, HW, C, groups, eps);
+    return hipGetLastError();
+}
+
+// FAST variants: one pass over contiguous pixel chunks (every load a full 16-B vector), per-channel fp32
+// partials in registers, per-group double partials to memory, tiny finalize.
+#define GN_CHUNK_PIX 64
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double* partial, int HW, int C, int groups, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* ssum = reinterpret_cast<float*>(smem_raw);      // [C] sum, [C] sumsq
+    float* ssq = ssum + C;
+    const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+    const int p0 = ch * GN_CHUNK_PIX, p1 = min(HW, p0 + GN_CHUNK_PIX);
+    for (int c = threadIdx.x; c < 2 * C; c += 256) ssum[c] = 0.0f;
+    __syncthreads();
+    const int vec_per_pix = C / 8;
+    const int total = (p1 - p0) * vec_per_pix;
+    // thread t always handles the same 8 channels when 256 % vec_per_pix == 0 (C in {64..2048}); else falls back to atomics only
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.0f; q[i] = 0.0f; }
+    const bf16_t* base = x + ((long long)b * HW + p0) * C;
+    const bool fixed = (256 % vec_per_pix) == 0;
+    int myc = -1;
+    for (int v = threadIdx.x; v < total; v += 256) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(base + (long long)v * 8);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+        const int c8 = (v % vec_per_pix) * 8;
+        if (!fixed && myc >= 0 && myc != c8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { atomicAdd(&ssum[myc + i], s[i]); atomicAdd(&ssq[myc + i], q[i]); s[i] = 0.0f; q[i] = 0.0f; }
+        }
+        myc = c8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lo = bf16_to_f32((bf16_t)(w[i] & 0xffffu)), hi = bf16_to_f32((bf16_t)(w[i] >> 16));
+            s[2 * i] += lo; q[2 * i] += lo * lo; s[2 * i + 1] += hi; q[2 * i + 1] += hi * hi;
+        }
+    }
+    if (myc >= 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { atomicAdd(&ssum[myc + i], s[i]); atomicAdd(&ssq[myc + i], q[i]); }
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double a = 0.0, c2 = 0.0;
+        for (int i = 0; i < cpg; ++i) { a += (double)ssum[g * cpg + i]; c2 += (double)ssq[g * cpg + i]; }
+        partial[((long long)blockIdx.x * groups + g) * 2] = a;
+        partial[((long long)blockIdx.x * groups + g) * 2 + 1] = c2;
+    }
+}
+__global__ void gn_finalize_kernel(const double* partial, float* stats, int nchunk, int groups, double count, float eps) {
+    const int bg = blockIdx.x * blockDim.x + threadIdx.x;     // b * groups + g
+    const int b = bg / groups, g = bg % groups;
+    double a = 0.0, q = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        a += partial[(((long long)b * nchunk + ch) * groups + g) * 2];
+        q += partial[(((long long)b * nchunk + ch) * groups + g) * 2 + 1];
+    }
+    const double mean = a / count;
+    const double var = fmax(q / count - mean * mean, 0.0);
+    stats[(long long)bg * 2] = (float)mean;
+    stats[(long long)bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups) {
+    (void)C;
+    return (size_t)B * ((HW + GN_CHUNK_PIX - 1) / GN_CHUNK_PIX) * groups * 2;
+}
+hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, int B, int HW, int C, int groups, float eps,
+                                hipStream_t st) {
+    const int nchunk = (HW + GN_CHUNK_PIX - 1) / GN_CHUNK_PIX;
+    gn_partial_kernel<<<B * nchunk, 256, 2 * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int n = B * groups;
+    gn_finalize_kernel<<<(n + 63) / 64, 64, 0, st>>>(partial, stats, nchunk, groups, (double)HW * (C / groups), eps);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* y, const float* stats, const float* gamma,
+                                                       const float* beta, long long total_vec, int HW, int C, int groups, int swish) {
+    const int cpg = C / groups, vec_per_pix = C / 8;
+    for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < total_vec; v += (long long)gridDim.x * blockDim.x) {
+        const long long pix = v / vec_per_pix;
+        const int c8 = (int)(v - pix * vec_per_pix) * 8;
+        const int b = (int)(pix / HW);
+        const uint4 raw = *reinterpret_cast<const uint4*>(x + v * 8);
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); f[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* st = stats + ((long long)b * groups + (c8 + i) / cpg) * 2;
+            float t = (f[i] - st[0]) * st[1] * gamma[c8 + i] + beta[c8 + i];
+            if (swish) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+            f[i] = t;
+        }
+        uint4 o;
+        o.x = (unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16);
+        o.y = (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16);
+        o.z = (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16);
+        o.w = (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16);
+        *reinterpret_cast<uint4*>(y + v * 8) = o;
+    }
+}
+hipError_t launch_gn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, int B, int HW,
+                           int C, int groups, int swish, hipStream_t st) {
+    const long long total_vec = (long long)B * HW * C / 8;
+    const int grid = (int)std::min<long long>((total_vec + 255) / 256, 256 * 16);
+    gn_apply_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, stats, gamma, beta, total_vec, HW, C, groups, swish);
     return hipGetLastError();
 }
 

@@ -216,6 +216,29 @@ def test_decode_fast_tolerance():
         assert d.max() <= 0.1 and d.mean() <= 1e-2, (name, d.max(), d.mean())
 
 
+def test_decode_fast_big_tile_kernels_vs_oracle():
+    """FAST decode on a config wide enough (Cin % 64 == 0, Cout >= 128) for the LDS-DMA 128x128x64 MFMA conv
+    kernel; HQT_FORCE_TILE128 makes the dispatcher pick it even though the grid is small.  Same tolerance as
+    test_decode_fast_tolerance, against the CPU oracle."""
+    import os
+    spec = Stage1Spec(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=64, z_channels=64,
+                      embed_dim=32, n_embed=256)
+    weights = synth.stage1_weights(spec, 31, 'fixture')
+    r = np.random.default_rng(32)
+    ct, cb = r.integers(0, 256, (3, 8, 8)), r.integers(0, 256, (3, 16, 16))
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    os.environ['HQT_FORCE_TILE128'] = '1'
+    try:
+        eng = engine_s1(spec, weights, 3)
+        got = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
+        exact = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_EXACT))
+    finally:
+        del os.environ['HQT_FORCE_TILE128']
+    assert np.abs(exact - want).max() <= PIXEL_TOL
+    d = np.abs(got - want)
+    assert d.max() <= 0.1 and d.mean() <= 1e-2, (d.max(), d.mean())
+
+
 def test_decode_batch_chunking_and_ragged():
     """More images than one decode chunk, decoded in one call, equal the per-image decodes."""
     fx = load('g5_decode_64.npz')
