@@ -93,6 +93,18 @@ __device__ __forceinline__ u32x4 gn_apply(const GemmArgs& g, u32x4 v, int img, i
 }
 }  // namespace
 
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8 share one).  Remap the linear id so
+// that every XCD owns a contiguous run of tiles in n-fastest order: the ~64 workgroups resident on one XCD
+// then cover a few m-tiles x all n-tiles and march through K together, so each A and B k-slice is fetched
+// into that XCD's L2 once and reused by all of them (speed only; any placement is correct).
+__device__ __forceinline__ void xcd_tile(int& tile_m, int& tile_n) {
+    const int nx = gridDim.x, total = gridDim.x * gridDim.y;
+    int id = blockIdx.x + nx * blockIdx.y;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    tile_m = id / nx;
+    tile_n = id - tile_m * nx;
+}
+
 template <int BM, int BN, typename TC>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
@@ -103,7 +115,9 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bz = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A) + (long long)bz * g.a_batch_stride;
     const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(g.Bw) + (long long)bz * g.b_batch_stride;
 
@@ -234,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bz = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A) + (long long)bz * g.a_batch_stride;
     const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(g.Bw) + (long long)bz * g.b_batch_stride;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g.zero_page);
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
-    const bool plain = g.store == STORE_ROWS && g.rows_per_group == 0;
+    // epilogue (plain row-major store only; glds_ok() routes every other store mode to the register kernel)
     TC* Cb = reinterpret_cast<TC*>(g.C) + (long long)bz * g.c_batch_stride;
     const TC* Rb = g.resid ? reinterpret_cast<const TC*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
 #pragma unroll
@@ -334,20 +350,17 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m >= g.M) continue;
-                if (plain) {
-                    const long long idx = (long long)m * g.ldc + n;
-                    float v = apply_act(acc[i][j][r] * g.alpha + bn, g.act);
-                    if (Rb) v += ld1<TC>(Rb + idx);
-                    st1<TC>(Cb + idx, v);
-                } else {
-                    gemm_store<TC>(g, bz, m, n, acc[i][j][r]);
-                }
+                const long long idx = (long long)m * g.ldc + n;
+                float v = apply_act(acc[i][j][r] * g.alpha + bn, g.act);
+                if (Rb) v += ld1<TC>(Rb + idx);
+                st1<TC>(Cb + idx, v);
             }
         }
 }
 
 static bool glds_ok(const GemmArgs& g) {
     if (!g.zero_page || g.gn_stats || g.a_packed_mb) return false;
+    if (g.store != STORE_ROWS || g.rows_per_group != 0) return false;
     if (g.K % 64 != 0 || g.ldb % 8 != 0) return false;
     if (g.conv_taps) return g.Cin % 64 == 0;
     return g.lda % 8 == 0;
