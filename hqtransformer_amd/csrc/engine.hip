@@ -207,7 +207,7 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
     if (c.has_stage2) {
         if (c.embed_dim % c.n_heads || c.embed_dim % 16) return fail(HQT_ERR_INVALID, "embed_dim must be a multiple of n_heads and 16");
         const int hs = c.embed_dim / c.n_heads;
-        if (hs % 4 || hs > 256) return fail(HQT_ERR_INVALID, "head_dim %d unsupported", hs);
+        if (hs % 8 || hs > 256 || (hs & (hs - 1))) return fail(HQT_ERR_INVALID, "head_dim %d unsupported (power of two in [8, 256])", hs);
         if (c.vocab_top != c.vocab_bot) return fail(HQT_ERR_INVALID, "vocab_top != vocab_bot");
         if (c.vocab_top > HQT_MAX_V || c.vocab_top % 4) return fail(HQT_ERR_INVALID, "vocab size %d unsupported", c.vocab_top);
         if (c.cond_type == HQT_COND_CLASS && c.n_classes < 1) return fail(HQT_ERR_INVALID, "n_classes");

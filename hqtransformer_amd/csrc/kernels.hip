@@ -2,6 +2,7 @@
 // fused sampler, codebook gather, GroupNorm statistics.  gfx950 only (wave = 64).
 #include "kernels.h"
 #include "gemm_generic.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // reductions (256-thread workgroups = 4 waves), deterministic for a fixed launch shape
@@ -105,67 +106,84 @@ hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepS
 // ---------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-5), two-pass, one workgroup per row
 // ---------------------------------------------------------------------------------------------
+// One wave per row (4 rows per workgroup): the row lives in registers as float4 vectors (coalesced 1-KiB
+// wave loads), mean and variance are two shuffle reductions, no LDS and no barrier.
 template <typename TO>
 __global__ __launch_bounds__(256) void layernorm_kernel(LNArgs a) {
-    __shared__ float red[4];
-    const int m = blockIdx.x, D = a.D;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int D = a.D;
     float* x = a.x + ((long long)m * a.in_rows_per_group + a.in_row_offset) * D;
-    // each thread keeps its (up to 8) elements in registers: one global read of the row
-    float v[8];
+    constexpr int MAXV = 8;                       // D <= 2048 in registers; wider rows fall back to re-reading
+    float4 v[MAXV], gmv[MAXV], btv[MAXV];      // affine parameters are fetched with the row, ahead of the reductions
     float s = 0.0f;
+    const int nvec = D >> 2;                      // D % 4 == 0
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int d = threadIdx.x + i * 256;
-        v[i] = 0.0f;
-        if (d < D) {
-            float t = x[d];
-            if (a.n_slabs > 0) {              // fold in the split-K partial sums (+bias) of the previous GEMM
-                if (a.slab_bias) t += a.slab_bias[d];
-                for (int sl = 0; sl < a.n_slabs; ++sl) t += a.slabs[((long long)sl * a.slab_rows + m) * D + d];
-                x[d] = t;
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = lane + i * 64;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gmv[i] = v[i]; btv[i] = v[i];
+        if (vi < nvec) {
+            gmv[i] = *reinterpret_cast<const float4*>(a.gamma + vi * 4);
+            btv[i] = *reinterpret_cast<const float4*>(a.beta + vi * 4);
+            if (a.add) { const float4 ad = *reinterpret_cast<const float4*>(a.add + vi * 4); btv[i].x += ad.x; btv[i].y += ad.y; btv[i].z += ad.z; btv[i].w += ad.w; }
+            float4 t = *reinterpret_cast<const float4*>(x + vi * 4);
+            if (a.n_slabs > 0) {                  // fold in the split-K partial sums (+bias) of the previous GEMM
+                if (a.slab_bias) { const float4 bb = *reinterpret_cast<const float4*>(a.slab_bias + vi * 4); t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
+                for (int sl = 0; sl < a.n_slabs; ++sl) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.slabs + ((long long)sl * a.slab_rows + m) * D + vi * 4);
+                    t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+                }
+                *reinterpret_cast<float4*>(x + vi * 4) = t;
             }
             v[i] = t;
-            s += t;
+            s += (t.x + t.y) + (t.z + t.w);
         }
     }
-    float mean, rstd;
-    if (D <= 2048) {
-        mean = block_reduce(s, OpAdd(), red) / (float)D;
-        float q = 0.0f;
+    for (int vi = lane + MAXV * 64; vi < nvec; vi += 64) { const float4 t = *reinterpret_cast<const float4*>(x + vi * 4); s += (t.x + t.y) + (t.z + t.w); }
+    const float mean = wave_reduce(s, OpAdd()) / (float)D;
+    float q = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const int d = threadIdx.x + i * 256; if (d < D) { const float t = v[i] - mean; q += t * t; } }
-        rstd = 1.0f / sqrtf(block_reduce(q, OpAdd(), red) / (float)D + a.eps);
-    } else {                                   // wide rows: re-read
-        for (int d = threadIdx.x + 2048; d < D; d += 256) s += x[d];
-        mean = block_reduce(s, OpAdd(), red) / (float)D;
-        float q = 0.0f;
-        for (int d = threadIdx.x; d < D; d += 256) { const float t = x[d] - mean; q += t * t; }
-        rstd = 1.0f / sqrtf(block_reduce(q, OpAdd(), red) / (float)D + a.eps);
+    for (int i = 0; i < MAXV; ++i) {
+        if (lane + i * 64 < nvec) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
     }
-    TO* y = reinterpret_cast<TO*>(a.y) + (long long)m * D;
-    if (D <= 2048) {
+    for (int vi = lane + MAXV * 64; vi < nvec; vi += 64) {
+        const float4 t = *reinterpret_cast<const float4*>(x + vi * 4);
+        const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float rstd = 1.0f / sqrtf(wave_reduce(q, OpAdd()) / (float)D + a.eps);
+    auto emit = [&](int vi, float4 t, float4 gm, float4 bt) {
+        const int d = vi * 4;
+        float o[4] = {(t.x - mean) * rstd * gm.x + bt.x, (t.y - mean) * rstd * gm.y + bt.y, (t.z - mean) * rstd * gm.z + bt.z,
+                      (t.w - mean) * rstd * gm.w + bt.w};
+        TO* dst = a.out_packed_mb ? reinterpret_cast<TO*>(a.y) + packed_off(m, d, a.out_packed_mb)      // 4 consecutive k stay contiguous
+                                  : reinterpret_cast<TO*>(a.y) + (long long)m * D + d;
+        if (sizeof(TO) == 2) {
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+            *reinterpret_cast<uint2*>(dst) = pk;
+        } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int d = threadIdx.x + i * 256;
-            if (d < D) {
-                float t = (v[i] - mean) * rstd * a.gamma[d] + a.beta[d];
-                if (a.add) t += a.add[d];
-                if (a.out_packed_mb) st1<TO>(reinterpret_cast<TO*>(a.y) + packed_off(m, d, a.out_packed_mb), t);
-                else st1<TO>(y + d, t);
-            }
-        }
-    } else {
-        for (int d = threadIdx.x; d < D; d += 256) {
-            float t = (x[d] - mean) * rstd * a.gamma[d] + a.beta[d];
-            if (a.add) t += a.add[d];
-            if (a.out_packed_mb) st1<TO>(reinterpret_cast<TO*>(a.y) + packed_off(m, d, a.out_packed_mb), t);
-            else st1<TO>(y + d, t);
-        }
+    for (int i = 0; i < MAXV; ++i) if (lane + i * 64 < nvec) emit(lane + i * 64, v[i], gmv[i], btv[i]);
+    for (int vi = lane + MAXV * 64; vi < nvec; vi += 64) {
+        float4 bt = *reinterpret_cast<const float4*>(a.beta + vi * 4);
+        if (a.add) { const float4 ad = *reinterpret_cast<const float4*>(a.add + vi * 4); bt.x += ad.x; bt.y += ad.y; bt.z += ad.z; bt.w += ad.w; }
+        emit(vi, *reinterpret_cast<const float4*>(x + vi * 4), *reinterpret_cast<const float4*>(a.gamma + vi * 4), bt);
     }
 }
 hipError_t launch_layernorm(const LNArgs& a, hipStream_t st) {
-    if (a.out_dtype == DT_BF16) layernorm_kernel<bf16_t><<<a.M, 256, 0, st>>>(a);
-    else layernorm_kernel<float><<<a.M, 256, 0, st>>>(a);
+    if (a.D % 4 != 0) return hipErrorInvalidValue;
+    if (a.out_dtype == DT_BF16) layernorm_kernel<bf16_t><<<(a.M + 3) / 4, 256, 0, st>>>(a);
+    else layernorm_kernel<float><<<(a.M + 3) / 4, 256, 0, st>>>(a);
     return hipGetLastError();
 }
 
@@ -173,58 +191,138 @@ hipError_t launch_layernorm(const LNArgs& a, hipStream_t st) {
 // A4/K3: KV-cache attention, one wave per (sample, head, query) -- stage2/layers.py:93-102,183-187.
 // The scale 1/sqrt(hs) is applied to K before the product, as the reference does (:102).
 // ---------------------------------------------------------------------------------------------
+// One wave per (sample, head, query), four waves per workgroup.  A key/value row of one head (hs elements)
+// is read by hs/8 adjacent lanes, 8 elements (one 16-B vector in bf16) each, so every wave load covers
+// 64 / (hs/8) whole rows: QK^T is 8 FMAs per lane plus a log2(hs/8)-step shuffle reduction, PV keeps 8
+// accumulators per lane and reduces over the row slots at the end.
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); v[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* qs = reinterpret_cast<float*>(smem_raw);            // [hs]
-    float* ps = qs + a.head_dim;                               // [Tmax]
-    const int lane = threadIdx.x;
-    const int gid = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* ps = reinterpret_cast<float*>(smem_raw) + wave * a.Tmax;      // [Tmax] scores / probabilities of this wave
+    const int gid = blockIdx.x * 4 + wave;
+    if (gid >= a.B * a.n_heads * a.Tq) return;
     const int qi = gid % a.Tq;
     const int h = (gid / a.Tq) % a.n_heads;
     const int b = gid / (a.Tq * a.n_heads);
     const int hs = a.head_dim, D = a.n_heads * hs;
+    const int chunks = hs >> 3;                  // lanes per row (power of two: hs in {8,16,32,64,128,256})
+    const int rows_per_pass = 64 / chunks;
+    const int c = lane % chunks, slot = lane / chunks;
     const int tb = a.t_base + (a.t_base_dev ? *a.t_base_dev : 0);
     const int nkeys = a.causal ? tb + qi + 1 : tb + a.Tq;
-    const T* q = reinterpret_cast<const T*>(a.q) + ((long long)(b * a.Tq + qi)) * D + h * hs;
-    const T* kc = reinterpret_cast<const T*>(a.kcache) + (long long)b * a.Tmax * D + h * hs;
-    const T* vc = reinterpret_cast<const T*>(a.vcache) + (long long)b * a.Tmax * D + h * hs;
-    for (int d = lane; d < hs; d += 64) qs[d] = ld1<T>(q + d);
-    __syncthreads();
+    const T* q = reinterpret_cast<const T*>(a.q) + ((long long)(b * a.Tq + qi)) * D + h * hs + c * 8;
+    const T* kc = reinterpret_cast<const T*>(a.kcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
+    const T* vc = reinterpret_cast<const T*>(a.vcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
+    float qv[8];
+    ld8<T>(q, qv);
     const float scale = 1.0f / sqrtf((float)hs);
-    float lmax = -INFINITY;
-    for (int j = lane; j < nkeys; j += 64) {
-        const T* kr = kc + (long long)j * D;
-        float s = 0.0f;
-        for (int d = 0; d < hs; d += 4) {
-            float kv[4];
-            ld4<T>(kr + d, kv);
+    typedef typename std::conditional<sizeof(T) == 2, uint4, float4>::type raw_t;     // 16-B vector of the cache dtype
+    constexpr int NRAW = sizeof(T) == 2 ? 1 : 2, PB = 8;                               // passes whose loads are issued together
+    auto unpack = [](const raw_t* r, float (&f)[8]) {
+        if (sizeof(T) == 2) {
+            const uint4 t = *reinterpret_cast<const uint4*>(r);
+            const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s = fmaf(qs[d + i], kv[i] * scale, s);
+            for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); f[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
+        } else {
+            const float4 a0 = *reinterpret_cast<const float4*>(r), a1 = *reinterpret_cast<const float4*>(r + 1);
+            f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
         }
-        ps[j] = s;
-        lmax = fmaxf(lmax, s);
+    };
+    float lmax = -INFINITY;
+    for (int j0 = 0; j0 < nkeys; j0 += rows_per_pass * PB) {
+        raw_t buf[PB][NRAW];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {                                  // unconditional (clamped) loads: all in flight at once
+            const int j = min(j0 + p * rows_per_pass + slot, nkeys - 1);
+            const raw_t* src = reinterpret_cast<const raw_t*>(kc + (long long)j * D);
+#pragma unroll
+            for (int e = 0; e < NRAW; ++e) buf[p][e] = src[e];
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int j = j0 + p * rows_per_pass + slot;
+            float kv[8];
+            unpack(buf[p], kv);
+            float sc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sc = fmaf(qv[i], kv[i] * scale, sc);          // scale on K, as layers.py:102
+            for (int off = chunks >> 1; off > 0; off >>= 1) sc += __shfl_xor(sc, off, 64);
+            if (j < nkeys) {
+                if (c == 0) ps[j] = sc;
+                lmax = fmaxf(lmax, sc);
+            }
+        }
     }
     lmax = wave_reduce(lmax, OpMax());
+    __builtin_amdgcn_wave_barrier();
     float lsum = 0.0f;
     for (int j = lane; j < nkeys; j += 64) { const float e = expf(ps[j] - lmax); ps[j] = e; lsum += e; }
     lsum = wave_reduce(lsum, OpAdd());
-    __syncthreads();
     for (int j = lane; j < nkeys; j += 64) ps[j] = ps[j] / lsum;
-    __syncthreads();
-    T* o = reinterpret_cast<T*>(a.out) + ((long long)(b * a.Tq + qi)) * D + h * hs;
-    for (int d = lane; d < hs; d += 64) {
-        float acc = 0.0f;
-        for (int j = 0; j < nkeys; ++j) acc = fmaf(ps[j], ld1<T>(vc + (long long)j * D + d), acc);
-        if (a.out_packed_mb) st1<T>(reinterpret_cast<T*>(a.out) + packed_off(b * a.Tq + qi, h * hs + d, a.out_packed_mb), acc);
-        else st1<T>(o + d, acc);
+    __builtin_amdgcn_wave_barrier();
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+    for (int j0 = 0; j0 < nkeys; j0 += rows_per_pass * PB) {
+        raw_t buf[PB][NRAW];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int j = min(j0 + p * rows_per_pass + slot, nkeys - 1);
+            const raw_t* src = reinterpret_cast<const raw_t*>(vc + (long long)j * D);
+#pragma unroll
+            for (int e = 0; e < NRAW; ++e) buf[p][e] = src[e];
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int j = j0 + p * rows_per_pass + slot;
+            float vv[8];
+            unpack(buf[p], vv);
+            const float pj = j < nkeys ? ps[j] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(pj, vv[i], acc[i]);
+        }
+    }
+    for (int off = chunks; off < 64; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off, 64);
+    if (slot == 0) {
+        const int row = b * a.Tq + qi, col = h * hs + c * 8;
+        T* o = a.out_packed_mb ? reinterpret_cast<T*>(a.out) + packed_off(row, col, a.out_packed_mb)
+                               : reinterpret_cast<T*>(a.out) + (long long)row * D + col;
+        if (sizeof(T) == 2) {
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(acc[4]) | ((unsigned)f32_to_bf16(acc[5]) << 16);
+            pk.w = (unsigned)f32_to_bf16(acc[6]) | ((unsigned)f32_to_bf16(acc[7]) << 16);
+            *reinterpret_cast<uint4*>(o) = pk;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st1<T>(o + i, acc[i]);
+        }
     }
 }
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
-    const size_t smem = (size_t)(a.head_dim + a.Tmax) * sizeof(float);
-    const int grid = a.B * a.n_heads * a.Tq;
-    if (a.dtype == DT_BF16) attention_kernel<bf16_t><<<grid, 64, smem, st>>>(a);
-    else attention_kernel<float><<<grid, 64, smem, st>>>(a);
+    const int chunks = a.head_dim / 8;
+    if (a.head_dim % 8 != 0 || chunks > 64 || (chunks & (chunks - 1)) != 0) return hipErrorInvalidValue;
+    const size_t smem = (size_t)4 * a.Tmax * sizeof(float);
+    const int grid = (a.B * a.n_heads * a.Tq + 3) / 4;
+    if (a.dtype == DT_BF16) attention_kernel<bf16_t><<<grid, 256, smem, st>>>(a);
+    else attention_kernel<float><<<grid, 256, smem, st>>>(a);
     return hipGetLastError();
 }
 

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
 // XOR.  With 128-B rows two rows share a 256-B bank line and 16 rows of one ds_read_b128 group land on 16
 // distinct 16-B slots.  Zero padding of the 3x3 taps comes from a zero page (DMA cannot predicate).
 // ---------------------------------------------------------------------------------------------
-template <typename TC>
+template <typename TC, bool NCHW>
 __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
     constexpr int BM = 128, BN = 128, BKG = 64, ROWB = 128;            // ROWB: bytes per LDS row
     __shared__ __attribute__((aligned(16))) char lds[2][2][BM * ROWB];    // [buf][A|B]
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
-    // epilogue (plain row-major store only; glds_ok() routes every other store mode to the register kernel)
+    // epilogue: plain row-major store (template NCHW = false) or the fp32 NCHW store of conv_out
     TC* Cb = reinterpret_cast<TC*>(g.C) + (long long)bz * g.c_batch_stride;
     const TC* Rb = g.resid ? reinterpret_cast<const TC*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
 #pragma unroll
@@ -350,17 +350,24 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m >= g.M) continue;
-                const long long idx = (long long)m * g.ldc + n;
-                float v = apply_act(acc[i][j][r] * g.alpha + bn, g.act);
-                if (Rb) v += ld1<TC>(Rb + idx);
-                st1<TC>(Cb + idx, v);
+                if (NCHW) {                       // conv_out: fp32 NCHW (+clamp), n < out_ch only
+                    float v = acc[i][j][r] * g.alpha + bn;
+                    if (g.clamp01) v = fminf(fmaxf(0.5f * v + 0.5f, 0.0f), 1.0f);
+                    const int img = m / g.rows_per_image, pix = m - img * g.rows_per_image;
+                    st1<TC>(Cb + ((long long)img * g.N + n) * g.rows_per_image + pix, v);
+                } else {
+                    const long long idx = (long long)m * g.ldc + n;
+                    float v = apply_act(acc[i][j][r] * g.alpha + bn, g.act);
+                    if (Rb) v += ld1<TC>(Rb + idx);
+                    st1<TC>(Cb + idx, v);
+                }
             }
         }
 }
 
 static bool glds_ok(const GemmArgs& g) {
     if (!g.zero_page || g.gn_stats || g.a_packed_mb) return false;
-    if (g.store != STORE_ROWS || g.rows_per_group != 0) return false;
+    if (!((g.store == STORE_ROWS && g.rows_per_group == 0) || (g.store == STORE_NCHW && !g.resid && g.act == ACT_NONE))) return false;
     if (g.K % 64 != 0 || g.ldb % 8 != 0) return false;
     if (g.conv_taps) return g.Cin % 64 == 0;
     return g.lda % 8 == 0;
@@ -369,7 +376,7 @@ static bool glds_ok(const GemmArgs& g) {
 bool mfma_gemm_ok(const GemmArgs& g, int a_dt, int b_dt, int c_dt) {
     (void)c_dt;
     if (a_dt != DT_BF16 || b_dt != DT_BF16 || g.a_packed_mb) return false;
-    if (g.K % BK != 0 || g.N < 32) return false;
+    if (g.K % BK != 0) return false;
     if (g.conv_taps && g.Cin % BK != 0) return false;
     if (!g.conv_taps && (g.lda % 8 != 0)) return false;
     if (g.ldb % 8 != 0) return false;
@@ -388,11 +395,17 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
     (void)a_dt; (void)b_dt;
     const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.batch > 0 ? g.batch : 1);
     static const bool force128 = getenv("HQT_FORCE_TILE128") != nullptr;          // test hook: exercise the big-tile kernels on tiny shapes
-    if (g.N >= 128 && g.M >= 128 && (tiles128 >= 192 || force128)) {
+    const bool narrow = g.N < 32 && g.M >= 4096 && glds_ok(g);       // conv_out (N = 3): one zero-padded 128-wide n-tile
+    if (narrow || (g.N >= 128 && g.M >= 128 && (tiles128 >= 192 || force128))) {
         if (glds_ok(g)) {
             const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
-            if (c_dt == DT_BF16) conv_glds_kernel<bf16_t><<<grid, 256, 0, st>>>(g);
-            else conv_glds_kernel<float><<<grid, 256, 0, st>>>(g);
+            if (g.store == STORE_NCHW) {
+                if (c_dt == DT_BF16) conv_glds_kernel<bf16_t, true><<<grid, 256, 0, st>>>(g);
+                else conv_glds_kernel<float, true><<<grid, 256, 0, st>>>(g);
+            } else {
+                if (c_dt == DT_BF16) conv_glds_kernel<bf16_t, false><<<grid, 256, 0, st>>>(g);
+                else conv_glds_kernel<float, false><<<grid, 256, 0, st>>>(g);
+            }
             return hipGetLastError();
         }
         return launch_t<128, 128>(g, c_dt, st);

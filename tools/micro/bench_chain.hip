@@ -1,0 +1,62 @@
+// Micro-benchmark: what a small kernel (LayerNorm, attention) costs alone, back to back, and in between
+// weight-streaming GEMMs (cold caches), inside a hipGraph -- to separate kernel time from boundary effects.
+#include "../../hqtransformer_amd/csrc/fast_kernels.hip"
+#include "../../hqtransformer_amd/csrc/kernels.hip"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <typename F>
+static float graph_time(hipStream_t st, int reps, F body) {
+    hipGraph_t graph; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    body();
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, st));
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(graph));
+    return 1000.f * ms / reps;
+}
+
+int main() {
+    hipStream_t st; CK(hipStreamCreate(&st));
+    CK(stream_gemm_configure());
+    const int D = 1536, M = 64, nh = 24, T = 64;
+    float *x, *gam, *bet; bf16_t *h, *q, *kc, *vc, *o; float* y;
+    CK(hipMalloc(&x, 256 * D * 4)); CK(hipMemset(x, 0, 256 * D * 4));
+    CK(hipMalloc(&gam, D * 4)); CK(hipMemset(gam, 0, D * 4)); CK(hipMalloc(&bet, D * 4)); CK(hipMemset(bet, 0, D * 4));
+    CK(hipMalloc(&h, 256 * 6144 * 2)); CK(hipMalloc(&q, 256 * D * 2)); CK(hipMalloc(&o, 256 * D * 2));
+    CK(hipMemset(q, 0, 256 * D * 2));
+    CK(hipMalloc(&kc, (size_t)64 * 128 * D * 2)); CK(hipMalloc(&vc, (size_t)64 * 128 * D * 2));
+    CK(hipMemset(kc, 0, (size_t)64 * 128 * D * 2)); CK(hipMemset(vc, 0, (size_t)64 * 128 * D * 2));
+    CK(hipMalloc(&y, 256 * 8192 * 4));
+    const int N = 4608, K = 1536, nbuf = 40;
+    std::vector<bf16_t*> w(nbuf);
+    for (auto& p : w) { CK(hipMalloc(&p, (size_t)N * K * 2)); CK(hipMemset(p, 0x3c, (size_t)N * K * 2)); }
+    LNArgs ln{x, gam, bet, nullptr, h, M, D, 1, 0, 1e-5f, DT_BF16, 2, nullptr, 0, 0, nullptr};
+    AttnArgs at{q, kc, vc, o, 64, 1, nh, 64, 128, T - 1, nullptr, 1, DT_BF16, 2};
+    GemmArgs g{};
+    g.A = h; g.a_packed_mb = 2; g.M = M; g.N = N; g.K = K; g.batch = 1; g.C = y; g.ldc = N; g.alpha = 1.f; g.store = STORE_ROWS;
+    CK(sampler_configure(8192, false));
+    const int n = 40;
+    float t;
+    t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_layernorm(ln, st)); });
+    printf("LayerNorm x%d back to back: %.2f us each\n", n, t / n);
+    t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_attention(at, st)); });
+    printf("attention (B=64, 24 heads, %d keys) x%d back to back: %.2f us each\n", T, n, t / n);
+    t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); });
+    const float tg = t / n;
+    printf("stream GEMM qkv (cold weights) x%d: %.2f us each\n", n, tg);
+    t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_layernorm(ln, st)); CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); } });
+    printf("LayerNorm + GEMM alternating: %.2f us per pair -> LayerNorm costs %.2f us in the chain\n", t / n, t / n - tg);
+    t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_attention(at, st)); CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); } });
+    printf("attention + GEMM alternating: %.2f us per pair -> attention costs %.2f us in the chain\n", t / n, t / n - tg);
+    t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_layernorm(ln, st)); CK(launch_attention(at, st)); CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); } });
+    printf("LN + attention + GEMM: %.2f us per triple\n", t / n);
+    return 0;
+}
