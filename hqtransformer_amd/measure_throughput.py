@@ -1,0 +1,110 @@
+"""Counterpart of the reference's throughput harness (``measure_throughput/__main__.py:51-180``).
+
+    python -m hqtransformer_amd.measure_throughput model_path=configs/imagenet-12l.yaml batch_size=64
+
+Same dot-list keys and defaults (``Experiment`` dataclass, :34-48), same loop accounting: ``n_loop`` loops of
+``ceil(1000 / batch_size)`` iterations, the first ``warmup`` loops discarded, every iteration = one
+``sampling_ihqgpt`` call (random class, ``top_k = top_p = None``, temperatures 1.0, ``use_fp16=True``) timed as
+"ar", then code rearrange + ``stage1.decode_code`` + ``clamp(0.5 x + 0.5, 0, 1)`` timed as "decode", GPU events for
+both, and the same printed lines (``ms/sample (ar: .., decode: ..)``).  Random-init weights, like the reference.
+Differences, stated: the whole batch is decoded in one call instead of ``batch_size`` calls of one image
+(``decode_batch=1`` restores the reference's chunking), and ``decode_precision=exact`` selects the reference's
+fp32 decode arithmetic (default ``fast`` = bf16 MFMA).
+"""
+from __future__ import annotations
+
+import platform
+import random
+import sys
+import time
+
+import torch
+
+from .config import load_config, parse_dotlist
+from .models import ImageGPT2
+from .sampling import rearrange_codes, sampling_ihqgpt
+
+EXPERIMENT_DEFAULTS = dict(f=32, model='huge', d=4, c=16384, batch_size=50, n_loop=6, warmup=1, model_path='',
+                           top_resolution=8, code_levels=2, decode_batch=0, decode_precision='fast', seed=0)
+
+
+def iterations_per_loop(batch_size: int) -> int:
+    """``n_iter_per_loop = (1000 + batch_size - 1) // batch_size`` (measure_throughput/__main__.py:76)."""
+    return (1000 + batch_size - 1) // batch_size
+
+
+def load_model(result_path: str) -> ImageGPT2:
+    return ImageGPT2(load_config(result_path))
+
+
+def main(args) -> dict:
+    torch.set_grad_enabled(False)
+    if args.code_levels != 2:
+        raise NotImplementedError('code_levels=3 (HQTransformer 3-level path) is not built yet (SURVEY.md §8f rank 1)')
+    random.seed(args.seed)
+    model_ar = load_model(args.model_path)
+    device = torch.device('cuda')
+    model_ar = model_ar.to(device)
+    model_ar.eval()
+    title = f'bs{args.batch_size}, sampling loops {args.warmup + 1}-{args.n_loop}'
+    print(title)
+    print('python: %s, torch: %s, hip: %s, gpu: %s' % (platform.python_version(), torch.__version__, torch.version.hip,
+                                                      torch.cuda.get_device_name(device)))
+    ar_size = sum(p.numel() for p in model_ar.stage2.parameters()) / (10 ** 6)
+    print(f'transformer size: {ar_size:.1f}M')
+    batch_size = args.batch_size
+    n_iter_per_loop = iterations_per_loop(batch_size)
+    n_loop = args.n_loop
+
+    def loop(loop_idx: int):
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
+        middles = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
+        torch.cuda.synchronize(device)
+        tic = time.time()
+        for i in range(n_iter_per_loop):
+            starts[i].record()
+            codes_t, codes_b = sampling_ihqgpt(model_ar.stage2, cond=random.randint(0, 999), num_candidates=batch_size,
+                                               top_k_top=None, top_p_top=None, top_k_bot=None, top_p_bot=None,
+                                               softmax_temperature=[1.0 for _ in range(args.code_levels)], use_fp16=True,
+                                               is_tqdm=False, max_seq_len=args.top_resolution * args.top_resolution,
+                                               model_stage1=None)
+            middles[i].record()
+            if args.decode_batch and args.decode_batch < batch_size:
+                grid_t, grid_b = rearrange_codes(codes_t, codes_b, args.top_resolution)
+                pixels = torch.cat([model_ar.stage1.decode_code(ct, cb, precision=args.decode_precision)
+                                    for ct, cb in zip(grid_t.split(args.decode_batch), grid_b.split(args.decode_batch))], dim=0)
+                _ = (0.5 * pixels + 0.5).clamp(0, 1)
+            else:      # rearranges and the clamp are folded into the decode kernels
+                _ = model_ar.stage1.decode_sequences(codes_t, codes_b, precision=args.decode_precision, clamp01=True)
+            ends[i].record()
+        torch.cuda.synchronize(device)
+        toc = time.time()
+        elapsed_time = toc - tic
+        elapsed_time_ar = sum(starts[i].elapsed_time(middles[i]) for i in range(n_iter_per_loop)) / 1000
+        elapsed_time_decode = sum(middles[i].elapsed_time(ends[i]) for i in range(n_iter_per_loop)) / 1000
+        print(f'{loop_idx + 1}/{n_loop} | {elapsed_time:.1f} s/loop (ar: {elapsed_time_ar:.1f}, decode: {elapsed_time_decode:.1f})')
+        n = n_iter_per_loop * batch_size
+        speed, speed_ar, speed_decode = (elapsed_time / n * 1000, elapsed_time_ar / n * 1000, elapsed_time_decode / n * 1000)
+        print(f'{loop_idx + 1}/{n_loop} | {speed:.1f} ms/sample (ar: {speed_ar:.1f}, decode: {speed_decode:.1f})')
+        return speed, speed_ar, speed_decode
+
+    speeds, speeds_ar, speeds_decode = [], [], []
+    print('-' * 80)
+    for loop_idx in range(args.n_loop):
+        speed, speed_ar, speed_decode = loop(loop_idx)
+        if loop_idx < args.warmup:
+            continue
+        speeds.append(speed)
+        speeds_ar.append(speed_ar)
+        speeds_decode.append(speed_decode)
+    print('-' * 80)
+    n = len(speeds)
+    speed, speed_ar, speed_decode = sum(speeds) / n, sum(speeds_ar) / n, sum(speeds_decode) / n
+    print(f'{title} | {speed:.4f} ms/sample (ar: {speed_ar:.4f}, decode: {speed_decode:.4f})')
+    print('=' * 80)
+    return dict(ms_per_sample=speed, ms_ar=speed_ar, ms_decode=speed_decode, images_per_s=1000.0 / speed)
+
+
+if __name__ == '__main__':
+    main(parse_dotlist(sys.argv[1:], EXPERIMENT_DEFAULTS))

@@ -1,0 +1,80 @@
+"""The reference-shaped Python surface on the GPU: ImageGPT2 / sampling_ihqgpt / decode_code and the two harness
+counterparts, checked against the CPU oracle built from the same state dict."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from hqtransformer_amd import synth
+from hqtransformer_amd.config import load_config, parse_dotlist
+from hqtransformer_amd.models import ImageGPT2
+from hqtransformer_amd.sampling import rearrange_codes, sampling_ihqgpt
+from hqtransformer_amd.utils import set_seed
+from oracle import hqt_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = os.path.join(ROOT, 'configs', 'tiny-cls.yaml')
+
+
+@pytest.fixture(scope='module')
+def model():
+    return ImageGPT2(load_config(TINY), seed=5).to('cuda').eval()
+
+
+def test_sampling_ihqgpt_and_decode_code_match_the_oracle(model):
+    s2, s1 = model.stage2.spec, model.stage1.spec
+    w2 = {k: v.numpy() for k, v in model.stage2.state_dict().items()}
+    w1 = {k: v.numpy() for k, v in model.stage1.state_dict().items()}
+    B, n = 3, 64
+    noise = synth.exp_noise(11, n, B, s2.vocab_top)
+    ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=417, top_k_top=100, top_p_top=0.9, top_k_bot=50,
+                             top_p_bot=None, softmax_temperature=[1.0, 0.9], use_fp16=False, is_tqdm=False, max_seq_len=n,
+                             noise=torch.from_numpy(noise))
+    assert ct.dtype == torch.int64 and tuple(ct.shape) == (B, n) and tuple(cb.shape) == (B, n, 4) and ct.is_cuda
+    want = O.OracleStage2(s2, w2).sample(np.full(B, 417), B, n, noise, (100, 50), (0.9, None), (1.0, 0.9))
+    assert (ct.cpu().numpy() == want[0]).all() and (cb.cpu().numpy() == want[1]).all()
+    gt, gb = rearrange_codes(ct, cb, 8)
+    px = model.stage1.decode_code(gt, gb)                      # default precision = the reference's fp32 decode
+    ref = O.OracleStage1(s1, w1).decode_code(*O.rearrange_codes(want[0], want[1], 8))
+    assert tuple(px.shape) == (B, 3, 64, 64) and np.abs(px.cpu().numpy() - ref).max() <= 1e-4
+    px_seq = model.stage1.decode_sequences(ct, cb, clamp01=True)
+    assert np.abs(px_seq.cpu().numpy() - O.postprocess(ref)).max() <= 1e-4
+    half = model.stage1.decode_code(gt[:1], None)
+    assert np.abs(half.cpu().numpy() - O.OracleStage1(s1, w1).decode_code(gt[:1].cpu().numpy(), None)).max() <= 1e-4
+
+
+def test_set_seed_controls_the_in_kernel_noise(model):
+    def run():
+        return sampling_ihqgpt(model.stage2, 4, 3, use_fp16=True, is_tqdm=False, max_seq_len=16)
+    set_seed(0)
+    a = run()
+    set_seed(0)
+    b = run()
+    set_seed(1)
+    c = run()
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[0] != c[0]).any()
+    with pytest.raises(IndexError):
+        sampling_ihqgpt(model.stage2, 2, 1000, max_seq_len=4)          # class id out of range, as nn.Embedding raises
+
+
+def test_measure_throughput_counterpart(capsys):
+    from hqtransformer_amd import measure_throughput as mt
+    args = parse_dotlist([f'model_path={TINY}', 'batch_size=500', 'n_loop=2', 'warmup=1'], mt.EXPERIMENT_DEFAULTS)
+    out = mt.main(args)
+    text = capsys.readouterr().out
+    assert 'bs500, sampling loops 2-2' in text and 'transformer size:' in text and 'ms/sample (ar:' in text
+    assert out['ms_per_sample'] > 0 and abs(out['ms_ar'] + out['ms_decode'] - out['ms_per_sample']) / out['ms_per_sample'] < 0.2
+
+
+def test_sampling_hqmodel_counterpart_writes_reference_formats(tmp_path):
+    from hqtransformer_amd import sampling_hqmodel as sh
+    sh.main(['-r', str(tmp_path), '-m', TINY, '--batch-size', '2', '--num-classes', '2', '--samples-per-class', '2',
+             '--top-k', '100', '--top-resolution', '8'])
+    for cls in (1, 2):
+        px = pickle.load(open(tmp_path / f'samples_({cls}_0).pkl', 'rb'))
+        tg = np.load(tmp_path / f'targets_({cls}_0).npz')['targets']
+        assert px.dtype == np.float32 and px.shape == (2, 3, 64, 64) and px.min() >= 0 and px.max() <= 1
+        assert tg.dtype == np.int64 and (tg == cls - 1).all()

@@ -1,0 +1,117 @@
+"""Host-side logic of the drop-in surface (no GPU): config loading and defaults, spec derivation, state-dict
+contract, harness accounting, code-grid maps, and the refusal to compute off-GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hqtransformer_amd import _lib
+from hqtransformer_amd.config import get_base_config, load_config, merge, parse_dotlist
+from hqtransformer_amd.measure_throughput import EXPERIMENT_DEFAULTS, iterations_per_loop
+from hqtransformer_amd.models import ImageGPT2
+from hqtransformer_amd.sampling import rearrange_codes, sampling_ihqgpt
+from hqtransformer_amd.sampling_hqmodel import build_parser, remap_legacy_keys
+from hqtransformer_amd.spec import (decoder_plan, stage1_param_shapes, stage1_spec_from_config, stage2_param_shapes,
+                                    stage2_spec_from_config, work_per_image)
+from tests.helpers import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = os.path.join(ROOT, 'configs', 'tiny-cls.yaml')
+IMAGENET = os.path.join(ROOT, 'configs', 'imagenet-12l.yaml')
+
+
+def test_defaults_the_yaml_files_omit():
+    cfg = load_config(TINY)
+    assert cfg.stage2.ratio_bot2top == 4 and cfg.stage2.vocab_size_txt == 16384          # config2.py:88,92
+    assert cfg.stage2.hparams.position_embedding == '1d' and cfg.stage2.hparams.use_random_order is False
+    assert cfg.stage2.hparams.ctx_len_txt == 64 and cfg.stage2.hparams_dec is None
+    assert cfg.stage1.hparams.num_res_blocks == 2 and cfg.stage1.hparams.out_ch == 3
+    assert cfg.stage1.hparams_aux.bottom_start == 100000000000
+    base = get_base_config(False)
+    assert base.stage2.hparams is None and base.stage1.hparams.ch_mult == [1, 1, 2, 2, 4]
+    over = merge(base, {'stage2': {'hparams': {'embed_dim': 64}}})
+    assert over.stage2.hparams.embed_dim == 64 and over.stage2.hparams.n_heads == 24     # Stage2Hparams defaults fill in
+
+
+def test_imagenet_spec_matches_the_survey_numbers():
+    cfg = load_config(IMAGENET)
+    s2, s1 = stage2_spec_from_config(cfg), stage1_spec_from_config(cfg)
+    assert (s2.embed_dim, s2.n_layers, s2.n_layers_depth, s2.n_heads, s2.vocab_top) == (1536, 12, 4, 24, 8192)
+    n2 = sum(int(np.prod(s)) for s in stage2_param_shapes(s2).values())
+    assert abs(n2 / 1e6 - 530.76) < 0.01
+    dec = sum(int(np.prod(s)) for k, s in stage1_param_shapes(s1).items() if k.startswith('decoder'))
+    assert abs(dec / 1e6 - 53.95) < 0.01
+    w = work_per_image(s2, s1, 64)
+    assert abs(w['ar_weight_bytes_per_pos'] / 1e9 - 1.184) < 0.002 and abs(w['dec_flops'] / 1e9 - 177.5) < 0.1
+    plan = decoder_plan(s1)
+    assert [l.kind for l in plan].count('attn') == 4 and plan[-1].res == 256 and plan[0].res == 16
+
+
+def test_unsupported_configs_are_refused():
+    cfg = load_config(TINY)
+    cfg.stage2.type = 'hq-transformer/top2bot'
+    with pytest.raises(NotImplementedError):
+        stage2_spec_from_config(cfg)
+    cfg = load_config(TINY)
+    cfg.stage1.type = 'hqvae'
+    with pytest.raises(NotImplementedError):
+        stage1_spec_from_config(cfg)
+
+
+def test_dotlist_like_omegaconf_from_cli():
+    a = parse_dotlist(['model_path=x.yaml', 'batch_size=64', 'n_loop=3'], EXPERIMENT_DEFAULTS)
+    assert a.batch_size == 64 and a.n_loop == 3 and a.warmup == 1 and a.top_resolution == 8 and a.model_path == 'x.yaml'
+    with pytest.raises(KeyError):
+        parse_dotlist(['nope=1'], EXPERIMENT_DEFAULTS)
+    assert iterations_per_loop(50) == 20 and iterations_per_loop(64) == 16 and iterations_per_loop(1000) == 1
+
+
+def test_sampling_hqmodel_arguments_and_legacy_keys():
+    a = build_parser().parse_args(['-r', 'out', '-m', 'cfg.yaml'])
+    assert (a.top_k, a.top_p, a.temperature, a.temperature_decay, a.batch_size, a.seed, a.num_classes) == (2048, 1.0, 1.0, 1.0, 50, 0, 1000)
+    sd = {'generator.stage1XXXX.decoder.conv_in.weight': 1, 'stage2.ln_f.weight': 2}
+    out = remap_legacy_keys(sd)
+    assert 'stage2.ln_f.weight' in out and any(k.startswith('stage1.') for k in out)
+
+
+def test_model_surface_and_state_dict_contract():
+    model = ImageGPT2(load_config(TINY), seed=0).eval()
+    s2 = model.stage2
+    assert s2.use_cls_cond and not s2.use_txt_cond and s2.idx_pred == 0
+    assert tuple(s2.sos.weight.shape) == (1000, 128)
+    fx = load('g4_tiny_cls.npz')
+    assert sum(p.numel() for p in s2.parameters()) > 0
+    sd = model.state_dict()
+    assert all(k.startswith(('stage1.', 'stage2.')) for k in sd)
+    model.load_state_dict(sd, strict=True)
+    extra = dict(sd)
+    extra['stage1.encoder.conv_in.weight'] = torch.zeros(1)                  # encode-side tensors are tolerated
+    extra['stage1.quantize_t.cluster_size'] = torch.zeros(1)
+    model.load_state_dict(extra, strict=True)
+    bad = dict(sd)
+    bad.pop('stage2.ln_f.weight')
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(bad, strict=True)
+    bad = dict(sd)
+    bad['stage2.ln_f.weight'] = torch.zeros(3)
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(bad, strict=False)
+    bad = dict(sd)
+    bad['stage2.bogus'] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(bad, strict=True)
+
+
+def test_no_cpu_compute_path():
+    model = ImageGPT2(load_config(TINY), seed=0)
+    with pytest.raises(_lib.HqtLibraryError):
+        sampling_ihqgpt(model.stage2, 2, 3, max_seq_len=4)
+    with pytest.raises(_lib.HqtLibraryError):
+        model.stage1.decode_code(torch.zeros(1, 8, 8, dtype=torch.long), torch.zeros(1, 16, 16, dtype=torch.long))
+
+
+def test_rearrange_codes_matches_einops_fixture():
+    fx = load('g6_index_maps.npz')
+    gt, gb = rearrange_codes(torch.from_numpy(fx['codes_top']), torch.from_numpy(fx['codes_bot']), 8)
+    assert (gt.numpy() == fx['grid_top']).all() and (gb.numpy() == fx['grid_bot']).all()
