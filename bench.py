@@ -52,6 +52,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-graph', action='store_true')
+    p.add_argument('--positions', type=int, default=0, help='DEBUG ONLY (counter collection): sample this many top positions '
+                   'instead of the full grid; the resulting line is marked invalid')
     return p.parse_args()
 
 
@@ -106,6 +108,9 @@ def main():
     s2, s1 = model.stage2.spec, model.stage1.spec
     B = args.batch
     n_pos = (s1.z_res // 2) ** 2
+    n_full = n_pos
+    if args.positions:
+        n_pos = min(n_pos, args.positions)
     fast = args.precision == 'fast'
     classes = synth.class_ids(1000 + rank, args.steps + args.warmup + 4, max(s2.n_classes, 1))
     H = s1.resolution
@@ -113,12 +118,18 @@ def main():
     if dist is not None and args.gather == 'pixels' and rank == 0:
         gathered = [torch.empty((B, s1.out_ch, H, H), dtype=torch.float32, device=dev) for _ in range(world)]
 
+    def decode(ct, cb):
+        if n_pos < n_full:      # debug runs: pad the code grids so the decoder still sees full-size inputs
+            ct = torch.cat([ct, ct.new_zeros(B, n_full - n_pos)], 1)
+            cb = torch.cat([cb, cb.new_zeros(B, n_full - n_pos, 4)], 1)
+        return model.stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
+
     def step(i, graph=True):
         ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), top_k_top=None, top_p_top=None,
                                  top_k_bot=None, top_p_bot=None, softmax_temperature=[1.0, 1.0], use_fp16=fast,
                                  is_tqdm=False, max_seq_len=n_pos, model_stage1=None, seed=1 + i,
                                  sample_offset=rank * B, use_graph=graph and not args.no_graph)
-        px = model.stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
+        px = decode(ct, cb)
         if dist is not None and args.gather == 'pixels':
             dist.gather(px, gathered, dst=0)
         elif dist is not None and args.gather == 'codes':
@@ -143,7 +154,7 @@ def main():
                                  use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i, sample_offset=rank * B,
                                  use_graph=not args.no_graph)
         ev[3 * k + 1].record()
-        px = model.stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
+        px = decode(ct, cb)
         ev[3 * k + 2].record()
         if dist is not None and args.gather == 'pixels':
             dist.gather(px, gathered, dst=0)
@@ -174,6 +185,8 @@ def main():
                        'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph},
             'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
         }
+        if n_pos < n_full:
+            out['INVALID'] = f'debug run: {n_pos} of {n_full} top positions sampled'
 
     # ---- roofline: per-launch HIP-event timers inside libhqt, un-graphed pass, rank 0 only
     if rank == 0 and not args.no_roofline:

@@ -106,6 +106,9 @@ struct hqt_handle {
     // ---- timing
     bool timing = false;
     std::vector<TimingSlot> slots;
+    hipEvent_t chain_ev = nullptr;
+    bool chain_valid = false;
+    std::vector<hipEvent_t> all_events;
 };
 
 static int dev_alloc(hqt_handle* h, void** p, size_t bytes, bool workspace) {
@@ -123,35 +126,43 @@ static int slot_id(hqt_handle* h, const char* name) {
     h->slots.back().name = name;
     return (int)h->slots.size() - 1;
 }
+// Per-launch timers (bench.py's roofline numerator): consecutive launches share one event -- the end event of a
+// launch is the start event of the next -- so a timed pass adds one hipEventRecord per kernel.
 struct Timed {
     hqt_handle* h; int slot; hipStream_t st; bool on;
     Timed(hqt_handle* h_, const char* name, hipStream_t st_) : h(h_), slot(-1), st(st_), on(h_->timing) {
         if (!on) return;
         slot = slot_id(h, name);
-        TimingSlot& s = h->slots[slot];
-        if (s.used == s.ev.size()) {
-            hipEvent_t a, b;
-            hipEventCreate(&a); hipEventCreate(&b);
-            s.ev.push_back({a, b});
+        if (!h->chain_valid) {
+            hipEventCreate(&h->chain_ev);
+            hipEventRecord(h->chain_ev, st);
+            h->chain_valid = true;
         }
-        hipEventRecord(s.ev[s.used].first, st);
     }
     ~Timed() {
         if (!on) return;
-        TimingSlot& s = h->slots[slot];
-        hipEventRecord(s.ev[s.used].second, st);
-        s.used++;
+        hipEvent_t e;
+        hipEventCreate(&e);
+        hipEventRecord(e, st);
+        h->slots[slot].ev.push_back({h->chain_ev, e});
+        h->slots[slot].used++;
+        h->all_events.push_back(h->chain_ev);
+        h->chain_ev = e;
     }
 };
 static void timing_collect(hqt_handle* h) {
+    if (h->chain_valid) hipEventSynchronize(h->chain_ev);
     for (auto& s : h->slots) {
-        for (size_t i = 0; i < s.used; ++i) {
-            hipEventSynchronize(s.ev[i].second);
+        for (auto& pr : s.ev) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, s.ev[i].first, s.ev[i].second) == hipSuccess) { s.total_ms += ms; s.launches++; }
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { s.total_ms += ms; s.launches++; }
         }
+        s.ev.clear();
         s.used = 0;
     }
+    for (hipEvent_t e : h->all_events) hipEventDestroy(e);
+    h->all_events.clear();
+    if (h->chain_valid) { hipEventDestroy(h->chain_ev); h->chain_valid = false; }
 }
 
 // ------------------------------------------------------------------------------------------ plan
@@ -281,7 +292,7 @@ extern "C" int hqt_destroy(hqt_handle* h) {
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
-    for (auto& s : h->slots) for (auto& e : s.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    timing_collect(h);
     for (void* p : h->owned) hipFree(p);
     delete h;
     return HQT_OK;
@@ -825,7 +836,7 @@ extern "C" int hqt_decode_seq(hqt_handle* h, int B, const int64_t* codes_top, co
 // ------------------------------------------------------------------------------------------ introspection
 extern "C" int64_t hqt_param_count(const hqt_handle* h, int stage) { return (h && (stage == 1 || stage == 2)) ? h->params[stage] : -1; }
 extern "C" int64_t hqt_workspace_bytes(const hqt_handle* h) { return h ? (int64_t)h->workspace_bytes : -1; }
-extern "C" int hqt_timing_enable(hqt_handle* h, int on) { if (!h) return fail(HQT_ERR_INVALID, "null"); h->timing = on != 0; return HQT_OK; }
+extern "C" int hqt_timing_enable(hqt_handle* h, int on) { if (!h) return fail(HQT_ERR_INVALID, "null"); timing_collect(h); h->timing = on != 0; return HQT_OK; }
 extern "C" int hqt_timing_reset(hqt_handle* h) {
     if (!h) return fail(HQT_ERR_INVALID, "null");
     timing_collect(h);
