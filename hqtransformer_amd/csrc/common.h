@@ -20,7 +20,7 @@ __device__ __host__ inline bf16_t f32_to_bf16(float f) {
 }
 
 enum { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_SIGMOID = 2 };
-enum { STORE_ROWS = 0, STORE_NCHW = 1, STORE_QKV = 2, STORE_PACKED = 3 };
+enum { STORE_ROWS = 0, STORE_NCHW = 1, STORE_QKV = 2, STORE_PACKED = 3, STORE_RESID = 4 };
 
 // MFMA-fragment-packed activation layout of the AR loop's GEMM A operands (FAST precision):
 // element (row m, column k) of an [Mpad = 32*MB, K] matrix lives at packed_off(m, k, MB), i.e.
@@ -79,6 +79,19 @@ struct GemmArgs {
     int qkv_D;
     int c_packed_mb;         // STORE_PACKED (and the q part of STORE_QKV stays row-major)
     const void* zero_page;   // >= 16 zero bytes in device memory (source of padded im2col taps for LDS-DMA loads)
+    // ---- deferred LayerNorm on the A operand (FAST AR loop).  A holds bf16(x), not LN(x); with W' = gamma o W,
+    //      LN(x) W^T + b = rstd_m (x W'^T - mean_m colsum(W')) + (b + W beta), so the normalisation becomes an epilogue.
+    //      Row statistics arrive as partial (sum, sum of squares) over column tiles: ln_parts[p][32 a_packed_mb][2].
+    const float* ln_parts;
+    int ln_nparts;
+    const float* ln_colsum;  // [N] = sum_k bf16(W'[n][k])
+    float ln_eps;
+    // ---- STORE_RESID: C (fp32 [M, ldc]) += value + bias; the bf16 copy of the new row goes to resid_pk in the
+    //      packed_off() layout (c_packed_mb) and the partial statistics of that copy to resid_parts as
+    //      [n_tile][32 c_packed_mb][2].  (Dedicated fields: reusing C2/C3 here made hipcc drop the STORE_QKV stores
+    //      through C3 in the same kernel.)
+    bf16_t* resid_pk;
+    float* resid_parts;
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position

@@ -47,6 +47,9 @@ struct Lin {            // one nn.Linear / conv filter bank in every layout the 
     const float* b32 = nullptr;   // [N] or null
     bf16_t* w16 = nullptr;        // [N, K] bf16 row-major (FAST generic + conv MFMA)
     bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)
+    bf16_t* wpk_ln = nullptr;     // same packing of gamma o W (deferred LayerNorm), with its column sums and folded bias
+    float* colsum = nullptr;
+    float* bias_ln = nullptr;
     int N = 0, K = 0;
 };
 
@@ -86,6 +89,10 @@ struct hqt_handle {
     float *x = nullptr, *xd = nullptr, *logits = nullptr;
     void *hbuf = nullptr, *qbuf = nullptr, *abuf = nullptr, *mbuf = nullptr;    // fp32-sized, reused as bf16 in FAST
     void *kcache = nullptr, *vcache = nullptr, *dk = nullptr, *dv = nullptr;
+    bf16_t *xpk = nullptr, *xdpk = nullptr;   // bf16 packed copies of the residual streams (FAST deferred LayerNorm)
+    float *parts = nullptr, *partsd = nullptr; // their partial row statistics [D/32][Mpad][2]
+    int nparts = 0, npartsd = 0;
+    float* fold_tmp = nullptr;
     float* splitk = nullptr;                  // split-K partial slabs of the streaming GEMM
     size_t splitk_elems = 0;
     struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
@@ -243,6 +250,10 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         h->splitk_elems = (size_t)16 * rows * (size_t)std::max<size_t>(4 * D, (size_t)c.vocab_top);
         CHK(dev_alloc(h.get(), (void**)&h->splitk, h->splitk_elems * 4, true));
         CHK(dev_alloc(h.get(), (void**)&h->state, sizeof(StepState), true));
+        CHK(dev_alloc(h.get(), (void**)&h->xpk, rows * D * 2, true));
+        CHK(dev_alloc(h.get(), (void**)&h->xdpk, rows * D * 2, true));
+        CHK(dev_alloc(h.get(), (void**)&h->parts, (D / 32 + 1) * rows * 2 * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->partsd, (D / 32 + 1) * rows * 2 * 4, true));
     }
     if (c.has_stage1) {
         if (c.s1_n_mult < 1 || c.s1_n_mult > 8) return fail(HQT_ERR_INVALID, "s1_n_mult");
@@ -345,6 +356,16 @@ static int make_lin(hqt_handle* h, Lin& l, const float* w32, const float* b32, i
     return HQT_OK;
 }
 
+// deferred LayerNorm: fold (gamma, beta) of the LayerNorm in front of `l` into a second packed copy of its weights
+static int fold_ln(hqt_handle* h, Lin& l, const float* gamma, const float* beta) {
+    if (!l.wpk) return HQT_OK;
+    CHK(dev_alloc(h, (void**)&l.wpk_ln, (size_t)l.N * l.K * 2, false));
+    CHK(dev_alloc(h, (void**)&l.colsum, (size_t)l.N * 4, false));
+    CHK(dev_alloc(h, (void**)&l.bias_ln, (size_t)l.N * 4, false));
+    HIPCHK(launch_fold_layernorm(l.w32, gamma, beta, l.b32, h->fold_tmp, l.wpk_ln, l.colsum, l.bias_ln, l.N, l.K, 0));
+    return HQT_OK;
+}
+
 static int load_block(hqt_handle* h, const std::string& p, BlockW& b) {
     const int64_t D = h->cfg.embed_dim;
     CHK(get_w(h, p + ".ln1.weight", {D}, &b.ln1_g));
@@ -377,6 +398,8 @@ static int load_block(hqt_handle* h, const std::string& p, BlockW& b) {
     CHK(get_w(h, p + ".mlp.2.weight", {D, 4 * D}, &w));
     CHK(get_w(h, p + ".mlp.2.bias", {D}, &bias));
     CHK(make_lin(h, b.fc2, w, bias, D, 4 * D, true));
+    CHK(fold_ln(h, b.qkv, b.ln1_g, b.ln1_b));
+    CHK(fold_ln(h, b.fc1, b.ln2_g, b.ln2_b));
     return HQT_OK;
 }
 
@@ -399,6 +422,7 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
     HIPCHK(hipSetDevice(h->device));
     const hqt_config& c = h->cfg;
     if (c.has_stage2) {
+        HIPCHK(hipMalloc((void**)&h->fold_tmp, (size_t)std::max(4 * c.embed_dim, c.vocab_top) * c.embed_dim * 4));
         h->body.resize(c.n_layers);
         h->depth.resize(c.n_layers_depth);
         for (int i = 0; i < c.n_layers; ++i) CHK(load_block(h, "stage2.blocks." + std::to_string(i), h->body[i]));
@@ -421,6 +445,16 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
         CHK(get_w(h, "stage2.pos_emb_top.weight", {c.ctx_len_img, D}, &t));
         CHK(get_w(h, "stage2.tok_emb_top_depth.weight", {c.vocab_top, D}, &t));
         CHK(get_w(h, "stage2.pos_emb_depth.weight", {5, D}, &t));
+        {
+            const float *g1, *b1;
+            CHK(get_w(h, "stage2.ln_top.weight", {D}, &g1)); CHK(get_w(h, "stage2.ln_top.bias", {D}, &b1));
+            CHK(fold_ln(h, h->head_top, g1, b1));
+            CHK(get_w(h, "stage2.ln_bot.weight", {D}, &g1)); CHK(get_w(h, "stage2.ln_bot.bias", {D}, &b1));
+            CHK(fold_ln(h, h->head_bot, g1, b1));
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipFree(h->fold_tmp));
+            h->fold_tmp = nullptr;
+        }
         if (c.cond_type == HQT_COND_CLASS) CHK(get_w(h, "stage2.sos.weight", {c.n_classes, D}, &t));
         else if (c.cond_type == HQT_COND_TEXT) {
             CHK(get_w(h, "stage2.tok_emb_txt.weight", {c.vocab_txt, D}, &t));
@@ -480,8 +514,14 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     if (g.lda == 0) g.lda = l.K;
     Timed t(h, tag, st);
     if (md.fast) {
+        if (g.ln_parts) {                       // deferred LayerNorm: gamma-folded weights, folded bias; stream kernel only
+            if (!l.wpk_ln || !stream_gemm_ok(g, a_dt, c_dt)) return fail(HQT_ERR_STATE, "deferred-LayerNorm GEMM without folded weights (%s)", tag);
+            g.bias = l.bias_ln;
+            HIPCHK(launch_stream_gemm(g, l.wpk_ln, a_dt, c_dt, 1, nullptr, st));
+            return HQT_OK;
+        }
         if (l.wpk && !g.conv_taps && stream_gemm_ok(g, a_dt, c_dt)) {
-            int S = defer_residual ? stream_gemm_splitk(g) : 1;
+            int S = (defer_residual && g.store != STORE_RESID) ? stream_gemm_splitk(g) : 1;
             if ((size_t)S * 32 * g.a_packed_mb * g.N > h->splitk_elems) S = 1;
             HIPCHK(launch_stream_gemm(g, l.wpk, a_dt, c_dt, S, h->splitk, st));
             if (S > 1) { h->pend.slabs = h->splitk; h->pend.S = S; h->pend.rows = 32 * g.a_packed_mb; h->pend.bias = l.b32; }
@@ -515,7 +555,7 @@ static const float* W(hqt_handle* h, const char* name) { return h->w[std::string
 static int run_ln(hqt_handle* h, hipStream_t st, float* x, const float* g, const float* b, const float* add, void* y, int M,
                   int D, int in_rpg, int in_off, int out_dt, int out_pk) {
     Timed t(h, "layernorm", st);
-    LNArgs ln{x, g, b, add, y, M, D, in_rpg, in_off, 1e-5f, out_dt, out_pk, h->pend.slabs, h->pend.S, h->pend.rows, h->pend.bias};
+    LNArgs ln{x, g, b, add, y, M, D, in_rpg, in_off, 1e-5f, out_dt, out_pk, h->pend.slabs, h->pend.S, h->pend.rows, h->pend.bias, nullptr, 0, nullptr};
     h->pend.slabs = nullptr; h->pend.S = 0;
     HIPCHK(launch_layernorm(ln, st));
     return HQT_OK;
@@ -554,6 +594,46 @@ static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float*
     return HQT_OK;
 }
 
+// FAST block with deferred LayerNorm (5 launches instead of 7): the residual stream is kept as an fp32 master row plus
+// a bf16 packed copy with partial row statistics; qkv / fc1 consume the copy with gamma-folded weights and normalise in
+// their epilogue, proj / fc2 update all three in theirs.
+static bool dln_ok(hqt_handle* h, const SampleCtx& c, const BlockW& bw, int M) {
+    static const bool off = getenv("HQT_NO_DLN") != nullptr;      // debugging / A-B switch: classic LayerNorm kernels
+    if (off) return false;
+    return c.md.fast && M <= 256 && bw.qkv.wpk_ln && bw.fc1.wpk_ln && bw.proj.wpk && bw.fc2.wpk && h->cfg.embed_dim % 32 == 0;
+}
+static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float* x32, bf16_t* xpk, float* parts, int* nparts,
+                         int Tq, void* kc, void* vc, int Tcache, int t_base, const int* t_base_dev, int causal) {
+    const int D = h->cfg.embed_dim, M = c.B * Tq, pk = packed_mb(M);
+    GemmArgs g{};
+    g.A = xpk; g.M = M; g.batch = 1; g.a_packed_mb = pk;
+    g.ln_parts = parts; g.ln_nparts = *nparts; g.ln_colsum = bw.qkv.colsum; g.ln_eps = 1e-5f;
+    g.C = h->qbuf; g.C2 = kc; g.C3 = vc; g.ldc = D; g.qkv_D = D; g.store = STORE_QKV;
+    g.rows_per_group = Tq; g.group_stride = Tcache; g.row_offset = t_base; g.row_offset_dev = t_base_dev;
+    CHK(run_linear(h, c.md, g, bw.qkv, DT_BF16, DT_BF16, c.st, "gemm_qkv"));
+    {
+        Timed t(h, "attention", c.st);
+        AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, DT_BF16, pk};
+        HIPCHK(launch_attention(a, c.st));
+    }
+    g = GemmArgs{};
+    g.A = h->abuf; g.M = M; g.batch = 1; g.a_packed_mb = pk;
+    g.C = x32; g.ldc = D; g.store = STORE_RESID; g.resid_pk = xpk; g.resid_parts = parts; g.c_packed_mb = pk;
+    CHK(run_linear(h, c.md, g, bw.proj, DT_BF16, DT_F32, c.st, "gemm_proj"));
+    *nparts = D / 32;
+    g = GemmArgs{};
+    g.A = xpk; g.M = M; g.batch = 1; g.a_packed_mb = pk;
+    g.ln_parts = parts; g.ln_nparts = *nparts; g.ln_colsum = bw.fc1.colsum; g.ln_eps = 1e-5f;
+    g.C = h->mbuf; g.ldc = 4 * D; g.store = STORE_PACKED; g.c_packed_mb = pk;
+    g.act = h->cfg.gelu_approx ? ACT_GELU_SIGMOID : ACT_GELU_ERF;
+    CHK(run_linear(h, c.md, g, bw.fc1, DT_BF16, DT_BF16, c.st, "gemm_fc1"));
+    g = GemmArgs{};
+    g.A = h->mbuf; g.M = M; g.batch = 1; g.a_packed_mb = pk;
+    g.C = x32; g.ldc = D; g.store = STORE_RESID; g.resid_pk = xpk; g.resid_parts = parts; g.c_packed_mb = pk;
+    CHK(run_linear(h, c.md, g, bw.fc2, DT_BF16, DT_F32, c.st, "gemm_fc2"));
+    return HQT_OK;
+}
+
 // Everything of one top position after the body input x is ready (hierarchical_ar.py:482-563,667-789)
 static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body_t_base, bool body_tbase_from_state) {
     const hqt_config& cf = h->cfg;
@@ -561,20 +641,43 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     const int adt = c.md.act_dt();
     const size_t esz = c.md.act_sz();
     const size_t kv_layer = (size_t)cf.max_batch * h->Tmax * D * esz;
-    for (int l = 0; l < cf.n_layers; ++l)
-        CHK(run_block(h, c, h->body[l], h->x, Tq_body, (char*)h->kcache + l * kv_layer, (char*)h->vcache + l * kv_layer,
-                      h->Tmax, body_t_base, body_tbase_from_state ? &h->state->t_base : nullptr, 1));
-    // ln_f on the last token of each sample, + sos_depth (hierarchical_ar.py:561,684-686)
-    CHK(run_ln(h, c.st, h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, DT_F32, 0));
+    const int* tb_dev = body_tbase_from_state ? &h->state->t_base : nullptr;
+    const bool dln_body = dln_ok(h, c, h->body[0], B * Tq_body);          // the caller's embedding kernel filled xpk / parts
+    for (int l = 0; l < cf.n_layers; ++l) {
+        void* kc = (char*)h->kcache + l * kv_layer;
+        void* vc = (char*)h->vcache + l * kv_layer;
+        if (dln_body) CHK(run_block_dln(h, c, h->body[l], h->x, h->xpk, h->parts, &h->nparts, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
+        else CHK(run_block(h, c, h->body[l], h->x, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
+    }
+    const bool dln1 = dln_ok(h, c, h->depth[0], B) && h->head_top.wpk_ln;
+    const bool dln4 = dln_ok(h, c, h->depth[0], 4 * B) && h->head_bot.wpk_ln;
+    // ln_f on the last token of each sample, + sos_depth (hierarchical_ar.py:561,684-686) -> depth-head input
+    {
+        Timed t(h, "layernorm", c.st);
+        LNArgs ln{h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, 1e-5f, DT_F32, 0,
+                  h->pend.slabs, h->pend.S, h->pend.rows, h->pend.bias, dln1 ? h->xdpk : nullptr, dln1 ? packed_mb(B) : 0, h->partsd};
+        h->pend.slabs = nullptr; h->pend.S = 0;
+        HIPCHK(launch_layernorm(ln, c.st));
+        h->npartsd = 1;
+    }
     const size_t dkv_layer = (size_t)cf.max_batch * 5 * D * esz;
     const int pk1 = (c.md.fast && B <= 256 && h->head_top.wpk) ? packed_mb(B) : 0;
     const int pk4 = (c.md.fast && 4 * B <= 256 && h->head_bot.wpk) ? packed_mb(4 * B) : 0;
     // ---- depth sub-step 0: top code
-    for (int l = 0; l < cf.n_layers_depth; ++l)
-        CHK(run_block(h, c, h->depth[l], h->xd, 1, (char*)h->dk + l * dkv_layer, (char*)h->dv + l * dkv_layer, 5, 0, nullptr, 0));
-    CHK(run_ln(h, c.st, h->xd, W(h, "ln_top.weight"), W(h, "ln_top.bias"), nullptr, h->hbuf, B, D, 1, 0, adt, pk1));
+    for (int l = 0; l < cf.n_layers_depth; ++l) {
+        void* kc = (char*)h->dk + l * dkv_layer;
+        void* vc = (char*)h->dv + l * dkv_layer;
+        if (dln1) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, 1, kc, vc, 5, 0, nullptr, 0));
+        else CHK(run_block(h, c, h->depth[l], h->xd, 1, kc, vc, 5, 0, nullptr, 0));
+    }
     GemmArgs g{};
-    g.A = h->hbuf; g.M = B; g.batch = 1; g.a_packed_mb = pk1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
+    if (dln1) {                                  // ln_top folded into head_top
+        g.A = h->xdpk; g.a_packed_mb = pk1; g.ln_parts = h->partsd; g.ln_nparts = h->npartsd; g.ln_colsum = h->head_top.colsum; g.ln_eps = 1e-5f;
+    } else {
+        CHK(run_ln(h, c.st, h->xd, W(h, "ln_top.weight"), W(h, "ln_top.bias"), nullptr, h->hbuf, B, D, 1, 0, adt, pk1));
+        g.A = h->hbuf; g.a_packed_mb = pk1;
+    }
+    g.M = B; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
     CHK(run_linear(h, c.md, g, h->head_top, adt, DT_F32, c.st, "gemm_head"));
     {
         Timed t(h, "sampler", c.st);
@@ -586,13 +689,23 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     {
         Timed t(h, "embed", c.st);
         HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
-                                  h->xd, B, D, c.st));
+                                  h->xd, B, D, dln4 ? h->xdpk : nullptr, dln4 ? packed_mb(4 * B) : 0, h->partsd, c.st));
+        h->npartsd = 1;
     }
-    for (int l = 0; l < cf.n_layers_depth; ++l)
-        CHK(run_block(h, c, h->depth[l], h->xd, 4, (char*)h->dk + l * dkv_layer, (char*)h->dv + l * dkv_layer, 5, 1, nullptr, 0));
-    CHK(run_ln(h, c.st, h->xd, W(h, "ln_bot.weight"), W(h, "ln_bot.bias"), nullptr, h->hbuf, 4 * B, D, 1, 0, adt, pk4));
+    for (int l = 0; l < cf.n_layers_depth; ++l) {
+        void* kc = (char*)h->dk + l * dkv_layer;
+        void* vc = (char*)h->dv + l * dkv_layer;
+        if (dln4) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, 4, kc, vc, 5, 1, nullptr, 0));
+        else CHK(run_block(h, c, h->depth[l], h->xd, 4, kc, vc, 5, 1, nullptr, 0));
+    }
     g = GemmArgs{};
-    g.A = h->hbuf; g.M = 4 * B; g.batch = 1; g.a_packed_mb = pk4; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
+    if (dln4) {
+        g.A = h->xdpk; g.a_packed_mb = pk4; g.ln_parts = h->partsd; g.ln_nparts = h->npartsd; g.ln_colsum = h->head_bot.colsum; g.ln_eps = 1e-5f;
+    } else {
+        CHK(run_ln(h, c.st, h->xd, W(h, "ln_bot.weight"), W(h, "ln_bot.bias"), nullptr, h->hbuf, 4 * B, D, 1, 0, adt, pk4));
+        g.A = h->hbuf; g.a_packed_mb = pk4;
+    }
+    g.M = 4 * B; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
     CHK(run_linear(h, c.md, g, h->head_bot, adt, DT_F32, c.st, "gemm_head"));
     {
         Timed t(h, "sampler", c.st);
@@ -611,7 +724,8 @@ static int run_decode_step(hqt_handle* h, const SampleCtx& c) {      // one KV-c
                     cf.cond_type == HQT_COND_CLASS ? W(h, "sos.weight") : (cf.cond_type == HQT_COND_NONE ? W(h, "sos") : nullptr),
                     W(h, "tok_emb_top.weight"), W(h, "tok_emb_bot.weight"), W(h, "pos_emb_top.weight"),
                     cf.embedding_type == HQT_EMB_TRANSFORMER1 ? W(h, "pos_emb_emb.weight") : nullptr,
-                    c.feed_top, c.feed_bot, h->x};
+                    c.feed_top, c.feed_bot, h->x, nullptr, 0, h->parts};
+        if (dln_ok(h, c, h->body[0], c.B)) { e.xpk = h->xpk; e.pk_mb = packed_mb(c.B); h->nparts = 1; }
         HIPCHK(launch_embed_step(e, c.st));
     }
     CHK(run_position(h, c, 1, 0, true));

@@ -11,6 +11,9 @@ hipError_t launch_repack_conv(const float* src, float* dst, int O, int I, int ta
 // ---- weight-streaming GEMM (AR loop, M = B or 4B rows): y[M,N] = x[M,K] W[N,K]^T, W pre-packed
 bool stream_gemm_supported(int N, int K);
 hipError_t launch_pack_stream_weights(const float* w32, bf16_t* packed, int N, int K, hipStream_t st);
+// deferred LayerNorm: packed bf16 of gamma o W, its column sums and the folded bias b + W beta (see GemmArgs::ln_parts)
+hipError_t launch_fold_layernorm(const float* w32, const float* gamma, const float* beta, const float* bias, float* wfold_tmp,
+                                 bf16_t* packed, float* colsum, float* bias_out, int N, int K, hipStream_t st);
 bool stream_gemm_ok(const GemmArgs& g, int a_dt, int c_dt);
 hipError_t stream_gemm_configure();     // raise dynamic-LDS limits once (call outside stream capture)
 // S = stream_gemm_splitk(g) (> 1 only when the caller can defer bias + residual to the next LayerNorm):

@@ -86,6 +86,18 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm_kernel(GemmArgs g, const 
     constexpr int TILE = NT * MBW * 1024;
     long long stamp[6];
     if (ABL == 9) { stamp[0] = wall_clock64(); stamp[1] = clock64(); }
+    // deferred LayerNorm: this thread's share of the partial row statistics (issued first, consumed in the epilogue)
+    float* lnstat = red + (size_t)NW * NT * MBW * 1024;               // [MBW*32][2] (sum, sumsq), then (mean, rstd)
+    float ln_s = 0.0f, ln_q = 0.0f;
+    constexpr int ROWS = MBW * 32, PGROUPS = NW * 64 / ROWS;          // threads per row
+    if (g.ln_parts) {
+        const int row = threadIdx.x % ROWS, pg = threadIdx.x / ROWS;
+        const int Mpad = g.a_packed_mb * 32, mrow = blockIdx.y * ROWS + row;
+        for (int p = pg; p < g.ln_nparts; p += PGROUPS) {
+            const float2 v = *reinterpret_cast<const float2*>(g.ln_parts + ((size_t)p * Mpad + mrow) * 2);
+            ln_s += v.x; ln_q += v.y;
+        }
+    }
     const int ntile0 = blockIdx.x * NT;
     const int mb0 = blockIdx.y * MBW;
     const int MB = g.a_packed_mb;
@@ -171,7 +183,24 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm_kernel(GemmArgs g, const 
                     *reinterpret_cast<f32x4*>(my + ((t * MBW + mb) * 32 + c) * 32 + 8 * gq + 4 * h) = v;
                 }
     }
+    if (g.ln_parts) {                                   // fixed-order (deterministic) reduction of the partial statistics
+        float* lnpart = lnstat + 2 * ROWS;              // [PGROUPS][ROWS][2]
+        lnpart[2 * threadIdx.x] = ln_s;                 // thread id = pg * ROWS + row
+        lnpart[2 * threadIdx.x + 1] = ln_q;
+    }
     __syncthreads();
+    if (g.ln_parts) {
+        const float* lnpart = lnstat + 2 * ROWS;
+        if (threadIdx.x < ROWS) {
+            float a = 0.0f, q = 0.0f;
+            for (int pg = 0; pg < PGROUPS; ++pg) { a += lnpart[2 * (pg * ROWS + threadIdx.x)]; q += lnpart[2 * (pg * ROWS + threadIdx.x) + 1]; }
+            const float mean = a / (float)g.K;
+            const float var = fmaxf(q / (float)g.K - mean * mean, 0.0f);
+            lnstat[2 * threadIdx.x] = mean;
+            lnstat[2 * threadIdx.x + 1] = 1.0f / sqrtf(var + g.ln_eps);
+        }
+        __syncthreads();
+    }
     if (ABL == 9) stamp[4] = clock64();
     if (ABL == 3) {
         if (threadIdx.x == 0) reinterpret_cast<float*>(g.C)[blockIdx.x] = red[0] + red[TILE];
@@ -181,11 +210,32 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm_kernel(GemmArgs g, const 
         const int n = o & 31, ml = (o >> 5) & 31, blk = o >> 10;
         const int mb = blk % MBW, t = blk / MBW;
         const int m = (mb0 + mb) * 32 + ml;
-        if (m >= g.M) continue;
         float s = red[o];
 #pragma unroll
         for (int w = 1; w < NW; ++w) s += red[(size_t)w * TILE + o];
         const int ncol = (ntile0 + t) * 32 + n;
+        if (g.ln_parts) s = lnstat[2 * (mb * 32 + ml) + 1] * (s - lnstat[2 * (mb * 32 + ml)] * g.ln_colsum[ncol]);
+        if (g.store == STORE_RESID && S == 1) {
+            // residual producer: fp32 master row, bf16 packed copy for the next GEMM, partial row statistics of that copy
+            float r = 0.0f;
+            if (m < g.M) {
+                float* xp = reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + ncol;
+                const float v = *xp + s * g.alpha + (g.bias ? g.bias[ncol] : 0.0f);
+                *xp = v;
+                const bf16_t hb = f32_to_bf16(v);
+                g.resid_pk[packed_off(m, ncol, g.c_packed_mb)] = hb;
+                r = bf16_to_f32(hb);
+            }
+            float rs = r, rq = r * r;                               // the 32 lanes of a half-wave share row m
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) { rs += __shfl_xor(rs, off, 64); rq += __shfl_xor(rq, off, 64); }
+            if (n == 0 && m < g.c_packed_mb * 32) {
+                float* pp = g.resid_parts + ((size_t)(ntile0 + t) * (g.c_packed_mb * 32) + m) * 2;
+                pp[0] = rs; pp[1] = rq;
+            }
+            continue;
+        }
+        if (m >= g.M) continue;
         if (S > 1 && ABL != 9) slabs[((size_t)blockIdx.z * (MB * 32) + m) * g.N + ncol] = s;
         else gemm_store<TC>(g, 0, m, ncol, s);
     }
@@ -199,15 +249,48 @@ __global__ __launch_bounds__(NW * 64) void stream_gemm_kernel(GemmArgs g, const 
     }
 }
 
+// ---- deferred-LayerNorm weight folding (finalize): W' = gamma o W, colsum[n] = sum_k bf16(W'[n][k]), b' = b + W beta
+__global__ void fold_gamma_kernel(const float* w, const float* gamma, float* out, int N, int K) {
+    const size_t total = (size_t)N * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = w[i] * gamma[i % K];
+}
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* wfold, const float* w, const float* beta, const float* bias,
+                                                        float* colsum, float* bias_out, int K) {
+    __shared__ float red[8];
+    const int n = blockIdx.x;
+    float cs = 0.0f, bb = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        cs += bf16_to_f32(f32_to_bf16(wfold[(size_t)n * K + k]));
+        bb += w[(size_t)n * K + k] * beta[k];
+    }
+    for (int off = 32; off > 0; off >>= 1) { cs += __shfl_xor(cs, off, 64); bb += __shfl_xor(bb, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = cs; red[4 + (threadIdx.x >> 6)] = bb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        colsum[n] = (red[0] + red[1]) + (red[2] + red[3]);
+        bias_out[n] = (bias ? bias[n] : 0.0f) + ((red[4] + red[5]) + (red[6] + red[7]));
+    }
+}
+hipError_t launch_fold_layernorm(const float* w32, const float* gamma, const float* beta, const float* bias, float* wfold_tmp,
+                                 bf16_t* packed, float* colsum, float* bias_out, int N, int K, hipStream_t st) {
+    const size_t n = (size_t)N * K;
+    fold_gamma_kernel<<<(int)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(w32, gamma, wfold_tmp, N, K);
+    fold_rows_kernel<<<N, 256, 0, st>>>(wfold_tmp, w32, beta, bias, colsum, bias_out, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_pack_stream_weights(wfold_tmp, packed, N, K, st);
+}
+
 bool stream_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
     (void)c_dt;
-    return g.a_packed_mb > 0 && a_dt == DT_BF16 && !g.conv_taps && g.M <= 256 && g.batch <= 1 && g.N % 64 == 0 &&
+    return g.a_packed_mb > 0 && a_dt == DT_BF16 && !g.conv_taps && g.M <= 256 && g.batch <= 1 && g.N % 32 == 0 &&
            g.K % 16 == 0 && g.a_packed_mb == packed_mb(g.M);
 }
 
 template <int MBW, int NT, int NW, int U, typename TC>
 static hipError_t launch_stream_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
-    const size_t smem = (size_t)NW * NT * MBW * 4096;
+    const size_t smem = (size_t)NW * NT * MBW * 4096 + (size_t)MBW * 256 + (size_t)NW * 512;
     const dim3 grid(g.N / (32 * NT), g.a_packed_mb / MBW, S);
     stream_gemm_kernel<MBW, NT, NW, U, TC><<<grid, NW * 64, smem, st>>>(g, reinterpret_cast<const u32x4*>(wpk), slabs);
     return hipGetLastError();
@@ -240,7 +323,7 @@ hipError_t stream_gemm_configure() {
     hipError_t e;
 #define CFG(MBW, NT, NW, U, TC)                                                                                    \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, TC>),                 \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NW * NT * MBW * 4096));      \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NW * NT * MBW * 4096 + (size_t)MBW * 256 + (size_t)NW * 512));      \
     if (e != hipSuccess) return e;
     STREAM_CASES(CFG, bf16_t)
     STREAM_CASES(CFG, float)

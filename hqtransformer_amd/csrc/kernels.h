@@ -21,6 +21,9 @@ struct EmbedArgs {
     const int64_t* codes_top;    // [B, n_steps]    (drawn or teacher-forced)
     const int64_t* codes_bot;    // [B, n_steps, 4]
     float* x;                    // [B, D]
+    bf16_t* xpk;                 // optional: bf16 copy in the packed_off() layout (pk_mb) + row statistics (FAST deferred LN)
+    int pk_mb;
+    float* parts;                // [1][32 pk_mb][2] (sum, sumsq) of the bf16 copy
 };
 hipError_t launch_embed_step(const EmbedArgs& a, hipStream_t st);
 
@@ -30,7 +33,7 @@ hipError_t launch_embed_text(const int64_t* cond, const float* tok, const float*
 
 // depth sub-step 1 input: x[b*4+s, :] = tok_top_depth[top[b, step]] + pos_depth[s]
 hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
-                              const float* pos, float* x, int B, int D, hipStream_t st);
+                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st);
 
 struct LNArgs {
     float* x;                    // [rows_in, D]; rewritten in place when split-K slabs are folded in
@@ -49,6 +52,10 @@ struct LNArgs {
     int n_slabs;
     int slab_rows;
     const float* slab_bias;      // [D] or NULL
+    // optional second output for the FAST deferred-LN path: bf16 packed copy of y (fp32 out) + its row statistics
+    bf16_t* ypk;
+    int ypk_mb;
+    float* yparts;
 };
 hipError_t launch_layernorm(const LNArgs& a, hipStream_t st);
 

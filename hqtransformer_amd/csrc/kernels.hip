@@ -28,6 +28,21 @@ struct OpAdd { template <typename T> __device__ T operator()(T a, T b) const { r
 struct OpMax { template <typename T> __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
 struct OpMin { template <typename T> __device__ T operator()(T a, T b) const { return a < b ? a : b; } };
 
+// Writes the bf16 copy of one fp32 row into the packed_off() layout and its (sum, sumsq) -- computed on the rounded
+// values, which is what the MFMA will multiply -- for the deferred-LayerNorm GEMMs.  Called by all 256 threads.
+__device__ __forceinline__ void emit_packed_row(const float* x, int m, int D, bf16_t* xpk, int pk_mb, float* parts, float* red) {
+    float s = 0.0f, q = 0.0f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const bf16_t hb = f32_to_bf16(x[d]);
+        xpk[packed_off(m, d, pk_mb)] = hb;
+        const float r = bf16_to_f32(hb);
+        s += r; q += r * r;
+    }
+    s = block_reduce(s, OpAdd(), red);
+    q = block_reduce(q, OpAdd(), red);
+    if (threadIdx.x == 0) { parts[2 * m] = s; parts[2 * m + 1] = q; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // step state
 // ---------------------------------------------------------------------------------------------
@@ -46,12 +61,14 @@ hipError_t launch_set_step(StepState* s, int step, int t_base, hipStream_t st) {
 // A3/K1: input embedding of one top position (hierarchical_ar.py:493-544)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_step_kernel(EmbedArgs a) {
+    __shared__ float red[4];
     const int b = blockIdx.x, D = a.D;
     const int step = a.state->step;
     float* x = a.x + (long long)b * D;
     if (step == 0) {
         const float* src = a.cond_type == 1 ? a.sos + a.cond[b] * (long long)D : a.sos;
         for (int d = threadIdx.x; d < D; d += blockDim.x) x[d] = src[d];
+        if (a.xpk) { __syncthreads(); emit_packed_row(x, b, D, a.xpk, a.pk_mb, a.parts, red); }
         return;
     }
     const int p = step - 1;
@@ -73,6 +90,7 @@ __global__ __launch_bounds__(256) void embed_step_kernel(EmbedArgs a) {
             x[d] = s / 5.0f;
         }
     }
+    if (a.xpk) { __syncthreads(); emit_packed_row(x, b, D, a.xpk, a.pk_mb, a.parts, red); }
 }
 hipError_t launch_embed_step(const EmbedArgs& a, hipStream_t st) {
     embed_step_kernel<<<a.B, 256, 0, st>>>(a);
@@ -92,14 +110,17 @@ hipError_t launch_embed_text(const int64_t* cond, const float* tok, const float*
 }
 
 __global__ __launch_bounds__(256) void depth_embed_kernel(const int64_t* codes_top, int n_steps, const StepState* state,
-                                                          const float* tok, const float* pos, float* x, int D) {
+                                                          const float* tok, const float* pos, float* x, int D, bf16_t* xpk,
+                                                          int pk_mb, float* parts) {
+    __shared__ float red[4];
     const int row = blockIdx.x, b = row >> 2, s = row & 3;
     const long long code = codes_top[(long long)b * n_steps + state->step];
     for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long long)row * D + d] = tok[code * D + d] + pos[(long long)s * D + d];
+    if (xpk) { __syncthreads(); emit_packed_row(x + (long long)row * D, row, D, xpk, pk_mb, parts, red); }
 }
 hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
-                              const float* pos, float* x, int B, int D, hipStream_t st) {
-    depth_embed_kernel<<<B * 4, 256, 0, st>>>(codes_top, n_steps, state, tok, pos, x, D);
+                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st) {
+    depth_embed_kernel<<<B * 4, 256, 0, st>>>(codes_top, n_steps, state, tok, pos, x, D, xpk, pk_mb, parts);
     return hipGetLastError();
 }
 
@@ -157,6 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LNArgs a) {
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
     const float rstd = 1.0f / sqrtf(wave_reduce(q, OpAdd()) / (float)D + a.eps);
+    float ys = 0.0f, yq = 0.0f;
     auto emit = [&](int vi, float4 t, float4 gm, float4 bt) {
         const int d = vi * 4;
         float o[4] = {(t.x - mean) * rstd * gm.x + bt.x, (t.y - mean) * rstd * gm.y + bt.y, (t.z - mean) * rstd * gm.z + bt.z,
@@ -171,6 +193,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LNArgs a) {
         } else {
             *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         }
+        if (a.ypk) {                              // deferred-LN consumers read this row as bf16 + its statistics
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+            *reinterpret_cast<uint2*>(a.ypk + packed_off(m, d, a.ypk_mb)) = pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float r = bf16_to_f32(f32_to_bf16(o[e])); ys += r; yq += r * r; }
+        }
     };
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) if (lane + i * 64 < nvec) emit(lane + i * 64, v[i], gmv[i], btv[i]);
@@ -178,6 +208,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LNArgs a) {
         float4 bt = *reinterpret_cast<const float4*>(a.beta + vi * 4);
         if (a.add) { const float4 ad = *reinterpret_cast<const float4*>(a.add + vi * 4); bt.x += ad.x; bt.y += ad.y; bt.z += ad.z; bt.w += ad.w; }
         emit(vi, *reinterpret_cast<const float4*>(x + vi * 4), *reinterpret_cast<const float4*>(a.gamma + vi * 4), bt);
+    }
+    if (a.ypk) {
+        ys = wave_reduce(ys, OpAdd());
+        yq = wave_reduce(yq, OpAdd());
+        if (lane == 0) { a.yparts[2 * m] = ys; a.yparts[2 * m + 1] = yq; }
     }
 }
 hipError_t launch_layernorm(const LNArgs& a, hipStream_t st) {

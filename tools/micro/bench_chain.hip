@@ -38,7 +38,7 @@ int main() {
     const int N = 4608, K = 1536, nbuf = 40;
     std::vector<bf16_t*> w(nbuf);
     for (auto& p : w) { CK(hipMalloc(&p, (size_t)N * K * 2)); CK(hipMemset(p, 0x3c, (size_t)N * K * 2)); }
-    LNArgs ln{x, gam, bet, nullptr, h, M, D, 1, 0, 1e-5f, DT_BF16, 2, nullptr, 0, 0, nullptr};
+    LNArgs ln{x, gam, bet, nullptr, h, M, D, 1, 0, 1e-5f, DT_BF16, 2, nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
     AttnArgs at{q, kc, vc, o, 64, 1, nh, 64, 128, T - 1, nullptr, 1, DT_BF16, 2};
     GemmArgs g{};
     g.A = h; g.a_packed_mb = 2; g.M = M; g.N = N; g.K = K; g.batch = 1; g.C = y; g.ldc = N; g.alpha = 1.f; g.store = STORE_ROWS;
@@ -47,6 +47,17 @@ int main() {
     float t;
     t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_layernorm(ln, st)); });
     printf("LayerNorm x%d back to back: %.2f us each\n", n, t / n);
+    {
+        LNArgs z = ln; z.M = 0;       // every wave exits at once: launch + kernarg cost of this geometry
+        t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) layernorm_kernel<bf16_t><<<16, 256, 0, st>>>(z); });
+        printf("LayerNorm geometry (16 x 256 threads), immediate exit: %.2f us each\n", t / n);
+        LNArgs one = ln; one.M = 4;
+        t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_layernorm(one, st)); });
+        printf("LayerNorm with 4 rows (1 workgroup): %.2f us each\n", t / n);
+        LNArgs f32 = ln; f32.out_dtype = DT_F32; f32.out_packed_mb = 0; f32.y = y;
+        t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_layernorm(f32, st)); });
+        printf("LayerNorm fp32 row-major output: %.2f us each\n", t / n);
+    }
     t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_attention(at, st)); });
     printf("attention (B=64, 24 heads, %d keys) x%d back to back: %.2f us each\n", T, n, t / n);
     t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); });
@@ -56,6 +67,18 @@ int main() {
     printf("LayerNorm + GEMM alternating: %.2f us per pair -> LayerNorm costs %.2f us in the chain\n", t / n, t / n - tg);
     t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_attention(at, st)); CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); } });
     printf("attention + GEMM alternating: %.2f us per pair -> attention costs %.2f us in the chain\n", t / n, t / n - tg);
+    {   // the real pattern: split-K GEMM (fc2-like, S = 2, writes slabs) -> LayerNorm folding the slabs -> wide GEMM
+        float* slabs; CK(hipMalloc(&slabs, 4ull * 64 * D * 4)); CK(hipMemset(slabs, 0, 4ull * 64 * D * 4));
+        GemmArgs g2{};
+        g2.A = h; g2.a_packed_mb = 2; g2.M = M; g2.N = D; g2.K = D; g2.batch = 1; g2.C = x; g2.ldc = D; g2.alpha = 1.f; g2.store = STORE_ROWS;
+        LNArgs lf = ln; lf.slabs = slabs; lf.n_slabs = 2; lf.slab_rows = 64; lf.slab_bias = bet;
+        float t2 = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_stream_gemm(g2, w[i], DT_BF16, DT_F32, 2, slabs, st)); CK(launch_stream_gemm(g, w[(i + 7) % n], DT_BF16, DT_F32, 1, nullptr, st)); } });
+        float t3 = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_stream_gemm(g2, w[i], DT_BF16, DT_F32, 2, slabs, st)); CK(launch_layernorm(lf, st)); CK(launch_stream_gemm(g, w[(i + 7) % n], DT_BF16, DT_F32, 1, nullptr, st)); } });
+        printf("proj(S=2) -> qkv: %.2f us per pair; proj(S=2) -> LN(fold 2 slabs) -> qkv: %.2f us -> LayerNorm costs %.2f us in the real chain\n", t2 / n, t3 / n, (t3 - t2) / n);
+        LNArgs l256 = lf; l256.M = 256; l256.out_packed_mb = 8; l256.slab_rows = 256; l256.n_slabs = 0; l256.slabs = nullptr;
+        t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) CK(launch_layernorm(l256, st)); });
+        printf("LayerNorm M=256 back to back: %.2f us each\n", t / n);
+    }
     t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_layernorm(ln, st)); CK(launch_attention(at, st)); CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); } });
     printf("LN + attention + GEMM: %.2f us per triple\n", t / n);
     return 0;
