@@ -80,7 +80,7 @@ hipError_t launch_pack_stream_weights(const float* w32, bf16_t* packed, int N, i
 // (cross-workgroup split-K) the fp32 partial tile goes to slab z of `slabs` ([S][Mpad][N]) and the
 // epilogue runs in the consumer (LayerNorm combine); with S == 1 the fused epilogue runs here.
 template <int MBW, int NT, int NW, int U, typename TC, int ABL = 0>   // ABL: ablation switches of tools/micro/bench_stream
-__global__ __launch_bounds__(NW * 64) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
+__global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);                  // [NW][NT*32 n][MBW*32 m] as [NT][MBW][m32][n32]
     constexpr int TILE = NT * MBW * 1024;

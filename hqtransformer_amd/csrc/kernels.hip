@@ -649,13 +649,14 @@ hipError_t launch_gn_stats(const void* x, int dtype, float* stats, int B, int HW
 
 // FAST variants: one pass over contiguous pixel chunks (every load a full 16-B vector), per-channel fp32
 // partials in registers, per-group double partials to memory, tiny finalize.
-#define GN_CHUNK_PIX 64
-__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double* partial, int HW, int C, int groups, int nchunk) {
+// pixels per workgroup: HW/32 clamped to [64, 1024] -> 4..64 chunks per image
+static inline int gn_chunk_pix(int HW) { int c = HW / 32; return c < 64 ? 64 : (c > 1024 ? 1024 : c); }
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double* partial, int HW, int C, int groups, int nchunk, int chunk_pix) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ssum = reinterpret_cast<float*>(smem_raw);      // [C] sum, [C] sumsq
     float* ssq = ssum + C;
     const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
-    const int p0 = ch * GN_CHUNK_PIX, p1 = min(HW, p0 + GN_CHUNK_PIX);
+    const int p0 = ch * chunk_pix, p1 = min(HW, p0 + chunk_pix);
     for (int c = threadIdx.x; c < 2 * C; c += 256) ssum[c] = 0.0f;
     __syncthreads();
     const int vec_per_pix = C / 8;
@@ -695,8 +696,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double
         partial[((long long)blockIdx.x * groups + g) * 2 + 1] = c2;
     }
 }
-__global__ void gn_finalize_kernel(const double* partial, float* stats, int nchunk, int groups, double count, float eps) {
+__global__ void gn_finalize_kernel(const double* partial, float* stats, int nchunk, int groups, double count, float eps, int n) {
     const int bg = blockIdx.x * blockDim.x + threadIdx.x;     // b * groups + g
+    if (bg >= n) return;
     const int b = bg / groups, g = bg % groups;
     double a = 0.0, q = 0.0;
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -710,16 +712,18 @@ __global__ void gn_finalize_kernel(const double* partial, float* stats, int nchu
 }
 size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups) {
     (void)C;
-    return (size_t)B * ((HW + GN_CHUNK_PIX - 1) / GN_CHUNK_PIX) * groups * 2;
+    const int cp = gn_chunk_pix(HW);
+    return (size_t)B * ((HW + cp - 1) / cp) * groups * 2;
 }
 hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, int B, int HW, int C, int groups, float eps,
                                 hipStream_t st) {
-    const int nchunk = (HW + GN_CHUNK_PIX - 1) / GN_CHUNK_PIX;
-    gn_partial_kernel<<<B * nchunk, 256, 2 * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk);
+    const int cp = gn_chunk_pix(HW);
+    const int nchunk = (HW + cp - 1) / cp;
+    gn_partial_kernel<<<B * nchunk, 256, 2 * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk, cp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int n = B * groups;
-    gn_finalize_kernel<<<(n + 63) / 64, 64, 0, st>>>(partial, stats, nchunk, groups, (double)HW * (C / groups), eps);
+    gn_finalize_kernel<<<(n + 63) / 64, 64, 0, st>>>(partial, stats, nchunk, groups, (double)HW * (C / groups), eps, n);
     return hipGetLastError();
 }
 
