@@ -52,6 +52,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-graph', action='store_true')
+    p.add_argument('--overlap', action='store_true', help='EXPERIMENT: run the decode of batch k on a second stream underneath the AR '
+                   'loop of batch k+1 (measured slower on MI355X: the decoder starves the latency-bound AR kernels)')
     p.add_argument('--positions', type=int, default=0, help='DEBUG ONLY (counter collection): sample this many top positions '
                    'instead of the full grid; the resulting line is marked invalid')
     return p.parse_args()
@@ -145,21 +147,34 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    # Optional pipeline experiment (--overlap): decode (+gather) of batch k on a second, lower-priority stream underneath
+    # the AR loop of batch k+1.  Measured on MI355X: AR 101 -> 129 ms under contention, net 494 -> 473 images/s, so the
+    # default is the serial order of the reference harness.
+    overlap = args.overlap
+    lo_prio, hi_prio = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, -1)
+    s_ar = torch.cuda.Stream(device=dev, priority=hi_prio) if overlap else torch.cuda.current_stream(dev)
+    s_dec = torch.cuda.Stream(device=dev, priority=lo_prio) if overlap else s_ar
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
+    keep = []
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
         i = args.warmup + k
-        ev[3 * k].record()
-        ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), softmax_temperature=[1.0, 1.0],
-                                 use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i, sample_offset=rank * B,
-                                 use_graph=not args.no_graph)
-        ev[3 * k + 1].record()
-        px = decode(ct, cb)
-        ev[3 * k + 2].record()
-        if dist is not None and args.gather == 'pixels':
-            dist.gather(px, gathered, dst=0)
-        elif dist is not None and args.gather == 'codes':
-            dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+        with torch.cuda.stream(s_ar):
+            ev[3 * k].record()
+            ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), softmax_temperature=[1.0, 1.0],
+                                     use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i, sample_offset=rank * B,
+                                     use_graph=not args.no_graph)
+            ev[3 * k + 1].record()
+        with torch.cuda.stream(s_dec):
+            s_dec.wait_event(ev[3 * k + 1])
+            px = decode(ct, cb)
+            ev[3 * k + 2].record()
+            if dist is not None and args.gather == 'pixels':
+                dist.gather(px, gathered, dst=0)
+            elif dist is not None and args.gather == 'codes':
+                dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+        keep.append((ct, cb, px))
     barrier()
     elapsed = time.perf_counter() - t0
     ar_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)) / args.steps
@@ -182,7 +197,8 @@ def main():
                                    f'batch {B}/GPU, {n_pos} top positions, top_k=top_p=None, T=[1,1]',
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
                        'precision': 'FAST: bf16 weights+MFMA, fp32 accumulate' if fast else 'EXACT: fp32',
-                       'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph},
+                       'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph,
+                       'pipeline': 'decode(k) overlaps AR(k+1) on a second stream' if overlap else 'serial'},
             'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
         }
         if n_pos < n_full:
