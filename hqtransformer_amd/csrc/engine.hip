@@ -492,6 +492,7 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
         }
     }
     HIPCHK(stream_gemm_configure());
+    HIPCHK(mfma_gemm_configure());
     HIPCHK(hipDeviceSynchronize());
     h->finalized = true;
     return HQT_OK;

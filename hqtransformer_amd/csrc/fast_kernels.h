@@ -24,3 +24,4 @@ hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, in
 // ---- tiled MFMA GEMM / implicit-GEMM conv (decoder, text prefill)
 bool mfma_gemm_ok(const GemmArgs& g, int a_dt, int b_dt, int c_dt);
 hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hipStream_t st);
+hipError_t mfma_gemm_configure();

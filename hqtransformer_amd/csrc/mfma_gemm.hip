@@ -241,10 +241,15 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
 // XOR.  With 128-B rows two rows share a 256-B bank line and 16 rows of one ds_read_b128 group land on 16
 // distinct 16-B slots.  Zero padding of the 3x3 taps comes from a zero page (DMA cannot predicate).
 // ---------------------------------------------------------------------------------------------
-template <typename TC, bool NCHW>
-__global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
+// NSTAGE = 2: two LDS buffers, plain __syncthreads() (hipcc drains the DMA in front of it), 2 workgroups per CU.
+// NSTAGE = 4: four-slot LDS ring (128 KiB, 1 workgroup per CU) with two k-tiles of DMA in flight across the barrier:
+//   counted s_waitcnt vmcnt(8 * tiles_in_flight) + raw s_barrier per k-tile; the slot of tile kt-1 is refilled right
+//   after the barrier that every wave passes only once it has finished reading that tile.
+template <typename TC, bool NCHW, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(GemmArgs g) {
     constexpr int BM = 128, BN = 128, BKG = 64, ROWB = 128;            // ROWB: bytes per LDS row
-    __shared__ __attribute__((aligned(16))) char lds[2][2][BM * ROWB];    // [buf][A|B]
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];     // [NSTAGE][A|B][BM * ROWB]
+    auto LDS = [&](int stage, int op) -> char* { return lds_raw + (size_t)(stage * 2 + op) * (BM * ROWB); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int bz = blockIdx.z;
@@ -285,14 +290,14 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
                         src = Abase + (((long long)arow[i].img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * g.Cin + c0 + chunk[i];
                 }
             }
-            char* dst = &lds[buf][0][(wave * 4 + i) * 8 * ROWB];            // wave-uniform base; HW adds 16 * lane
+            char* dst = LDS(buf, 0) + (wave * 4 + i) * 8 * ROWB;            // wave-uniform base; HW adds 16 * lane
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16_t* src = brow[i] ? brow[i] + k0 + chunk[i] : zero;
-            char* dst = &lds[buf][1][(wave * 4 + i) * 8 * ROWB];
+            char* dst = LDS(buf, 1) + (wave * 4 + i) * 8 * ROWB;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -307,14 +312,10 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int KT = g.K / BKG;
-    issue(0, 0);
-    __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
     const int fr = lane & 31, fh = lane >> 5;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
-        const char* Ab = lds[buf][0];
-        const char* Bb = lds[buf][1];
+    auto compute = [&](int buf) {
+        const char* Ab = LDS(buf, 0);
+        const char* Bb = LDS(buf, 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 2 + fh;
@@ -334,7 +335,30 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+    };
+    if constexpr (NSTAGE == 2) {
+        issue(0, 0);
+        __syncthreads();                               // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+            compute(buf);
+            __syncthreads();
+        }
+    } else {
+        for (int s0 = 0; s0 < NSTAGE - 1 && s0 < KT; ++s0) issue(s0, s0);
+        for (int kt = 0; kt < KT; ++kt) {
+            // tiles kt+1 .. kt+NSTAGE-2 may stay in flight; each tile is 8 DMA instructions per wave
+            const int inflight = min(NSTAGE - 2, KT - 1 - kt);
+            if (inflight >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (inflight == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+            compute(kt % NSTAGE);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads are done before it re-arrives
+        }
     }
     // epilogue: plain row-major store (template NCHW = false) or the fp32 NCHW store of conv_out
     TC* Cb = reinterpret_cast<TC*>(g.C) + (long long)bz * g.c_batch_stride;
@@ -399,16 +423,34 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
     if (narrow || (g.N >= 128 && g.M >= 128 && (tiles128 >= 192 || force128))) {
         if (glds_ok(g)) {
             const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
+            static const int nstage = getenv("HQT_CONV_STAGES") ? atoi(getenv("HQT_CONV_STAGES")) : 2;   // A/B switch: the 4-slot ring (1 WG/CU) measured 1.5x slower than 2 buffers x 2 WGs/CU
+            const bool ring = nstage == 4 && g.K / 64 >= 4;
+            const size_t smem = (size_t)(ring ? 4 : 2) * 2 * 128 * 128;
+#define LAUNCH_GLDS(TC, NCHW_)                                                                      \
+            if (ring) conv_glds_kernel<TC, NCHW_, 4><<<grid, 256, smem, st>>>(g);                    \
+            else conv_glds_kernel<TC, NCHW_, 2><<<grid, 256, smem, st>>>(g);
             if (g.store == STORE_NCHW) {
-                if (c_dt == DT_BF16) conv_glds_kernel<bf16_t, true><<<grid, 256, 0, st>>>(g);
-                else conv_glds_kernel<float, true><<<grid, 256, 0, st>>>(g);
+                if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, true) } else { LAUNCH_GLDS(float, true) }
             } else {
-                if (c_dt == DT_BF16) conv_glds_kernel<bf16_t, false><<<grid, 256, 0, st>>>(g);
-                else conv_glds_kernel<float, false><<<grid, 256, 0, st>>>(g);
+                if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, false) } else { LAUNCH_GLDS(float, false) }
             }
+#undef LAUNCH_GLDS
             return hipGetLastError();
         }
         return launch_t<128, 128>(g, c_dt, st);
     }
     return launch_t<64, 64>(g, c_dt, st);
+}
+
+// raise the dynamic-LDS limits of the LDS-DMA conv kernels once (call outside stream capture)
+hipError_t mfma_gemm_configure() {
+    hipError_t e;
+#define CFG(TC, NCHW_, NS)                                                                                          \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_glds_kernel<TC, NCHW_, NS>),                        \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, NS * 2 * 128 * 128);                        \
+    if (e != hipSuccess) return e;
+    CFG(bf16_t, false, 2) CFG(bf16_t, false, 4) CFG(float, false, 2) CFG(float, false, 4)
+    CFG(bf16_t, true, 2) CFG(bf16_t, true, 4) CFG(float, true, 2) CFG(float, true, 4)
+#undef CFG
+    return hipSuccess;
 }
