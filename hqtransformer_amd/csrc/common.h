@@ -36,6 +36,45 @@ __device__ __host__ inline int packed_mb(int M) { return M <= 32 ? 1 : (M <= 64 
 //     nearest-x2 upsampling folded into the addressing and GroupNorm(+swish) applied on load;
 //   * an output row remap (KV-cache append), a per-image transposed store (NCHW / V^T), or a
 //     three-way column split (fused QKV).
+struct ChainSync {
+    const unsigned* wait;    // NULL: no predecessor to wait for
+    unsigned target;
+    unsigned* signal;        // NULL: nobody waits for this kernel
+    unsigned* err;
+};
+
+// Called by every thread of the workgroup.  Consumer side of the hand-off: one lane polls (relaxed, agent scope), fences
+// once (acquire, agent scope: drops this CU's L1 and the XCD L2's stale lines), then the workgroup barrier.
+#define HQT_CHAIN_SPIN_LIMIT (1u << 17)
+__device__ inline unsigned chain_poll(const ChainSync& c) {      // issued before the independent loads; consumed by chain_wait
+    return c.wait ? __hip_atomic_load(c.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+__device__ inline void chain_wait(const ChainSync& c, unsigned polled) {
+    if (!c.wait) return;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (polled < c.target) {
+            if (++spins > HQT_CHAIN_SPIN_LIMIT) { if (c.err) *c.err = 1u; break; }
+            __builtin_amdgcn_s_sleep(1);
+            polled = __hip_atomic_load(c.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+// Producer side: every wave drains its stores, workgroup barrier, one lane releases at agent scope and arrives.
+__device__ inline void chain_signal(const ChainSync& c) {
+    if (!c.signal) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(c.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 struct GemmArgs {
     // ---- A
     const void* A;           // plain: [M, lda]; conv: NHWC [batch_img, Hin, Win, Cin]
@@ -92,6 +131,11 @@ struct GemmArgs {
     //      through C3 in the same kernel.)
     bf16_t* resid_pk;
     float* resid_parts;
+    // ---- chained launches (AR loop on two alternating streams): consecutive kernels may be co-resident; a kernel issues
+    //      the loads that do not depend on its predecessor (weights), then waits until chain_wait[0] >= chain_target
+    //      (= the predecessor's workgroup count; every workgroup adds 1 to its chain_signal after its last store, behind
+    //      an agent-scope release).  Spins are bounded: on give-up chain_err[0] is set and the results are garbage.
+    ChainSync chain;
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position

@@ -75,6 +75,24 @@ hipError_t launch_pack_stream_weights(const float* w32, bf16_t* packed, int N, i
     return hipGetLastError();
 }
 
+// This thread's share of the partial LayerNorm row statistics (thread = pg * ROWS + row): loads issued together
+// (clamped, never predicated), then summed in index order.
+template <int ROWS, int PGROUPS>
+__device__ inline void ln_partial_stats(const GemmArgs& g, float& ln_s, float& ln_q) {
+    const int row = threadIdx.x % ROWS, pg = threadIdx.x / ROWS;
+    const int Mpad = g.a_packed_mb * 32, mrow = blockIdx.y * ROWS + row;
+    const float2* base = reinterpret_cast<const float2*>(g.ln_parts) + mrow;
+    constexpr int NPL = 4;
+    for (int p0 = pg; p0 < g.ln_nparts; p0 += NPL * PGROUPS) {
+        float2 v[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) v[i] = base[(size_t)min(p0 + i * PGROUPS, g.ln_nparts - 1) * Mpad];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+            if (p0 + i * PGROUPS < g.ln_nparts) { ln_s += v[i].x; ln_q += v[i].y; }
+    }
+}
+
 // Tile of one workgroup: (32 NT) weight rows x (32 MBW) activation rows x K / gridDim.z; the NW waves
 // split that K range into contiguous runs.  gridDim = (N / (32 NT), MB_total / MBW, S).  With S > 1
 // (cross-workgroup split-K) the fp32 partial tile goes to slab z of `slabs` ([S][Mpad][N]) and the
@@ -90,14 +108,6 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
     float* lnstat = red + (size_t)NW * NT * MBW * 1024;               // [MBW*32][2] (sum, sumsq), then (mean, rstd)
     float ln_s = 0.0f, ln_q = 0.0f;
     constexpr int ROWS = MBW * 32, PGROUPS = NW * 64 / ROWS;          // threads per row
-    if (g.ln_parts) {
-        const int row = threadIdx.x % ROWS, pg = threadIdx.x / ROWS;
-        const int Mpad = g.a_packed_mb * 32, mrow = blockIdx.y * ROWS + row;
-        for (int p = pg; p < g.ln_nparts; p += PGROUPS) {
-            const float2 v = *reinterpret_cast<const float2*>(g.ln_parts + ((size_t)p * Mpad + mrow) * 2);
-            ln_s += v.x; ln_q += v.y;
-        }
-    }
     const int ntile0 = blockIdx.x * NT;
     const int mb0 = blockIdx.y * MBW;
     const int MB = g.a_packed_mb;
@@ -124,14 +134,22 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
     u32x4 wbuf[U][NT];
     u32x4 xbuf[U][MBW];
     int ks = 0;
+    bool first = true;
+    const unsigned polled = chain_poll(g.chain);
     for (; ks + U <= cnt; ks += U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < NT; ++t) wbuf[u][t] = __builtin_nontemporal_load(wp + ((size_t)t * KS + (ABL == 2 ? 0 : ks + u)) * 64);
+        if (first) {                                  // weights are in flight; everything below depends on the predecessor
+            __builtin_amdgcn_sched_barrier(0);
+            chain_wait(g.chain, polled);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) xbuf[u][mb] = xp[((size_t)(ABL == 1 ? 0 : ks + u) * MB + mb) * 64];
-        }
+        first = false;
         // keep every load of the run in flight before the first MFMA: without this fence the
         // scheduler re-rolls the block into 2-4 loads per wait to save VGPRs (12+ serial round trips)
         __builtin_amdgcn_sched_barrier(0);
@@ -145,6 +163,9 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
                 for (int mb = 0; mb < MBW; ++mb)
                     acc[t][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, xbuf[u][mb]), acc[t][mb], 0, 0, 0);
             }
+    }
+    if (first) {                                      // K too short for a full run: nothing was prefetched
+        chain_wait(g.chain, polled);
     }
     if (ks < cnt) {                                   // ragged tail (tiny K only)
         const int rem = cnt - ks;
@@ -169,6 +190,8 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
             }
     }
     if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); stamp[3] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+    // deferred LayerNorm: partial row statistics, loaded while the operand registers are dead and the accumulators drain
+    if (g.ln_parts) ln_partial_stats<ROWS, PGROUPS>(g, ln_s, ln_q);
     // ---- cross-wave reduction through LDS; C/D map: col = lane & 31 -> m, row = (r&3) + 8 (r>>2) + 4 (lane>>5) -> n
     {
         float* my = red + (size_t)wave * TILE;
@@ -239,6 +262,7 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
         if (S > 1 && ABL != 9) slabs[((size_t)blockIdx.z * (MB * 32) + m) * g.N + ncol] = s;
         else gemm_store<TC>(g, 0, m, ncol, s);
     }
+    chain_signal(g.chain);
     if (ABL == 9) {
         stamp[5] = clock64();
         if (lane == 0) {

@@ -19,6 +19,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 constexpr int BK = 32;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
 // NSTAGE = 4: four-slot LDS ring (128 KiB, 1 workgroup per CU) with two k-tiles of DMA in flight across the barrier:
 //   counted s_waitcnt vmcnt(8 * tiles_in_flight) + raw s_barrier per k-tile; the slot of tile kt-1 is refilled right
 //   after the barrier that every wave passes only once it has finished reading that tile.
-template <typename TC, bool NCHW, int NSTAGE>
+template <typename TC, bool NCHW, int NSTAGE, int ABL = 0>       // ABL: ablation switches of tools/micro/bench_conv
 __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(GemmArgs g) {
     constexpr int BM = 128, BN = 128, BKG = 64, ROWB = 128;            // ROWB: bytes per LDS row
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];     // [NSTAGE][A|B][BM * ROWB]
@@ -341,8 +342,8 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
         __syncthreads();                               // hipcc drains the DMA (vmcnt(0)) in front of the barrier
         for (int kt = 0; kt < KT; ++kt) {
             const int buf = kt & 1;
-            if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
-            compute(buf);
+            if (kt + 1 < KT && ABL != 2) issue(ABL == 4 ? 1 : kt + 1, buf ^ 1);
+            if (ABL != 3 || kt == 0) compute(buf);
             __syncthreads();
         }
     } else {
@@ -359,6 +360,17 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
             compute(kt % NSTAGE);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads are done before it re-arrives
         }
+    }
+    if (ABL == 1) {                                     // no epilogue: keep the accumulators alive, one store per wave
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
+        return;
     }
     // epilogue: plain row-major store (template NCHW = false) or the fp32 NCHW store of conv_out
     TC* Cb = reinterpret_cast<TC*>(g.C) + (long long)bz * g.c_batch_stride;
@@ -387,6 +399,235 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
                 }
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 'same' convolution with the input patch resident in LDS ("halo tile").
+// One workgroup = an 8 x 16 pixel tile of one image x 128 output channels.  Per 64-channel chunk the (8+2) x (16+2)
+// input patch (180 rows of 128 B) is DMA'd into LDS ONCE and serves all nine taps: tap (dy, dx) of output pixel
+// (py, px) is patch row (py + dy) * 18 + px + dx, so the im2col view never exists, not even as addresses.  Against
+// the generic implicit GEMM above this cuts the LDS-DMA pieces per k-tile from 8 to 4.6 per wave (the measured
+// bound of that kernel: tools/micro/bench_conv) and the address arithmetic to one add per chunk.  Zero padding and
+// the nearest x2 upsample are folded into the patch rows' source addresses (zero page for rows outside the image).
+// K order is chunk-major (c, tap); the filter matrix stays tap-major [O][tap][I], k0 = tap * Cin + 64 c.
+// The weights are the MFMA A operand here (D rows = n, D cols = pixels): a lane then owns 4 consecutive output
+// channels of one pixel per register quad, and the epilogue stages the fp32 tile through LDS (the dead patch/filter
+// buffers) to write full 256-B NHWC rows with 16-B stores per lane instead of 64 two-byte stores.
+// LDS: patch 2 x 184 rows + filters 2 x 128 rows, 128 B each = 78 KiB -> two workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int HALO_TY = 8, HALO_TX = 16, HALO_PITCH = HALO_TX + 2, HALO_ROWS = (HALO_TY + 2) * HALO_PITCH;   // 180
+constexpr int HALO_PIECES = (HALO_ROWS + 7) / 8;                                                             // 23 DMA pieces of 8 rows
+constexpr int HALO_PATCH_BYTES = HALO_PIECES * 8 * 128, HALO_B_BYTES = 128 * 128;
+constexpr int HALO_LDS = 2 * HALO_PATCH_BYTES + 2 * HALO_B_BYTES;
+constexpr int HALO_CPITCH = 128 * 4 + 16;                                                                    // fp32 staging row (bytes)
+static_assert(128 * HALO_CPITCH <= HALO_LDS, "epilogue staging must fit in the operand buffers");
+
+template <typename TC, bool NCHW, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    auto PATCH = [&](int s) -> char* { return lds_raw + (size_t)s * HALO_PATCH_BYTES; };
+    auto BT = [&](int s) -> char* { return lds_raw + 2 * HALO_PATCH_BYTES + (size_t)s * HALO_B_BYTES; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int n0 = tile_n * 128;
+    const int tiles_x = g.W / HALO_TX, tiles_y = g.H / HALO_TY;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * HALO_TY, tx0 = (trem % tiles_x) * HALO_TX;
+    const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
+    const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A);
+    const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(g.Bw);
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g.zero_page);
+
+    // ---- DMA sources.  Patch piece p = wave + 4 t fills patch rows 8 p .. 8 p + 7; lane -> (row q, slot lane & 7),
+    //      source chunk = slot ^ ((q >> 1) & 7) (the same involution the fragment reads apply).
+    constexpr int PPW = (HALO_PIECES + 3) / 4;                      // pieces per wave (6; the last wave has 5)
+    const bf16_t* psrc[PPW];
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+        const int q = (wave + 4 * t) * 8 + (lane >> 3);
+        const int qy = q / HALO_PITCH, qx = q - qy * HALO_PITCH;
+        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+        const int ch = ((lane & 7) ^ ((q >> 1) & 7)) * 8;
+        psrc[t] = (q < HALO_ROWS && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                      ? Abase + (((long long)img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * g.Cin + ch
+                      : nullptr;
+    }
+    const bf16_t* brow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        brow[i] = (n0 + row < g.N) ? Bbase + (long long)(n0 + row) * g.ldb + ch : nullptr;
+    }
+    auto issue_patch = [&](int c, int s) {
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            if (wave + 4 * t < HALO_PIECES) {                       // wave-uniform
+                const bf16_t* src = psrc[t] ? psrc[t] + c * 64 : zero;
+                char* dst = PATCH(s) + (wave + 4 * t) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    auto issue_b = [&](int k0, int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* src = brow[i] ? brow[i] + k0 : zero;
+            char* dst = BT(s) + (wave * 4 + i) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];                                               // [pixel block i][channel block j]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // pixel of this lane in fragment i: tile row wm * 64 + i * 32 + fr -> (py, px); patch row of tap (0, 0)
+    int qbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) qbase[i] = (wm * 4 + i * 2 + (fr >> 4)) * HALO_PITCH + (fr & 15);
+    int brd[2];                                                     // filter fragment rows
+#pragma unroll
+    for (int j = 0; j < 2; ++j) brd[j] = wn * 64 + j * 32 + fr;
+
+    auto compute = [&](int ps, int bs, int tapoff) {
+        const char* Pb = PATCH(ps);
+        const char* Bb = BT(bs);
+        int qa[2], sw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { qa[i] = (qbase[i] + tapoff) * 128; sw[i] = ((qbase[i] + tapoff) >> 1) & 7; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks * 2 + fh;
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Pb + qa[i] + ((c ^ sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + brd[j] * 128 + ((c ^ ((brd[j] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int NC = g.Cin / 64, KT = NC * 9;
+    issue_patch(0, 0);
+    issue_b(0, 0);
+    __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    int kt = 0;
+    for (int c = 0; c < NC; ++c) {
+        for (int tap = 0; tap < 9; ++tap, ++kt) {
+            if (kt + 1 < KT && ABL != 2) {
+                const int tn = tap == 8 ? 0 : tap + 1, cn = tap == 8 ? c + 1 : c;
+                issue_b(tn * g.Cin + cn * 64, (kt + 1) & 1);
+                if (tap == 0 && c + 1 < NC) issue_patch(c + 1, (c + 1) & 1);
+            }
+            const int t3 = (tap * 11) >> 5;            // tap / 3 for tap < 9
+            if (ABL != 3 || kt == 0) compute(c & 1, kt & 1, t3 * HALO_PITCH + (tap - 3 * t3));
+            __syncthreads();
+        }
+    }
+    if (ABL == 1) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
+        return;
+    }
+    // ---- epilogue.  D map: col = lane & 31 -> pixel fr of block i; row = (r & 3) + 8 (r >> 2) + 4 fh -> channel
+    const long long pix0 = ((long long)img * g.H + ty0) * g.W + tx0;         // NHWC row of tile pixel (0, 0)
+    if (NCHW) {                                        // conv_out: fp32 NCHW (+clamp); lanes = consecutive pixels of a row
+        TC* Cb = reinterpret_cast<TC*>(g.C);
+        const long long hw = (long long)g.H * g.W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wm * 64 + i * 32 + fr;
+            const long long pix = (long long)(ty0 + (r >> 4)) * g.W + tx0 + (r & 15);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = n0 + wn * 64 + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    if (n >= g.N) continue;
+                    float v = acc[i][j][e] * g.alpha + (g.bias ? g.bias[n] : 0.0f);
+                    if (g.clamp01) v = fminf(fmaxf(0.5f * v + 0.5f, 0.0f), 1.0f);
+                    st1<TC>(Cb + ((long long)img * g.N + n) * hw + pix, v);
+                }
+        }
+        return;
+    }
+    char* stage = lds_raw;                              // [128 pixels][HALO_CPITCH] fp32; every operand read is behind the last barrier
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int nl = wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                *reinterpret_cast<f32x4*>(stage + r * HALO_CPITCH + nl * 4) = v;
+            }
+    }
+    __syncthreads();
+    {
+        TC* Cb = reinterpret_cast<TC*>(g.C);
+        const TC* Rb = reinterpret_cast<const TC*>(g.resid);
+        const int c8 = (tid & 15) * 8;                  // 8 consecutive channels per thread, 16 threads per pixel row
+        const int nn = n0 + c8;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (g.bias && nn + e < g.N) ? g.bias[nn + e] : 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int r = pass * 16 + (tid >> 4);
+            const long long m = pix0 + (long long)(r >> 4) * g.W + (r & 15);
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * HALO_CPITCH + c8 * 4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * HALO_CPITCH + c8 * 4 + 16);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * g.alpha + bv[e], g.act);
+            TC* dst = Cb + m * g.ldc + nn;
+            if (nn + 8 <= g.N) {
+                if (Rb) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(Rb + m * g.ldc + nn);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_to_f32((bf16_t)(rr[e] & 0xffffu)); v[2 * e + 1] += bf16_to_f32((bf16_t)(rr[e] >> 16)); }
+                }
+                const u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+                *reinterpret_cast<u32x4*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (nn + e < g.N) { float x = v[e]; if (Rb) x += ld1<TC>(Rb + m * g.ldc + nn + e); st1<TC>(dst + e, x); }
+            }
+        }
+    }
+}
+
+// shapes the halo kernel takes: bf16 3x3 conv, whole 8 x 16 pixel tiles, 64-channel chunks, NHWC bf16 rows that
+// can be stored 16 B at a time (or the fp32 NCHW store of conv_out)
+static bool halo_ok(const GemmArgs& g, int c_dt) {
+    if (g.conv_taps != 9 || !g.zero_page || g.gn_stats || g.a_packed_mb || (g.batch > 1)) return false;
+    if (g.Cin % 64 != 0 || g.ldb % 8 != 0 || g.K != 9 * g.Cin) return false;
+    if (g.H % HALO_TY != 0 || g.W % HALO_TX != 0 || g.M % (g.H * g.W) != 0) return false;
+    if (g.store == STORE_NCHW) return !g.resid && g.act == ACT_NONE;
+    return g.store == STORE_ROWS && g.rows_per_group == 0 && c_dt == DT_BF16 && g.ldc % 8 == 0;
 }
 
 static bool glds_ok(const GemmArgs& g) {
@@ -421,6 +662,17 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
     static const bool force128 = getenv("HQT_FORCE_TILE128") != nullptr;          // test hook: exercise the big-tile kernels on tiny shapes
     const bool narrow = g.N < 32 && g.M >= 4096 && glds_ok(g);       // conv_out (N = 3): one zero-padded 128-wide n-tile
     if (narrow || (g.N >= 128 && g.M >= 128 && (tiles128 >= 192 || force128))) {
+        const bool no_halo = getenv("HQT_NO_HALO") != nullptr;                // A/B switch (read per launch): generic implicit GEMM for the 3x3 convs too
+        if (!no_halo && halo_ok(g, c_dt)) {
+            const dim3 grid((g.N + 127) / 128, g.M / (HALO_TY * HALO_TX), 1);
+            if (g.store == STORE_NCHW) {
+                if (c_dt == DT_BF16) conv3x3_halo_kernel<bf16_t, true><<<grid, 256, HALO_LDS, st>>>(g);
+                else conv3x3_halo_kernel<float, true><<<grid, 256, HALO_LDS, st>>>(g);
+            } else {
+                conv3x3_halo_kernel<bf16_t, false><<<grid, 256, HALO_LDS, st>>>(g);
+            }
+            return hipGetLastError();
+        }
         if (glds_ok(g)) {
             const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
             static const int nstage = getenv("HQT_CONV_STAGES") ? atoi(getenv("HQT_CONV_STAGES")) : 2;   // A/B switch: the 4-slot ring (1 WG/CU) measured 1.5x slower than 2 buffers x 2 WGs/CU
@@ -452,5 +704,11 @@ hipError_t mfma_gemm_configure() {
     CFG(bf16_t, false, 2) CFG(bf16_t, false, 4) CFG(float, false, 2) CFG(float, false, 4)
     CFG(bf16_t, true, 2) CFG(bf16_t, true, 4) CFG(float, true, 2) CFG(float, true, 4)
 #undef CFG
+#define CFGH(TC, NCHW_)                                                                                             \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<TC, NCHW_>),                             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);                                      \
+    if (e != hipSuccess) return e;
+    CFGH(bf16_t, false) CFGH(bf16_t, true) CFGH(float, true)
+#undef CFGH
     return hipSuccess;
 }

@@ -239,6 +239,33 @@ def test_decode_fast_big_tile_kernels_vs_oracle():
     assert d.max() <= 0.1 and d.mean() <= 1e-2, (d.max(), d.mean())
 
 
+def test_decode_fast_halo_conv_matches_generic_implicit_gemm():
+    """The 3x3 'halo tile' conv kernel (input patch resident in LDS, chunk-major K order) against the generic LDS-DMA
+    implicit-GEMM kernel (HQT_NO_HALO=1) on the same bf16 inputs: they differ only in fp32 summation order (then bf16
+    rounding per layer), so they agree to about one bf16 ulp per pixel and are equally far from the fp32 oracle.  Covers upsampling convs, the
+    residual epilogue, image borders (zero page) and the NCHW conv_out store."""
+    import os
+    spec = Stage1Spec(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=64, z_channels=64,
+                      embed_dim=32, n_embed=256)
+    weights = synth.stage1_weights(spec, 41, 'fixture')
+    r = np.random.default_rng(42)
+    ct, cb = r.integers(0, 256, (5, 8, 8)), r.integers(0, 256, (5, 16, 16))
+    os.environ['HQT_FORCE_TILE128'] = '1'
+    try:
+        eng = engine_s1(spec, weights, 5)
+        halo = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
+        os.environ['HQT_NO_HALO'] = '1'
+        generic = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
+    finally:
+        os.environ.pop('HQT_NO_HALO', None)
+        del os.environ['HQT_FORCE_TILE128']
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    eh, eg = np.abs(halo - want), np.abs(generic - want)
+    assert eh.max() <= 0.1 and eh.mean() <= 1.25 * eg.mean() + 1e-3, (eh.max(), eh.mean(), eg.mean())
+    d = np.abs(halo - generic)                      # ~1 bf16 ulp of an O(1) pixel on average, no outliers (a wrong tap or border would be O(1))
+    assert d.max() <= 0.06 and d.mean() <= 8e-3, (d.max(), d.mean())
+
+
 def test_decode_batch_chunking_and_ragged():
     """More images than one decode chunk, decoded in one call, equal the per-image decodes."""
     fx = load('g5_decode_64.npz')
