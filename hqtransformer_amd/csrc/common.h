@@ -11,8 +11,12 @@ __device__ __host__ inline float bf16_to_f32(bf16_t v) {
     c.u = ((uint32_t)v) << 16;
     return c.f;
 }
-// round-to-nearest-even; NaN stays NaN
+// round-to-nearest-even; NaN stays NaN.  On the device this is gfx950's v_cvt_pk_bf16_f32 (same rounding; the
+// branchy software form cost more than the LDS traffic in the conv epilogues).
 __device__ __host__ inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+#endif
     union { uint32_t u; float f; } c;
     c.f = f;
     if ((c.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((c.u >> 16) | 0x40);

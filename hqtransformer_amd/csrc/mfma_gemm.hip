@@ -521,6 +521,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
         }
     };
 
+    float bv[8];                                        // epilogue bias of this thread's 8 channels, fetched under the main loop
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (g.bias && n0 + (tid & 15) * 8 + e < g.N) ? g.bias[n0 + (tid & 15) * 8 + e] : 0.0f;
     const int NC = g.Cin / 64, KT = NC * 9;
     issue_patch(0, 0);
     issue_b(0, 0);
@@ -572,6 +575,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
         return;
     }
     char* stage = lds_raw;                              // [128 pixels][HALO_CPITCH] fp32; every operand read is behind the last barrier
+    if (ABL == 6) { float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc; }
+    if (ABL != 6)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = wm * 64 + i * 32 + fr;
@@ -585,36 +597,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
             }
     }
     __syncthreads();
+    if (ABL == 7) return;
     {
         TC* Cb = reinterpret_cast<TC*>(g.C);
         const TC* Rb = reinterpret_cast<const TC*>(g.resid);
         const int c8 = (tid & 15) * 8;                  // 8 consecutive channels per thread, 16 threads per pixel row
         const int nn = n0 + c8;
-        float bv[8];
+        if (nn < g.N) {                                 // halo_ok(): N % 8 == 0, so a thread's 8 channels are all in or all out
+            long long moff[8];
+            u32x4 rr[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (g.bias && nn + e < g.N) ? g.bias[nn + e] : 0.0f;
+            for (int pass = 0; pass < 8; ++pass) {      // residual rows first: eight 16-B loads in flight, not one per pass
+                const int r = pass * 16 + (tid >> 4);
+                moff[pass] = (pix0 + (long long)(r >> 4) * g.W + (r & 15)) * g.ldc + nn;
+                if (Rb) rr[pass] = *reinterpret_cast<const u32x4*>(Rb + moff[pass]);
+            }
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 16 + (tid >> 4);
-            const long long m = pix0 + (long long)(r >> 4) * g.W + (r & 15);
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * HALO_CPITCH + c8 * 4);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * HALO_CPITCH + c8 * 4 + 16);
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int pass = 0; pass < 8; ++pass) {
+                const int r = pass * 16 + (tid >> 4);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * HALO_CPITCH + c8 * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * HALO_CPITCH + c8 * 4 + 16);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] * g.alpha + bv[e], g.act);
-            TC* dst = Cb + m * g.ldc + nn;
-            if (nn + 8 <= g.N) {
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];      // halo_ok(): no activation on this path
                 if (Rb) {
-                    const u32x4 rr = *reinterpret_cast<const u32x4*>(Rb + m * g.ldc + nn);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_to_f32((bf16_t)(rr[e] & 0xffffu)); v[2 * e + 1] += bf16_to_f32((bf16_t)(rr[e] >> 16)); }
+                    for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_to_f32((bf16_t)(rr[pass][e] & 0xffffu)); v[2 * e + 1] += bf16_to_f32((bf16_t)(rr[pass][e] >> 16)); }
                 }
                 const u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-                *reinterpret_cast<u32x4*>(dst) = o;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (nn + e < g.N) { float x = v[e]; if (Rb) x += ld1<TC>(Rb + m * g.ldc + nn + e); st1<TC>(dst + e, x); }
+                if (ABL != 5 || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(Cb + moff[pass]) = o;
             }
         }
     }
@@ -626,8 +637,9 @@ static bool halo_ok(const GemmArgs& g, int c_dt) {
     if (g.conv_taps != 9 || !g.zero_page || g.gn_stats || g.a_packed_mb || (g.batch > 1)) return false;
     if (g.Cin % 64 != 0 || g.ldb % 8 != 0 || g.K != 9 * g.Cin) return false;
     if (g.H % HALO_TY != 0 || g.W % HALO_TX != 0 || g.M % (g.H * g.W) != 0) return false;
-    if (g.store == STORE_NCHW) return !g.resid && g.act == ACT_NONE;
-    return g.store == STORE_ROWS && g.rows_per_group == 0 && c_dt == DT_BF16 && g.ldc % 8 == 0;
+    if (g.act != ACT_NONE) return false;               // swish lives in the GroupNorm pass; keeps the epilogue code small
+    if (g.store == STORE_NCHW) return !g.resid;
+    return g.store == STORE_ROWS && g.rows_per_group == 0 && c_dt == DT_BF16 && g.ldc % 8 == 0 && g.N % 8 == 0;
 }
 
 static bool glds_ok(const GemmArgs& g) {

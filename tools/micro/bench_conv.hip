@@ -58,8 +58,8 @@ int main(int argc, char** argv) {
         const float t0 = run<0>(g, st, reps), t1 = run<1>(g, st, reps), t2 = run<2>(g, st, reps), t3 = run<3>(g, st, reps), t4 = run<4>(g, st, reps);
         printf("%-28s %9.1f | %8.1f %8.1f | %8.1f %8.1f %8.1f %8.1f\n", s.name, fl * 1e-9, t0, fl / t0 * 1e-6, t1, t2, t3, t4);
         if (s.taps == 9) {
-            const float h0 = run_halo<0>(g, st, reps), h1 = run_halo<1>(g, st, reps), h2 = run_halo<2>(g, st, reps), h3 = run_halo<3>(g, st, reps);
-            printf("%-28s %9s | %8.1f %8.1f | %8.1f %8.1f %8.1f\n", "   halo tile", "", h0, fl / h0 * 1e-6, h1, h2, h3);
+            const float h0 = run_halo<0>(g, st, reps), h1 = run_halo<1>(g, st, reps), h2 = run_halo<2>(g, st, reps), h3 = run_halo<3>(g, st, reps), h5 = run_halo<5>(g, st, reps), h6 = run_halo<6>(g, st, reps), h7 = run_halo<7>(g, st, reps);
+            printf("%-28s %9s | %8.1f %8.1f | %8.1f %8.1f %8.1f   no-global-store %8.1f no-staging %8.1f staging-only %8.1f\n", "   halo tile", "", h0, fl / h0 * 1e-6, h1, h2, h3, h5, h6, h7);
             tot_halo += h0;
         } else tot_halo += t0;
         tot_us += t0; tot_fl += fl;
