@@ -120,6 +120,9 @@ struct GemmArgs {
     void* C2;
     void* C3;
     int qkv_D;
+    int qkv_first;           // STORE_QKV: part index of column 0 (1: the GEMM computes only [key; value], N = 2 D)
+    bf16_t* qkv_v_pk;        // STORE_QKV: optional second copy of the value part in the packed_off() layout (c_packed_mb):
+                             //   with a single key the attention output IS the value row (depth sub-step 0)
     int c_packed_mb;         // STORE_PACKED (and the q part of STORE_QKV stays row-major)
     const void* zero_page;   // >= 16 zero bytes in device memory (source of padded im2col taps for LDS-DMA loads)
     // ---- deferred LayerNorm on the A operand (FAST AR loop).  A holds bf16(x), not LN(x); with W' = gamma o W,

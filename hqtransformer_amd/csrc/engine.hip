@@ -611,8 +611,22 @@ static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, fl
     g.ln_parts = parts; g.ln_nparts = *nparts; g.ln_colsum = bw.qkv.colsum; g.ln_eps = 1e-5f;
     g.C = h->qbuf; g.C2 = kc; g.C3 = vc; g.ldc = D; g.qkv_D = D; g.store = STORE_QKV;
     g.rows_per_group = Tq; g.group_stride = Tcache; g.row_offset = t_base; g.row_offset_dev = t_base_dev;
-    CHK(run_linear(h, c.md, g, bw.qkv, DT_BF16, DT_BF16, c.st, "gemm_qkv"));
-    {
+    // One query over one key (depth sub-step 0: hierarchical_ar.py:690-702 with an empty cache): softmax of a single
+    // score is exactly 1, so the attention output is the value row itself.  The GEMM then skips the query third of
+    // the fused weight (rows [D, 3D) only), appends K/V to the cache for sub-step 1 and writes V straight into the
+    // projection's operand; no attention launch.
+    const bool single_key = Tq == 1 && t_base == 0 && !t_base_dev && !getenv("HQT_NO_SINGLE_KEY");
+    if (single_key) {
+        g.qkv_first = 1; g.qkv_v_pk = reinterpret_cast<bf16_t*>(h->abuf); g.c_packed_mb = pk;
+        Lin kv = bw.qkv;
+        kv.N = 2 * D;
+        kv.wpk_ln = bw.qkv.wpk_ln + (size_t)D * bw.qkv.K;          // packed n-tiles are contiguous: skip D rows
+        kv.bias_ln = bw.qkv.bias_ln + D;
+        kv.colsum = bw.qkv.colsum + D;
+        g.ln_colsum = kv.colsum;
+        CHK(run_linear(h, c.md, g, kv, DT_BF16, DT_BF16, c.st, "gemm_qkv"));
+    } else {
+        CHK(run_linear(h, c.md, g, bw.qkv, DT_BF16, DT_BF16, c.st, "gemm_qkv"));
         Timed t(h, "attention", c.st);
         AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, DT_BF16, pk};
         HIPCHK(launch_attention(a, c.st));

@@ -78,12 +78,12 @@ hipError_t launch_pack_stream_weights(const float* w32, bf16_t* packed, int N, i
 // This thread's share of the partial LayerNorm row statistics (thread = pg * ROWS + row): loads issued together
 // (clamped, never predicated), then summed in index order.
 template <int ROWS, int PGROUPS>
-__device__ inline void ln_partial_stats(const GemmArgs& g, float& ln_s, float& ln_q) {
+__device__ inline void ln_partial_stats(const GemmArgs& g, float& ln_s, float& ln_q, int first_part = 0) {
     const int row = threadIdx.x % ROWS, pg = threadIdx.x / ROWS;
     const int Mpad = g.a_packed_mb * 32, mrow = blockIdx.y * ROWS + row;
     const float2* base = reinterpret_cast<const float2*>(g.ln_parts) + mrow;
     constexpr int NPL = 4;
-    for (int p0 = pg; p0 < g.ln_nparts; p0 += NPL * PGROUPS) {
+    for (int p0 = first_part + pg; p0 < g.ln_nparts; p0 += NPL * PGROUPS) {
         float2 v[NPL];
 #pragma unroll
         for (int i = 0; i < NPL; ++i) v[i] = base[(size_t)min(p0 + i * PGROUPS, g.ln_nparts - 1) * Mpad];
@@ -97,8 +97,12 @@ __device__ inline void ln_partial_stats(const GemmArgs& g, float& ln_s, float& l
 // split that K range into contiguous runs.  gridDim = (N / (32 NT), MB_total / MBW, S).  With S > 1
 // (cross-workgroup split-K) the fp32 partial tile goes to slab z of `slabs` ([S][Mpad][N]) and the
 // epilogue runs in the consumer (LayerNorm combine); with S == 1 the fused epilogue runs here.
+// occupancy hint (waves per SIMD): 128 VGPRs let two 8-wave workgroups (or one 16-wave workgroup) share a CU
+constexpr int stream_min_waves(int MBW, int NT, int NW, int U) {
+    return (NW == 16 || (MBW * NT == 1 && NW == 8) || 16 * NT * MBW + 4 * U * (NT + MBW) + 40 <= 128) ? 4 : 1;
+}
 template <int MBW, int NT, int NW, int U, typename TC, int ABL = 0>   // ABL: ablation switches of tools/micro/bench_stream
-__global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
+__global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);                  // [NW][NT*32 n][MBW*32 m] as [NT][MBW][m32][n32]
     constexpr int TILE = NT * MBW * 1024;
@@ -108,6 +112,15 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
     float* lnstat = red + (size_t)NW * NT * MBW * 1024;               // [MBW*32][2] (sum, sumsq), then (mean, rstd)
     float ln_s = 0.0f, ln_q = 0.0f;
     constexpr int ROWS = MBW * 32, PGROUPS = NW * 64 / ROWS;          // threads per row
+    // Variants with registers to spare (MBW >= 2: one workgroup per CU anyway) fetch their share of the partial row
+    // statistics together with the first run's operands and hold it across the MFMA loop; the others fetch it after
+    // the loop, when the operand registers are dead.  Unconditional loads (a valid dummy row when there is no LayerNorm).
+    constexpr bool EARLY_STATS = MBW >= 2 && U >= 12;
+    constexpr int NPE = 6;
+    float2 sv[NPE];
+    bool sv_loaded = false;
+    const float2* sbase = reinterpret_cast<const float2*>(g.ln_parts ? (const void*)g.ln_parts : g.A) + (blockIdx.y * ROWS + threadIdx.x % ROWS);
+    const int snp = g.ln_parts ? g.ln_nparts : 1;
     const int ntile0 = blockIdx.x * NT;
     const int mb0 = blockIdx.y * MBW;
     const int MB = g.a_packed_mb;
@@ -149,6 +162,11 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) xbuf[u][mb] = xp[((size_t)(ABL == 1 ? 0 : ks + u) * MB + mb) * 64];
+        if (EARLY_STATS && first) {
+            sv_loaded = true;
+#pragma unroll
+            for (int i = 0; i < NPE; ++i) sv[i] = sbase[(size_t)min((int)(threadIdx.x / ROWS) + i * PGROUPS, snp - 1) * (g.a_packed_mb * 32)];
+        }
         first = false;
         // keep every load of the run in flight before the first MFMA: without this fence the
         // scheduler re-rolls the block into 2-4 loads per wait to save VGPRs (12+ serial round trips)
@@ -191,7 +209,16 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
     }
     if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); stamp[3] = clock64(); __builtin_amdgcn_sched_barrier(0); }
     // deferred LayerNorm: partial row statistics, loaded while the operand registers are dead and the accumulators drain
-    if (g.ln_parts) ln_partial_stats<ROWS, PGROUPS>(g, ln_s, ln_q);
+    if (g.ln_parts) {
+        if (EARLY_STATS && sv_loaded) {
+#pragma unroll
+            for (int i = 0; i < NPE; ++i)
+                if ((int)(threadIdx.x / ROWS) + i * PGROUPS < g.ln_nparts) { ln_s += sv[i].x; ln_q += sv[i].y; }
+            ln_partial_stats<ROWS, PGROUPS>(g, ln_s, ln_q, NPE * PGROUPS);
+        } else {
+            ln_partial_stats<ROWS, PGROUPS>(g, ln_s, ln_q);
+        }
+    }
     // ---- cross-wave reduction through LDS; C/D map: col = lane & 31 -> m, row = (r&3) + 8 (r>>2) + 4 (lane>>5) -> n
     {
         float* my = red + (size_t)wave * TILE;
@@ -229,6 +256,12 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
         if (threadIdx.x == 0) reinterpret_cast<float*>(g.C)[blockIdx.x] = red[0] + red[TILE];
         return;
     }
+    // STORE_QKV destination of this workgroup's 32 columns
+    const int qkv_part_local = g.store == STORE_QKV ? (ntile0 * 32) / max(g.qkv_D, 1) : 0;
+    const int qkv_part = qkv_part_local + g.qkv_first;
+    TC* const qkv_base = reinterpret_cast<TC*>(qkv_part == 0 ? g.C : (qkv_part == 1 ? g.C2 : g.C3));
+    bf16_t* const qkv_vcopy = (g.store == STORE_QKV && qkv_part == 2) ? g.qkv_v_pk : nullptr;
+    const int qkv_row_dev = (g.store == STORE_QKV && g.row_offset_dev) ? *g.row_offset_dev : 0;
     for (int o = threadIdx.x; o < TILE; o += NW * 64) {
         const int n = o & 31, ml = (o >> 5) & 31, blk = o >> 10;
         const int mb = blk % MBW, t = blk / MBW;
@@ -259,8 +292,22 @@ __global__ __launch_bounds__(NW * 64, (MBW * NT == 1 && NW == 8) ? 4 : 1) void s
             continue;
         }
         if (m >= g.M) continue;
-        if (S > 1 && ABL != 9) slabs[((size_t)blockIdx.z * (MB * 32) + m) * g.N + ncol] = s;
-        else gemm_store<TC>(g, 0, m, ncol, s);
+        if (S > 1 && ABL != 9) { slabs[((size_t)blockIdx.z * (MB * 32) + m) * g.N + ncol] = s; continue; }
+        if (g.store == STORE_QKV && NT == 1) {
+            // fused [query; key; value]: D % 32 == 0, so the part is uniform per workgroup; destination picked once
+            // (a per-element select between C / C2 / C3 inside gemm_store was miscompiled by hipcc -O3 whenever a
+            // second bf16 store followed it: stores silently went missing)
+            const float v = s * g.alpha + (g.bias ? g.bias[ncol] : 0.0f);
+            const int nn = ncol - qkv_part_local * g.qkv_D;
+            long long row = m;
+            if (qkv_part > 0) {
+                row = (m / g.rows_per_group) * g.group_stride + m % g.rows_per_group + g.row_offset + qkv_row_dev;
+            }
+            st1<TC>(qkv_base + row * g.ldc + nn, v);
+            if (qkv_vcopy) qkv_vcopy[packed_off(m, nn, g.c_packed_mb)] = f32_to_bf16(v);
+            continue;
+        }
+        gemm_store<TC>(g, 0, m, ncol, s);
     }
     chain_signal(g.chain);
     if (ABL == 9) {
@@ -323,7 +370,7 @@ static hipError_t launch_stream_t(const GemmArgs& g, const bf16_t* wpk, int S, f
 // kernels, so the decomposition maximises the number of busy CUs; narrow-N GEMMs split K across
 // workgroups (S > 1) and leave the fp32 partial slabs to the next LayerNorm.
 #define STREAM_CASES(X, TC) \
-    X(1, 1, 8, 12, TC) X(2, 1, 8, 12, TC)
+    X(1, 1, 8, 12, TC) X(2, 1, 8, 12, TC) X(2, 1, 8, 6, TC)
 int stream_gemm_splitk(const GemmArgs& g) {
     const int KS = g.K / 16;
     const int wgs = (g.N / 32) * g.a_packed_mb;            // with MBW = 1
@@ -336,6 +383,10 @@ template <typename TC>
 static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
     const int wgs2 = (g.N / 32) * (g.a_packed_mb / 2);
     if (S == 1 && g.a_packed_mb == 2 && wgs2 >= 128) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);
+    if (S == 1 && g.a_packed_mb >= 4) {                 // M = 128..256 (depth sub-step 1): 64-row activation tiles halve the weight re-reads
+        if (g.N >= 3072) return launch_stream_t<2, 1, 8, 6, TC>(g, wpk, 1, nullptr, st);      // qkv / fc1 / heads: 18-20 us vs 20-25 us
+        return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);                        // proj / fc2: 8.7 / 20 us vs 9.3 / 25 us
+    }
     return launch_stream_t<1, 1, 8, 12, TC>(g, wpk, S, slabs, st);
 }
 hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, int S, float* slabs, hipStream_t st) {

@@ -102,7 +102,7 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int bz, int m, int
         if (g.row_offset_dev) orow += *g.row_offset_dev;
     }
     if (g.store == STORE_QKV) {
-        const int which = n / g.qkv_D, nn = n - which * g.qkv_D;
+        const int part = n / g.qkv_D, nn = n - part * g.qkv_D, which = part + g.qkv_first;
         if (which == 0) st1<TC>(reinterpret_cast<TC*>(g.C) + (long long)m * g.ldc + nn, v);
         else st1<TC>(reinterpret_cast<TC*>(which == 1 ? g.C2 : g.C3) + (long long)orow * g.ldc + nn, v);
         return;

@@ -177,6 +177,24 @@ def test_fast_precision_teacher_forced(tiny_cls):
         assert agree >= 0.9, f'code agreement {agree}'
 
 
+def test_fast_single_key_shortcut_is_bit_identical(tiny_cls):
+    """Depth sub-step 0 attends to exactly one key, so its attention output is the value row: the FAST path skips the
+    query third of the fused GEMM and the attention launch.  softmax of one score is exactly 1.0, hence logits and
+    codes must be BIT-identical to the long way round (HQT_NO_SINGLE_KEY=1)."""
+    import os
+    fx, spec, weights, eng = tiny_cls
+    B, n = int(fx['B']), 8
+    noise = torch.from_numpy(synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:n])
+    a = eng.sample(B, torch.full((B,), 3), n, precision=PRECISION_FAST, noise=noise, return_logits=True, use_graph=False)
+    os.environ['HQT_NO_SINGLE_KEY'] = '1'
+    try:
+        b = eng.sample(B, torch.full((B,), 3), n, precision=PRECISION_FAST, noise=noise, return_logits=True, use_graph=False)
+    finally:
+        del os.environ['HQT_NO_SINGLE_KEY']
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[2], b[2])
+
+
 # ----------------------------------------------------------------------------------------- stage 1
 def test_decode_64_exact_vs_reference_fixture():
     fx = load('g5_decode_64.npz')

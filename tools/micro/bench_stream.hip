@@ -11,7 +11,7 @@ template <int MBW, int NT, int NW, int U, int ABL = 0>
 static float run(const Shape& sh, int M, int S, const std::vector<bf16_t*>& wbufs, bf16_t* x, float* y, float* slabs, hipStream_t st) {
     const int MB = packed_mb(M);
     if (MB % MBW != 0 || sh.N % (32 * NT) != 0) return -1.f;
-    const size_t smem = (size_t)NW * NT * MBW * 4096;
+    const size_t smem = (size_t)NW * NT * MBW * 4096 + (size_t)MBW * 256 + (size_t)NW * 512;
     if (smem > 160 * 1024) return -1.f;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, float, ABL>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -78,10 +78,8 @@ int main() {
         for (int M : {64, 256}) {
             printf("== %s N=%d K=%d M=%d  (%.1f MB weights; HBM floor %.2f us @6.3TB/s)\n", sh.name, sh.N, sh.K, M, bytes / 1e6, bytes / 6.3e6);
 #define V(MBW, NT, NW, U, S) { float t = run<MBW, NT, NW, U>(sh, M, S, w, x, y, slabs, st); if (t > 0) printf("   MBW=%d NT=%d NW=%d U=%2d S=%d : %7.2f us  (%.2f TB/s)\n", MBW, NT, NW, U, S, t, bytes / t / 1e6); }
-            V(2, 1, 8, 12, 1) V(2, 1, 8, 6, 1) V(1, 1, 8, 12, 1) V(1, 2, 8, 6, 1) V(2, 2, 4, 6, 1) V(2, 2, 8, 6, 1) V(4, 1, 4, 6, 1) V(4, 2, 4, 3, 1) V(2, 1, 8, 12, 2) V(2, 1, 8, 12, 4) V(1, 1, 8, 12, 2) V(1, 1, 8, 12, 4)
-#define A(ABL) { float t = run<2, 1, 8, 12, ABL>(sh, M, 1, w, x, y, slabs, st); printf("   ablation %d (1: one X chunk, 2: one W chunk, 3: no epilogue): %7.2f us\n", ABL, t); }
-            A(1) A(2) A(3)
-            if (M == 64) { stamps<2, 1, 8, 12>(sh, M, 1, w[0], x, y, slabs, st); stamps<1, 1, 8, 12>(sh, M, 1, w[1], x, y, slabs, st); stamps<2, 2, 4, 6>(sh, M, 4, w[2], x, y, slabs, st); }
+            if (M == 64) { V(2, 1, 8, 12, 1) V(1, 1, 8, 12, 1) V(1, 1, 16, 12, 1) V(1, 1, 16, 6, 1) V(2, 1, 16, 6, 1) V(2, 1, 16, 4, 1) V(1, 1, 8, 6, 1) V(2, 1, 8, 4, 1) }
+            else { V(1, 1, 8, 12, 1) V(2, 1, 8, 12, 1) V(2, 1, 8, 4, 1) V(2, 1, 8, 6, 1) V(2, 1, 16, 4, 1) V(4, 1, 8, 3, 1) V(4, 1, 8, 4, 1) V(4, 1, 4, 4, 1) V(4, 1, 16, 2, 1) V(2, 2, 8, 4, 1) }
         }
         for (auto& p : w) CK(hipFree(p));
     }
