@@ -43,8 +43,8 @@ F32_PEAK_TFLOPS = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=5)
-    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--steps', type=int, default=12)
+    p.add_argument('--warmup', type=int, default=3)
     p.add_argument('--config', default=os.path.join(ROOT, 'configs', 'imagenet-12l.yaml'))
     p.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     p.add_argument('--precision', choices=['fast', 'exact'], default='fast')
@@ -52,6 +52,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-graph', action='store_true')
+    p.add_argument('--inflight', type=int, default=3, help='batches in flight per GPU: consecutive steps are round-robined over this many '
+                   'lanes (own HIP stream, KV cache and activations; shared weights).  1 = the serial order of the reference harness')
     p.add_argument('--overlap', action='store_true', help='EXPERIMENT: run the decode of batch k on a second stream underneath the AR '
                    'loop of batch k+1 (measured slower on MI355X: the decoder starves the latency-bound AR kernels)')
     p.add_argument('--positions', type=int, default=0, help='DEBUG ONLY (counter collection): sample this many top positions '
@@ -131,11 +133,11 @@ def main():
     if dist is not None and args.gather == 'pixels' and rank == 0:
         gathered = [torch.empty((B, s1.out_ch, H, H), dtype=torch.float32, device=dev) for _ in range(world)]
 
-    def decode(ct, cb):
+    def decode(ct, cb, m=None):
         if n_pos < n_full:      # debug runs: pad the code grids so the decoder still sees full-size inputs
             ct = torch.cat([ct, ct.new_zeros(B, n_full - n_pos)], 1)
             cb = torch.cat([cb, cb.new_zeros(B, n_full - n_pos, 4)], 1)
-        return model.stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
+        return (m or model).stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
 
     def step(i, graph=True):
         ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), top_k_top=None, top_p_top=None,
@@ -165,11 +167,42 @@ def main():
     lo_prio, hi_prio = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, -1)
     s_ar = torch.cuda.Stream(device=dev, priority=hi_prio) if overlap else torch.cuda.current_stream(dev)
     s_dec = torch.cuda.Stream(device=dev, priority=lo_prio) if overlap else s_ar
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
+    # ---- the timed region: K steps, round-robined over `inflight` lanes (hqtransformer_amd/pipeline.py).  Every step is
+    #      one complete batch-B pass (64-position AR loop + decode + clamp [+ gather]); lanes only change the schedule.
+    from hqtransformer_amd.pipeline import InflightSampler
+    inflight = max(1, args.inflight)
+    pipe = InflightSampler(model, lanes=inflight, device=dev)
+
+    def after(ct, cb, px):
+        if dist is not None and args.gather == 'pixels':
+            dist.gather(px, gathered, dst=0)
+        elif dist is not None and args.gather == 'codes':
+            dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+
+    for li in range(max(inflight, args.warmup)):                        # every lane at least once: workspace, graph capture
+        pipe.submit(B, int(classes[li % len(classes)]), seed=1000 + li, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
+                    use_graph=not args.no_graph, after=after)
+    pipe.drain()
+    barrier()
+    t0 = time.perf_counter()
+    kept = [pipe.submit(B, int(classes[args.warmup + k]), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
+                        sample_offset=rank * B, use_graph=not args.no_graph, after=after) for k in range(args.steps)]
+    pipe.drain()
+    barrier()
+    elapsed_lanes = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed_lanes], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_lanes = float(t.item())
+    del kept
+
+    # ---- reference pass: the same steps one at a time on one lane (the reference harness's order), with per-phase events
+    n_serial = args.steps if inflight == 1 else min(args.steps, 3)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n_serial)]
     keep = []
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(n_serial):
         i = args.warmup + k
         with torch.cuda.stream(s_ar):
             ev[3 * k].record()
@@ -188,12 +221,15 @@ def main():
         keep.append((ct, cb, px))
     barrier()
     elapsed = time.perf_counter() - t0
-    ar_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(args.steps)) / args.steps
-    dec_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(args.steps)) / args.steps
+    ar_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(n_serial)) / n_serial
+    dec_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(n_serial)) / n_serial
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    serial_value = world * B * n_serial / elapsed
+    serial_ms = 1000 * elapsed / n_serial
+    elapsed = elapsed_lanes
 
     out = None
     if rank == 0:
@@ -209,8 +245,11 @@ def main():
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
                        'precision': 'FAST: bf16 weights+MFMA, fp32 accumulate' if fast else 'EXACT: fp32',
                        'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph,
-                       'pipeline': 'decode(k) overlaps AR(k+1) on a second stream' if overlap else 'serial'},
-            'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
+                       'pipeline': (f'{inflight} steps in flight per GPU (round-robin over {inflight} lanes: own HIP stream, KV cache and '
+                                    f'activations, shared weights); each step is one full batch-{B} pass') if inflight > 1 else 'serial'},
+            'serial': {'value': round(serial_value, 2), 'ms_per_step': round(serial_ms, 3), 'steps': n_serial,
+                       'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
+                       'note': 'the same steps one at a time on one lane (the reference harness order)'},
         }
         if n_pos < n_full:
             out['INVALID'] = f'debug run: {n_pos} of {n_full} top positions sampled'
@@ -249,7 +288,9 @@ def main():
                         'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                         'traffic': pmc_traffic('stream_gemm'), 'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3),
                         'total_ms': round(gemm_ms, 3), 'algorithmic_bytes_per_launch': round(wbytes / n_l),
-                        'eager_to_graph_scale': round(ar_scale, 4)})
+                        'eager_to_graph_scale': round(ar_scale, 4),
+                        'note': 'per-launch figure from the one-lane pass; with several lanes launches overlap',
+                        'timed_region_weight_stream_GBps': round(wbytes * args.steps / elapsed_lanes / 1e9, 1)})
         if conv_ms > 0:
             n_l = sum(v[0] for v in conv.values())
             ach = cflops / (conv_ms * 1e-3) / 1e12

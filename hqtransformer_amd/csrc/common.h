@@ -145,9 +145,11 @@ struct GemmArgs {
     ChainSync chain;
 };
 
-struct StepState {           // lives in device memory; lets one captured graph serve every position
+struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call
     int step;                // current top position (0-based)
     int t_base;              // KV rows already in the body cache
+    unsigned long long seed; // Philox key of this hqt_sample call
+    long long sample_offset; // global index of row 0 of this call
 };
 
 #define HQT_MAX_V 16384

@@ -97,6 +97,7 @@ struct hqt_handle {
     size_t splitk_elems = 0;
     struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
     StepState* state = nullptr;
+    int64_t *cond_buf = nullptr, *codes_top = nullptr, *codes_bot = nullptr;   // call-independent homes of cond / the drawn codes
     // ---- stage 1
     std::vector<DecLayer> dec;
     Lin post_quant;
@@ -110,6 +111,9 @@ struct hqt_handle {
     // ---- graph cache
     hipGraphExec_t graph_exec = nullptr;
     std::vector<uint64_t> graph_key;
+    // ---- lanes: a clone shares every weight buffer of its parent (non-owning) and owns only its workspace
+    hqt_handle* parent = nullptr;
+    int n_clones = 0;
     // ---- timing
     bool timing = false;
     std::vector<TimingSlot> slots;
@@ -212,6 +216,8 @@ static void build_decoder_plan(hqt_handle* h) {
 extern "C" int hqt_abi_version(void) { return HQT_ABI_VERSION; }
 extern "C" const char* hqt_last_error(void) { return g_err.c_str(); }
 
+static int alloc_workspace(hqt_handle* hp);
+
 extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
     if (!cfg || !out) return fail(HQT_ERR_INVALID, "null argument");
     if (cfg->abi_version != HQT_ABI_VERSION) return fail(HQT_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, HQT_ABI_VERSION);
@@ -221,7 +227,6 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
     h->cfg = *cfg;
     h->device = device;
     const hqt_config& c = h->cfg;
-    const size_t B = (size_t)c.max_batch;
     if (c.has_stage2) {
         if (c.embed_dim % c.n_heads || c.embed_dim % 16) return fail(HQT_ERR_INVALID, "embed_dim must be a multiple of n_heads and 16");
         const int hs = c.embed_dim / c.n_heads;
@@ -230,6 +235,24 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         if (c.vocab_top > HQT_MAX_V || c.vocab_top % 4) return fail(HQT_ERR_INVALID, "vocab size %d unsupported", c.vocab_top);
         if (c.cond_type == HQT_COND_CLASS && c.n_classes < 1) return fail(HQT_ERR_INVALID, "n_classes");
         if (c.max_steps < 1 || c.max_steps > c.ctx_len_img) return fail(HQT_ERR_INVALID, "max_steps must be in [1, ctx_len_img]");
+    }
+    if (c.has_stage1) {
+        if (c.s1_n_mult < 1 || c.s1_n_mult > 8) return fail(HQT_ERR_INVALID, "s1_n_mult");
+        if (c.s1_ch % 32) return fail(HQT_ERR_INVALID, "GroupNorm(32) needs ch %% 32 == 0");
+        if (c.s1_z_channels % 16 || (2 * c.s1_embed_dim) % 16) return fail(HQT_ERR_INVALID, "z_channels and 2*embed_dim must be multiples of 16");
+        build_decoder_plan(h.get());
+    }
+    CHK(alloc_workspace(h.get()));
+    *out = h.release();
+    return HQT_OK;
+}
+
+// Everything a lane owns: activations, KV caches, step state, decoder buffers (the weights live in `w` / the Lin structs).
+static int alloc_workspace(hqt_handle* hp) {
+    struct { hqt_handle* p; hqt_handle* get() const { return p; } hqt_handle* operator->() const { return p; } } h{hp};
+    const hqt_config& c = h->cfg;
+    const size_t B = (size_t)c.max_batch;
+    if (c.has_stage2) {
         const size_t D = c.embed_dim;
         const int Tp = c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1;    // rows of the widest body pass
         h->Tmax = (c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 0) + c.max_steps;
@@ -250,16 +273,15 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         h->splitk_elems = (size_t)16 * rows * (size_t)std::max<size_t>(4 * D, (size_t)c.vocab_top);
         CHK(dev_alloc(h.get(), (void**)&h->splitk, h->splitk_elems * 4, true));
         CHK(dev_alloc(h.get(), (void**)&h->state, sizeof(StepState), true));
+        CHK(dev_alloc(h.get(), (void**)&h->cond_buf, B * (size_t)std::max(1, c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1) * 8, true));
+        CHK(dev_alloc(h.get(), (void**)&h->codes_top, B * (size_t)c.max_steps * 8, true));
+        CHK(dev_alloc(h.get(), (void**)&h->codes_bot, B * (size_t)c.max_steps * 4 * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->xpk, rows * D * 2, true));
         CHK(dev_alloc(h.get(), (void**)&h->xdpk, rows * D * 2, true));
         CHK(dev_alloc(h.get(), (void**)&h->parts, (D / 32 + 1) * rows * 2 * 4, true));
         CHK(dev_alloc(h.get(), (void**)&h->partsd, (D / 32 + 1) * rows * 2 * 4, true));
     }
     if (c.has_stage1) {
-        if (c.s1_n_mult < 1 || c.s1_n_mult > 8) return fail(HQT_ERR_INVALID, "s1_n_mult");
-        if (c.s1_ch % 32) return fail(HQT_ERR_INVALID, "GroupNorm(32) needs ch %% 32 == 0");
-        if (c.s1_z_channels % 16 || (2 * c.s1_embed_dim) % 16) return fail(HQT_ERR_INVALID, "z_channels and 2*embed_dim must be multiples of 16");
-        build_decoder_plan(h.get());
         size_t per_img = 0;
         for (auto& l : h->dec) {
             const size_t in_e = (size_t)l.res * l.res * l.cin;
@@ -294,17 +316,47 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         CHK(dev_alloc(h.get(), &h->quant, hw * 2 * c.s1_embed_dim * h->dec_chunk * 4, true));
         CHK(dev_alloc(h.get(), (void**)&h->gn, (size_t)h->dec_chunk * 32 * 2 * 2 * 4, true));
     }
+    return HQT_OK;
+}
+
+// A second lane over the same weights: several batches in flight on one GPU, one lane + stream each (the AR loop is a
+// chain of small latency-bound kernels that leaves most CUs idle; independent chains interleave).  The clone shares
+// every weight buffer and derived layout of `src` (which must be finalized and outlive it) and owns a fresh workspace.
+extern "C" int hqt_clone(hqt_handle* src, hqt_handle** out) {
+    if (!src || !out) return fail(HQT_ERR_INVALID, "null argument");
+    if (!src->finalized) return fail(HQT_ERR_STATE, "hqt_clone needs a finalized handle");
+    HIPCHK(hipSetDevice(src->device));
+    hqt_handle* root = src->parent ? src->parent : src;
+    std::unique_ptr<hqt_handle> h(new hqt_handle(*root));       // weights map, Lin structs and decoder plan by value: same device pointers
+    h->owned.clear();
+    h->workspace_bytes = 0;
+    h->parent = root;
+    h->n_clones = 0;
+    h->graph_exec = nullptr;
+    h->graph_key.clear();
+    h->timing = false;
+    h->slots.clear();
+    h->chain_ev = nullptr;
+    h->chain_valid = false;
+    h->all_events.clear();
+    h->pend = {nullptr, 0, 0, nullptr};
+    h->nparts = h->npartsd = 0;
+    const int rc = alloc_workspace(h.get());
+    if (rc != HQT_OK) { for (void* p : h->owned) hipFree(p); return rc; }
+    root->n_clones++;
     *out = h.release();
     return HQT_OK;
 }
 
 extern "C" int hqt_destroy(hqt_handle* h) {
     if (!h) return HQT_OK;
+    if (h->n_clones > 0) return fail(HQT_ERR_STATE, "%d clone(s) of this handle are still alive", h->n_clones);
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     timing_collect(h);
-    for (void* p : h->owned) hipFree(p);
+    for (void* p : h->owned) hipFree(p);             // a clone owns only its workspace
+    if (h->parent) h->parent->n_clones--;
     delete h;
     return HQT_OK;
 }
@@ -696,8 +748,8 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     CHK(run_linear(h, c.md, g, h->head_top, adt, DT_F32, c.st, "gemm_head"));
     {
         Timed t(h, "sampler", c.st);
-        SamplerArgs s{h->logits, B, V, 1, B, c.o.temperature_top, c.o.top_k_top, c.o.top_p_top, c.noise, 0, c.o.seed,
-                      c.o.sample_offset, h->state, c.o.n_steps, c.out_top, c.logits_out};
+        SamplerArgs s{h->logits, B, V, 1, B, c.o.temperature_top, c.o.top_k_top, c.o.top_p_top, c.noise, 0,
+                      h->state, c.o.n_steps, c.out_top, c.logits_out};
         HIPCHK(launch_sampler(s, c.st));
     }
     // ---- depth sub-step 1: four bottom codes in one pass
@@ -724,8 +776,8 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     CHK(run_linear(h, c.md, g, h->head_bot, adt, DT_F32, c.st, "gemm_head"));
     {
         Timed t(h, "sampler", c.st);
-        SamplerArgs s{h->logits, 4 * B, V, 4, B, c.o.temperature_bot, c.o.top_k_bot, c.o.top_p_bot, c.noise, 1, c.o.seed,
-                      c.o.sample_offset, h->state, c.o.n_steps, c.out_bot, c.logits_out};
+        SamplerArgs s{h->logits, 4 * B, V, 4, B, c.o.temperature_bot, c.o.top_k_bot, c.o.top_p_bot, c.noise, 1,
+                      h->state, c.o.n_steps, c.out_bot, c.logits_out};
         HIPCHK(launch_sampler(s, c.st));
     }
     return HQT_OK;
@@ -748,6 +800,8 @@ static int run_decode_step(hqt_handle* h, const SampleCtx& c) {      // one KV-c
     return HQT_OK;
 }
 
+static int sample_run(hqt_handle* h, const SampleCtx& c);
+
 extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_sample_opts* opts, const float* noise,
                           const int64_t* force_top, const int64_t* force_bot, float* logits_out, int64_t* out_top,
                           int64_t* out_bot, void* stream) {
@@ -761,16 +815,33 @@ extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_s
     if (!(opts->temperature_top > 0.f) || !(opts->temperature_bot > 0.f)) return fail(HQT_ERR_INVALID, "temperatures must be > 0");
     if ((opts->top_p_top > 0.f || opts->top_p_bot > 0.f) && cf.vocab_top > 8192) return fail(HQT_ERR_INVALID, "top-p needs vocab <= 8192");
     HIPCHK(hipSetDevice(h->device));
+    // The launch sequence reads cond and writes the drawn codes in buffers owned by the handle, and takes the Philox seed
+    // and the global row offset from device memory: nothing that changes from call to call is baked into the captured
+    // graph, so a steady stream of batches replays ONE graph (no re-capture, no exec destroyed under pending launches).
     SampleCtx c;
-    c.B = B; c.cond = cond; c.o = *opts; c.noise = noise;
-    c.feed_top = force_top ? force_top : out_top;
-    c.feed_bot = force_bot ? force_bot : out_bot;
-    c.logits_out = logits_out; c.out_top = out_top; c.out_bot = out_bot;
+    c.B = B; c.cond = cond ? h->cond_buf : nullptr; c.o = *opts; c.noise = noise;
+    c.feed_top = force_top ? force_top : h->codes_top;
+    c.feed_bot = force_bot ? force_bot : h->codes_bot;
+    c.logits_out = logits_out; c.out_top = h->codes_top; c.out_bot = h->codes_bot;
     c.st = (hipStream_t)stream;
     c.md.fast = opts->precision == HQT_PRECISION_FAST;
+    if (cond) HIPCHK(hipMemcpyAsync(h->cond_buf, cond, (size_t)B * (cf.cond_type == HQT_COND_TEXT ? cf.ctx_len_txt : 1) * 8, hipMemcpyDefault, c.st));
+    const int rc_run = sample_run(h, c);
+    if (rc_run != HQT_OK) return rc_run;
+    HIPCHK(hipMemcpyAsync(out_top, h->codes_top, (size_t)B * opts->n_steps * 8, hipMemcpyDeviceToDevice, c.st));
+    HIPCHK(hipMemcpyAsync(out_bot, h->codes_bot, (size_t)B * opts->n_steps * 4 * 8, hipMemcpyDeviceToDevice, c.st));
+    return HQT_OK;
+}
 
+static int sample_run(hqt_handle* h, const SampleCtx& c) {
+    const hqt_config& cf = h->cfg;
+    const hqt_sample_opts* opts = &c.o;
+    const int B = c.B;
+    const int64_t* cond = c.cond;
+    const float* noise = c.noise;
+    float* logits_out = c.logits_out;
     HIPCHK(sampler_configure(cf.vocab_top, opts->top_p_top > 0.f || opts->top_p_bot > 0.f));
-    HIPCHK(launch_set_step(h->state, 0, 0, c.st));
+    HIPCHK(launch_set_step(h->state, 0, 0, opts->seed, opts->sample_offset, c.st));
     int first = 0;
     if (cf.cond_type == HQT_COND_TEXT) {     // 64-token causal prefill (sampling.py:187-190, layers.py:107-111)
         const int T = cf.ctx_len_txt;
@@ -782,16 +853,19 @@ extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_s
     const int remaining = opts->n_steps - first;
     if (remaining <= 0) return HQT_OK;
     if (opts->use_graph && !h->timing) {
-        std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)cond, (uint64_t)noise, (uint64_t)c.feed_top, (uint64_t)c.feed_bot,
-                                     (uint64_t)logits_out, (uint64_t)out_top, (uint64_t)out_bot, (uint64_t)opts->precision,
-                                     (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot, opts->seed,
-                                     (uint64_t)opts->sample_offset};
+        std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)(cond != nullptr), (uint64_t)noise, (uint64_t)c.feed_top, (uint64_t)c.feed_bot,
+                                     (uint64_t)logits_out, (uint64_t)opts->precision,
+                                     (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot};
         uint32_t f[4];
         memcpy(f, &opts->top_p_top, 4); memcpy(f + 1, &opts->top_p_bot, 4);
         memcpy(f + 2, &opts->temperature_top, 4); memcpy(f + 3, &opts->temperature_bot, 4);
         for (int i = 0; i < 4; ++i) key.push_back(f[i]);
         if (!h->graph_exec || key != h->graph_key) {
-            if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            if (h->graph_exec) {                         // rare (options or test-only buffers changed): drain before destroying
+                HIPCHK(hipStreamSynchronize(c.st));
+                hipGraphExecDestroy(h->graph_exec);
+                h->graph_exec = nullptr;
+            }
             hipStream_t cs;
             HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             SampleCtx cc = c;

@@ -81,9 +81,7 @@ struct SamplerArgs {
     float top_p;                 // <= 0: none
     const float* noise;          // [n_steps, 5, B, V] or NULL
     int draw0;                   // first draw index of slot 0 (0 for top, 1 for bottom)
-    uint64_t seed;
-    int64_t sample_offset;
-    const StepState* state;
+    const StepState* state;      // step, Philox seed and global row offset of the current call
     int n_steps;
     int64_t* out;                // top: [B, n_steps]; bottom: [B, n_steps, 4]
     float* logits_out;           // optional [n_steps, 5, B, V]
@@ -93,7 +91,7 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
 hipError_t sampler_configure(int V, bool use_top_p);
 
 hipError_t launch_advance_step(StepState* state, int d_tbase, hipStream_t st);
-hipError_t launch_set_step(StepState* state, int step, int t_base, hipStream_t st);
+hipError_t launch_set_step(StepState* state, int step, int t_base, uint64_t seed, int64_t sample_offset, hipStream_t st);
 
 // int64 codes [B, n_steps(,4)] written by the sampler are final; this copies forced codes into the
 // feed-back arrays when teacher forcing is on.

@@ -47,13 +47,15 @@ __device__ __forceinline__ void emit_packed_row(const float* x, int m, int D, bf
 // step state
 // ---------------------------------------------------------------------------------------------
 __global__ void advance_step_kernel(StepState* s, int d_tbase) { s->step += 1; s->t_base += d_tbase; }
-__global__ void set_step_kernel(StepState* s, int step, int t_base) { s->step = step; s->t_base = t_base; }
+__global__ void set_step_kernel(StepState* s, int step, int t_base, unsigned long long seed, long long sample_offset) {
+    s->step = step; s->t_base = t_base; s->seed = seed; s->sample_offset = sample_offset;
+}
 hipError_t launch_advance_step(StepState* s, int d_tbase, hipStream_t st) {
     advance_step_kernel<<<1, 1, 0, st>>>(s, d_tbase);
     return hipGetLastError();
 }
-hipError_t launch_set_step(StepState* s, int step, int t_base, hipStream_t st) {
-    set_step_kernel<<<1, 1, 0, st>>>(s, step, t_base);
+hipError_t launch_set_step(StepState* s, int step, int t_base, uint64_t seed, int64_t sample_offset, hipStream_t st) {
+    set_step_kernel<<<1, 1, 0, st>>>(s, step, t_base, (unsigned long long)seed, (long long)sample_offset);
     return hipGetLastError();
 }
 
@@ -532,8 +534,9 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
     // ---- draw: argmax_i p_i / q_i, lowest index on ties
     float best = -1.0f;
     int besti = 0;
-    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-    const uint64_t grow = (uint64_t)(a.sample_offset + b);
+    const uint64_t seed = a.state->seed;                 // per-call values live in device memory: the captured graph is call-independent
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint64_t grow = (uint64_t)(a.state->sample_offset + b);
     for (int i4 = tid; i4 * 4 < V; i4 += 256) {
         float q[4];
         if (a.noise) {
@@ -666,10 +669,71 @@ hipError_t launch_gn_stats(const void* x, int dtype, float* stats, int B, int HW
 }
 
 // FAST variants: one pass over contiguous pixel chunks (every load a full 16-B vector), per-channel fp32
-// partials in registers, per-group double partials to memory, tiny finalize.
+// partials in registers, per-group double partials to memory, tiny finalize.  Fixed-order reductions throughout
+// (no atomics): the decode is bit-reproducible from run to run and from lane to lane.
 // pixels per workgroup: HW/32 clamped to [64, 1024] -> 4..64 chunks per image
 static inline int gn_chunk_pix(int HW) { int c = HW / 32; return c < 64 ? 64 : (c > 1024 ? 1024 : c); }
+static inline bool gn_fixed_ok(int C) { return C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0; }
+__device__ __forceinline__ void unpack8(const uint4& raw, float (&f)[8]) {
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); f[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
+}
+// thread t owns channels 8 (t % vpp) .. + 7 of pixels (t / vpp) + k rpi (vpp = C / 8 vectors per pixel, rpi = 256 / vpp)
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double* partial, int HW, int C, int groups, int nchunk, int chunk_pix) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* part = reinterpret_cast<float*>(smem_raw);      // [rpi][C] sums, then [rpi][C] sums of squares; later [C] + [C] totals
+    const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+    const int p0 = ch * chunk_pix, p1 = min(HW, p0 + chunk_pix);
+    const int vpp = C / 8, rpi = 256 / vpp;
+    const int cv = threadIdx.x % vpp, pl = threadIdx.x / vpp;
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.0f; q[i] = 0.0f; }
+    const bf16_t* base = x + ((long long)b * HW) * C + cv * 8;
+    int p = p0 + pl;
+    for (; p + 3 * rpi < p1; p += 4 * rpi) {                // four independent 16-B loads in flight
+        uint4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(base + (long long)(p + u * rpi) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            unpack8(r[u], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] += f[i] * f[i]; }
+        }
+    }
+    for (; p < p1; p += rpi) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(base + (long long)p * C), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] += f[i] * f[i]; }
+    }
+    float* ps = part + (size_t)pl * C + cv * 8;
+    float* pq = part + (size_t)rpi * C + (size_t)pl * C + cv * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ps[i] = s[i]; pq[i] = q[i]; }
+    __syncthreads();
+    float ts = 0.0f, tq = 0.0f;                             // C <= 2048 channels over 256 threads: loop, fixed order over the pixel lanes
+    for (int c = threadIdx.x; c < C; c += 256) {
+        ts = 0.0f; tq = 0.0f;
+        for (int r = 0; r < rpi; ++r) { ts += part[(size_t)r * C + c]; tq += part[(size_t)(rpi + r) * C + c]; }
+        part[(size_t)2 * rpi * C + c] = ts;
+        part[(size_t)2 * rpi * C + C + c] = tq;
+    }
+    __syncthreads();
+    const float* tot = part + (size_t)2 * rpi * C;
+    const int cpg = C / groups;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double a = 0.0, c2 = 0.0;
+        for (int i = 0; i < cpg; ++i) { a += (double)tot[g * cpg + i]; c2 += (double)tot[C + g * cpg + i]; }
+        partial[((long long)blockIdx.x * groups + g) * 2] = a;
+        partial[((long long)blockIdx.x * groups + g) * 2 + 1] = c2;
+    }
+}
+// channel counts the fixed mapping does not cover (C / 8 does not divide 256): one thread per 16-B vector, LDS float atomics
+__global__ __launch_bounds__(256) void gn_partial_generic_kernel(const bf16_t* x, double* partial, int HW, int C, int groups, int nchunk, int chunk_pix) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ssum = reinterpret_cast<float*>(smem_raw);      // [C] sum, [C] sumsq
     float* ssq = ssum + C;
@@ -679,31 +743,13 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double
     __syncthreads();
     const int vec_per_pix = C / 8;
     const int total = (p1 - p0) * vec_per_pix;
-    // thread t always handles the same 8 channels when 256 % vec_per_pix == 0 (C in {64..2048}); else falls back to atomics only
-    float s[8], q[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s[i] = 0.0f; q[i] = 0.0f; }
     const bf16_t* base = x + ((long long)b * HW + p0) * C;
-    const bool fixed = (256 % vec_per_pix) == 0;
-    int myc = -1;
     for (int v = threadIdx.x; v < total; v += 256) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(base + (long long)v * 8);
-        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(base + (long long)v * 8), f);
         const int c8 = (v % vec_per_pix) * 8;
-        if (!fixed && myc >= 0 && myc != c8) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { atomicAdd(&ssum[myc + i], s[i]); atomicAdd(&ssq[myc + i], q[i]); s[i] = 0.0f; q[i] = 0.0f; }
-        }
-        myc = c8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float lo = bf16_to_f32((bf16_t)(w[i] & 0xffffu)), hi = bf16_to_f32((bf16_t)(w[i] >> 16));
-            s[2 * i] += lo; q[2 * i] += lo * lo; s[2 * i + 1] += hi; q[2 * i + 1] += hi * hi;
-        }
-    }
-    if (myc >= 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { atomicAdd(&ssum[myc + i], s[i]); atomicAdd(&ssq[myc + i], q[i]); }
+        for (int i = 0; i < 8; ++i) { atomicAdd(&ssum[c8 + i], f[i]); atomicAdd(&ssq[c8 + i], f[i] * f[i]); }
     }
     __syncthreads();
     const int cpg = C / groups;
@@ -737,7 +783,12 @@ hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, in
                                 hipStream_t st) {
     const int cp = gn_chunk_pix(HW);
     const int nchunk = (HW + cp - 1) / cp;
-    gn_partial_kernel<<<B * nchunk, 256, 2 * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk, cp);
+    if (gn_fixed_ok(C)) {
+        const int rpi = 256 / (C / 8);
+        gn_partial_kernel<<<B * nchunk, 256, (size_t)(2 * rpi + 2) * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk, cp);
+    } else {
+        gn_partial_generic_kernel<<<B * nchunk, 256, 2 * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk, cp);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int n = B * groups;
@@ -745,22 +796,63 @@ hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, in
     return hipGetLastError();
 }
 
+// y = swish?(gamma (x - mean) rstd + beta): a thread keeps scale/shift of its 8 channels in registers and streams
+// pixels with four 16-B loads in flight (same thread <-> channel mapping as gn_partial_kernel)
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* y, const float* stats, const float* gamma,
-                                                       const float* beta, long long total_vec, int HW, int C, int groups, int swish) {
+                                                       const float* beta, int HW, int C, int groups, int swish, int nchunk, int chunk_pix) {
+    const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+    const int p0 = ch * chunk_pix, p1 = min(HW, p0 + chunk_pix);
+    const int vpp = C / 8, rpi = 256 / vpp, cpg = C / groups;
+    const int cv = threadIdx.x % vpp, pl = threadIdx.x / vpp;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = cv * 8 + i;
+        const float* st = stats + ((long long)b * groups + c / cpg) * 2;
+        sc[i] = st[1] * gamma[c];
+        sh[i] = beta[c] - st[0] * sc[i];
+    }
+    const long long off = ((long long)b * HW) * C + cv * 8;
+    auto norm_store = [&](const uint4& raw, long long pix) {
+        float f[8];
+        unpack8(raw, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = fmaf(f[i], sc[i], sh[i]);
+            if (swish) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+            f[i] = t;
+        }
+        uint4 o;
+        o.x = (unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16);
+        o.y = (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16);
+        o.z = (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16);
+        o.w = (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16);
+        *reinterpret_cast<uint4*>(y + off + pix * C) = o;
+    };
+    int p = p0 + pl;
+    for (; p + 3 * rpi < p1; p += 4 * rpi) {
+        uint4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(x + off + (long long)(p + u * rpi) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) norm_store(r[u], p + u * rpi);
+    }
+    for (; p < p1; p += rpi) norm_store(*reinterpret_cast<const uint4*>(x + off + (long long)p * C), p);
+}
+__global__ __launch_bounds__(256) void gn_apply_generic_kernel(const bf16_t* x, bf16_t* y, const float* stats, const float* gamma,
+                                                               const float* beta, long long total_vec, int HW, int C, int groups, int swish) {
     const int cpg = C / groups, vec_per_pix = C / 8;
     for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < total_vec; v += (long long)gridDim.x * blockDim.x) {
         const long long pix = v / vec_per_pix;
         const int c8 = (int)(v - pix * vec_per_pix) * 8;
         const int b = (int)(pix / HW);
-        const uint4 raw = *reinterpret_cast<const uint4*>(x + v * 8);
-        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
         float f[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); f[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
+        unpack8(*reinterpret_cast<const uint4*>(x + v * 8), f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float* st = stats + ((long long)b * groups + (c8 + i) / cpg) * 2;
-            float t = (f[i] - st[0]) * st[1] * gamma[c8 + i] + beta[c8 + i];
+            const float scl = st[1] * gamma[c8 + i];
+            float t = fmaf(f[i], scl, beta[c8 + i] - st[0] * scl);
             if (swish) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
             f[i] = t;
         }
@@ -774,9 +866,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* 
 }
 hipError_t launch_gn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, int B, int HW,
                            int C, int groups, int swish, hipStream_t st) {
+    if (gn_fixed_ok(C)) {
+        const int cp = gn_chunk_pix(HW);
+        const int nchunk = (HW + cp - 1) / cp;
+        gn_apply_kernel<<<B * nchunk, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, stats, gamma, beta, HW, C, groups, swish, nchunk, cp);
+        return hipGetLastError();
+    }
     const long long total_vec = (long long)B * HW * C / 8;
     const int grid = (int)std::min<long long>((total_vec + 255) / 256, 256 * 16);
-    gn_apply_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, stats, gamma, beta, total_vec, HW, C, groups, swish);
+    gn_apply_generic_kernel<<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, stats, gamma, beta, total_vec, HW, C, groups, swish);
     return hipGetLastError();
 }
 

@@ -64,7 +64,26 @@ class Engine:
         self.h = h
         self.finalized = False
 
+    def clone(self) -> 'Engine':
+        """A further lane over the same weights (``hqt_clone``): own KV cache / activations / graph cache, results
+        bit-identical to this engine's.  Lanes on different streams keep several batches in flight on one GPU."""
+        if not self.finalized:
+            raise _lib.HqtError(-1, 'clone() needs a finalized engine')
+        e = Engine.__new__(Engine)
+        e.lib, e.s2, e.s1, e.device = self.lib, self.s2, self.s1, self.device
+        e.max_batch, e.max_steps, e.cfg = self.max_batch, self.max_steps, self.cfg
+        h = C.c_void_p()
+        _lib.check(self.lib.hqt_clone(self.h, C.byref(h)))
+        e.h, e.finalized = h, True
+        e._parent = self                             # keeps the weights' owner alive
+        self._clones = getattr(self, '_clones', [])
+        self._clones.append(e)
+        return e
+
     def close(self) -> None:
+        for c in getattr(self, '_clones', []):       # clones go first: the parent owns the weights
+            c.close()
+        self._clones = []
         if getattr(self, 'h', None) is not None and self.h.value:
             self.lib.hqt_destroy(self.h)
             self.h = C.c_void_p()

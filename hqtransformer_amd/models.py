@@ -63,8 +63,19 @@ class _Stage:
 
     def _drop_engine(self):
         if self._engine is not None:
-            self._engine.close()
+            self._engine.close()                     # closes its lanes first
         self._engine = None
+        self._lanes = {}
+
+    def _lane(self, base: Engine, lane: int) -> Engine:
+        """Lane 0 is the engine that owns the weights; lane k > 0 is a clone sharing them (own workspace), created on
+        first use.  One lane per batch in flight (hqtransformer_amd.pipeline)."""
+        if lane == 0:
+            return base
+        lanes = self.__dict__.setdefault('_lanes', {})
+        if lane not in lanes:
+            lanes[lane] = base.clone()
+        return lanes[lane]
 
     def _ignored(self, key: str) -> bool:
         return False
@@ -118,7 +129,7 @@ class HQTransformerStage2(_Stage):
     def pos_emb_txt(self):
         return _Table(self._w['pos_emb_txt.weight'])
 
-    def engine(self, batch: int, n_steps: int) -> Engine:
+    def engine(self, batch: int, n_steps: int, lane: int = 0) -> Engine:
         self._need_gpu()
         e = self._engine
         if e is None or batch > e.max_batch or n_steps > e.max_steps:
@@ -127,7 +138,7 @@ class HQTransformerStage2(_Stage):
             e.load(stage2={k: v for k, v in self._w.items() if k not in STAGE2_UNUSED})
             e.finalize()
             self._engine = e
-        return e
+        return self._lane(e, lane)
 
 
 class HQVAEStage1(_Stage):
@@ -142,7 +153,7 @@ class HQVAEStage1(_Stage):
     def _ignored(self, key: str) -> bool:
         return stage1_is_ignored(key)
 
-    def engine(self, batch: int) -> Engine:
+    def engine(self, batch: int, lane: int = 0) -> Engine:
         self._need_gpu()
         e = self._engine
         if e is None or batch > e.max_batch:
@@ -151,24 +162,24 @@ class HQVAEStage1(_Stage):
             e.load(stage1=self._w)
             e.finalize()
             self._engine = e
-        return e
+        return self._lane(e, lane)
 
     def decode_code(self, code_t: Optional[torch.Tensor], code_b: Optional[torch.Tensor], precision: Optional[str] = None,
-                    clamp01: bool = False) -> torch.Tensor:
+                    clamp01: bool = False, lane: int = 0) -> torch.Tensor:
         """``SimRQGAN2Generator.decode_code`` (generator.py:323-367): int64 code grids -> fp32 [B, 3, H, W],
         unclamped; either level may be None (zero quant).  ``precision`` 'exact' (fp32, the reference's
         arithmetic for this call) or 'fast' (bf16 MFMA); defaults to ``self.precision``."""
         assert code_t is not None or code_b is not None
         ref = code_t if code_t is not None else code_b
         prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
-        return self.engine(int(ref.shape[0])).decode(code_t, code_b, precision=prec, clamp01=clamp01)
+        return self.engine(int(ref.shape[0]), lane).decode(code_t, code_b, precision=prec, clamp01=clamp01)
 
     def decode_sequences(self, codes_top: torch.Tensor, codes_bot: torch.Tensor, precision: Optional[str] = None,
-                         clamp01: bool = False) -> torch.Tensor:
+                         clamp01: bool = False, lane: int = 0) -> torch.Tensor:
         """Decode the sampler's own outputs ([B, HW], [B, HW, 4]); the two rearranges of
         sampling_hqmodel.py:119-120 are folded into the codebook-gather addressing."""
         prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
-        return self.engine(int(codes_top.shape[0])).decode(codes_top, codes_bot, precision=prec, clamp01=clamp01, seq_layout=True)
+        return self.engine(int(codes_top.shape[0]), lane).decode(codes_top, codes_bot, precision=prec, clamp01=clamp01, seq_layout=True)
 
 
 class ImageGPT2:

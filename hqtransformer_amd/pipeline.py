@@ -1,0 +1,58 @@
+"""Several batches in flight on one GPU.
+
+The reference's harness (``measure_throughput/__main__.py:84-116``) samples and decodes one batch at a time.  On an
+MI355X the 64-row AR loop is a dependent chain of ~100 small kernels per position, each of which keeps well under half
+of the 256 CUs busy and is bound by per-CU latency; independent chains interleave almost for free.  ``InflightSampler``
+therefore round-robins consecutive batches over N *lanes*: every lane has its own stream, KV cache and activations
+(``hqt_clone``) and shares the weights, every batch is still one complete ``sampling_ihqgpt`` + ``decode_code`` pass
+of the configured batch size, and results do not depend on the lane (bit-identical, tests/test_gpu_surface.py).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from .sampling import sampling_ihqgpt
+
+
+class InflightSampler:
+    def __init__(self, model, lanes: int = 3, device: Optional[torch.device] = None):
+        if lanes < 1:
+            raise ValueError('lanes must be >= 1')
+        self.model = model
+        self.n = int(lanes)
+        self.device = device if device is not None else model.stage2._device
+        self.streams: List[torch.cuda.Stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
+        self.k = 0
+
+    def submit(self, num_candidates: int, cond, *, seed: Optional[int] = None, max_seq_len: int = 64, use_fp16: bool = True,
+               decode: bool = True, precision: Optional[str] = None, clamp01: bool = True, use_graph: bool = True,
+               after=None, **sample_kw) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.cuda.Event]:
+        """Queue one batch on the next lane; returns (codes_top, codes_bot, pixels or None, done_event) immediately.
+        The tensors are valid once ``done_event`` has completed (or after ``drain()``)."""
+        lane = self.k % self.n
+        self.k += 1
+        st = self.streams[lane]
+        # order the lane after whatever the caller's stream has queued (inputs; earlier direct use of lane 0's engine):
+        # a lane's workspace must never be touched from two streams at once
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
+            ct, cb = sampling_ihqgpt(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
+                                     use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, **sample_kw)
+            px = None
+            if decode:
+                px = self.model.stage1.decode_sequences(ct, cb, precision=precision or ('fast' if use_fp16 else 'exact'),
+                                                        clamp01=clamp01, lane=lane)
+            if after is not None:
+                after(ct, cb, px)                    # e.g. a gather of the finished pixels, queued on the lane's stream
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return ct, cb, px, ev
+
+    def drain(self) -> None:
+        """Wait for every lane; also orders the caller's stream after the lanes."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+            st.synchronize()

@@ -35,7 +35,8 @@ def sampling_ihqgpt(model,
                     noise: Optional[torch.Tensor] = None,
                     sample_offset: int = 0,
                     seed: Optional[int] = None,
-                    use_graph: bool = True):
+                    use_graph: bool = True,
+                    lane: int = 0):
     """Returns ``(codes_top int64 [B, max_seq_len], codes_bot int64 [B, max_seq_len, 4])`` on the model's GPU.
 
     ``model`` is ``ImageGPT2.stage2``.  ``cond``: python int (class id, repeated for every candidate), an
@@ -44,7 +45,8 @@ def sampling_ihqgpt(model,
     ``False`` -> EXACT fp32 (what the reference computes on its CPU path).  ``is_tqdm`` and ``model_stage1``
     are accepted and ignored (the latter only feeds a dead branch, hierarchical_ar.py:697-699).
     Extensions: ``noise`` fp32 [max_seq_len, 5, B, V] Exp(1) variates (draw = argmax(p/q), the multinomial
-    identity) for bit-reproducible runs; ``sample_offset``/``seed`` for sharded batches.
+    identity) for bit-reproducible runs; ``sample_offset``/``seed`` for sharded batches; ``lane`` selects one of
+    several workspaces over the same weights (one per batch in flight, see ``hqtransformer_amd.pipeline``).
     """
     spec = model.spec
     if model.use_txt_cond:
@@ -73,7 +75,7 @@ def sampling_ihqgpt(model,
         if force_top.shape[0] != B:
             force_top = force_top.repeat(B, 1)
         force_top = force_top[:, :max_seq_len]
-    eng = model.engine(B, max_seq_len)
+    eng = model.engine(B, max_seq_len, lane)
     if seed is None and noise is None:
         seed = _seed_from_torch()
     return eng.sample(B, cond, max_seq_len, precision=PRECISION_FAST if use_fp16 else PRECISION_EXACT,

@@ -101,6 +101,14 @@ int hqt_set_weight(hqt_handle* h, const char* name, const void* data, int dtype,
  * (fused QKV, tap-major conv filters, bf16 MFMA-fragment packing for FAST). */
 int hqt_finalize_weights(hqt_handle* h);
 
+/* hqt_clone -- a further LANE over the weights of a finalized handle.  The reference's throughput harness
+ * (measure_throughput/__main__.py:84-116) runs one batch at a time; its 64-row AR loop is a chain of small
+ * latency-bound kernels that leaves most of an MI355X idle, so the harness here keeps several batches in flight,
+ * one lane and one HIP stream each (independent chains interleave on the GPU).  The clone shares every weight
+ * buffer of `src` and owns only its workspace (KV cache, activations, step state, graph cache); results of a lane
+ * are bit-identical to the parent's.  Destroy clones before their parent (hqt_destroy(parent) fails otherwise). */
+int hqt_clone(hqt_handle* src, hqt_handle** out);
+
 /* hqt_sample -- replaces sampling_ihqgpt + iHQGPT.sampling_step (hqvae/utils/sampling.py:164-237,
  * hierarchical_ar.py:428-480, 482-563, 667-789) for a batch of B independent images.
  *   cond        int64 [B] class ids (HQT_COND_CLASS), int64 [B, ctx_len_txt] token ids

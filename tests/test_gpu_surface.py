@@ -78,3 +78,34 @@ def test_sampling_hqmodel_counterpart_writes_reference_formats(tmp_path):
         tg = np.load(tmp_path / f'targets_({cls}_0).npz')['targets']
         assert px.dtype == np.float32 and px.shape == (2, 3, 64, 64) and px.min() >= 0 and px.max() <= 1
         assert tg.dtype == np.int64 and (tg == cls - 1).all()
+
+
+def test_lanes_share_weights_and_are_bit_identical(model):
+    """hqt_clone lanes (hqtransformer_amd.pipeline): a lane has its own KV cache / activations / graph cache over the
+    parent's weights.  Codes (exact AND fast arithmetic) and pixels must not depend on the lane, whether the batches
+    run one after another or interleaved on separate streams; the parent cannot be destroyed under a live clone."""
+    from hqtransformer_amd.pipeline import InflightSampler
+    B, n = 3, 16
+    s2 = model.stage2.spec
+    noise = torch.from_numpy(synth.exp_noise(21, n, B, s2.vocab_top))
+    ref = {}
+    for fp16 in (False, True):
+        ct, cb = sampling_ihqgpt(model.stage2, B, 5, use_fp16=fp16, is_tqdm=False, max_seq_len=n, noise=noise)
+        px = model.stage1.decode_sequences(torch.cat([ct] * 4, 1), torch.cat([cb] * 4, 1), precision='fast' if fp16 else 'exact')
+        ref[fp16] = (ct.clone(), cb.clone(), px.clone())
+        for lane in (1, 2):
+            ct2, cb2 = sampling_ihqgpt(model.stage2, B, 5, use_fp16=fp16, is_tqdm=False, max_seq_len=n, noise=noise, lane=lane)
+            px2 = model.stage1.decode_sequences(torch.cat([ct2] * 4, 1), torch.cat([cb2] * 4, 1), precision='fast' if fp16 else 'exact',
+                                                lane=lane)
+            assert torch.equal(ct2, ct) and torch.equal(cb2, cb) and torch.equal(px2, px)
+    # interleaved: six batches with different seeds over three lanes == the same six batches one at a time on lane 0
+    serial = [sampling_ihqgpt(model.stage2, B, 7, use_fp16=True, is_tqdm=False, max_seq_len=n, seed=100 + k) for k in range(6)]
+    serial = [(a.clone(), b.clone()) for a, b in serial]
+    pipe = InflightSampler(model, lanes=3)
+    got = [pipe.submit(B, 7, seed=100 + k, max_seq_len=n, use_fp16=True, decode=False) for k in range(6)]
+    pipe.drain()
+    eq = [bool(ev.query() and px is None and torch.equal(a, ct) and torch.equal(b, cb)) for (a, b), (ct, cb, px, ev) in zip(serial, got)]
+    assert all(eq), eq
+    # ownership: the parent handle refuses to go away while a clone lives
+    eng = model.stage2.engine(B, n)
+    assert eng.lib.hqt_destroy(eng.h) != 0 and b'clone' in eng.lib.hqt_last_error()
