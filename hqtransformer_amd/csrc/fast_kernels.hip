@@ -257,6 +257,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
         return;
     }
     // STORE_QKV destination of this workgroup's 32 columns
+    const bool qkv_uniform = g.store == STORE_QKV && g.qkv_D % (32 * NT) == 0;      // the workgroup's columns lie in one part
     const int qkv_part_local = g.store == STORE_QKV ? (ntile0 * 32) / max(g.qkv_D, 1) : 0;
     const int qkv_part = qkv_part_local + g.qkv_first;
     TC* const qkv_base = reinterpret_cast<TC*>(qkv_part == 0 ? g.C : (qkv_part == 1 ? g.C2 : g.C3));
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
         }
         if (m >= g.M) continue;
         if (S > 1 && ABL != 9) { slabs[((size_t)blockIdx.z * (MB * 32) + m) * g.N + ncol] = s; continue; }
-        if (g.store == STORE_QKV && NT == 1) {
+        if (g.store == STORE_QKV && qkv_uniform) {
             // fused [query; key; value]: D % 32 == 0, so the part is uniform per workgroup; destination picked once
             // (a per-element select between C / C2 / C3 inside gemm_store was miscompiled by hipcc -O3 whenever a
             // second bf16 store followed it: stores silently went missing)
@@ -370,7 +371,8 @@ static hipError_t launch_stream_t(const GemmArgs& g, const bf16_t* wpk, int S, f
 // kernels, so the decomposition maximises the number of busy CUs; narrow-N GEMMs split K across
 // workgroups (S > 1) and leave the fp32 partial slabs to the next LayerNorm.
 #define STREAM_CASES(X, TC) \
-    X(1, 1, 8, 12, TC) X(2, 1, 8, 12, TC) X(2, 1, 8, 6, TC)
+    X(1, 1, 8, 12, TC) X(2, 1, 8, 12, TC) X(2, 1, 8, 6, TC) \
+    X(2, 2, 4, 6, TC) X(2, 2, 8, 6, TC) X(2, 1, 4, 12, TC) X(1, 1, 4, 12, TC) X(1, 2, 4, 8, TC) X(4, 1, 4, 4, TC) X(4, 2, 4, 3, TC) X(2, 1, 4, 6, TC)
 int stream_gemm_splitk(const GemmArgs& g) {
     const int KS = g.K / 16;
     const int wgs = (g.N / 32) * g.a_packed_mb;            // with MBW = 1
@@ -379,8 +381,37 @@ int stream_gemm_splitk(const GemmArgs& g) {
         if (wgs * S <= 256 && KS % (S * 8) == 0) return S;
     return 1;
 }
+// Tuning hook: HQT_GEMM_<class>="MBW,NT,NW,U" picks another instantiated variant for a shape class
+// (M64W / M64N / M256W / M256N: 64- or 256-row activations, wide (N >= 3072) or narrow weights).
+struct StreamCfg { int mbw, nt, nw, u; };
+static StreamCfg stream_cfg_env(const char* name) {
+    StreamCfg c{0, 0, 0, 0};
+    const char* v = getenv(name);
+    if (v) sscanf(v, "%d,%d,%d,%d", &c.mbw, &c.nt, &c.nw, &c.u);
+    return c;
+}
+template <typename TC>
+static hipError_t launch_stream_cfg(const StreamCfg& c, const GemmArgs& g, const bf16_t* wpk, hipStream_t st, bool& taken) {
+    taken = true;
+    if (g.a_packed_mb % c.mbw != 0 || (g.N / 32) % c.nt != 0) { taken = false; return hipSuccess; }
+#define TRY(MBW, NT, NW, U, TC_) if (c.mbw == MBW && c.nt == NT && c.nw == NW && c.u == U) return launch_stream_t<MBW, NT, NW, U, TC>(g, wpk, 1, nullptr, st);
+    STREAM_CASES(TRY, TC)
+#undef TRY
+    taken = false;
+    return hipSuccess;
+}
 template <typename TC>
 static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
+    if (S == 1 && (g.a_packed_mb == 2 || g.a_packed_mb == 8)) {
+        static const StreamCfg cfgs[4] = {stream_cfg_env("HQT_GEMM_M64W"), stream_cfg_env("HQT_GEMM_M64N"),
+                                          stream_cfg_env("HQT_GEMM_M256W"), stream_cfg_env("HQT_GEMM_M256N")};
+        const StreamCfg& c = cfgs[(g.a_packed_mb == 8 ? 2 : 0) + (g.N >= 3072 ? 0 : 1)];
+        if (c.mbw > 0) {
+            bool taken = false;
+            const hipError_t e = launch_stream_cfg<TC>(c, g, wpk, st, taken);
+            if (taken) return e;
+        }
+    }
     const int wgs2 = (g.N / 32) * (g.a_packed_mb / 2);
     if (S == 1 && g.a_packed_mb == 2 && wgs2 >= 128) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);
     if (S == 1 && g.a_packed_mb >= 4) {                 // M = 128..256 (depth sub-step 1): 64-row activation tiles halve the weight re-reads

@@ -126,3 +126,32 @@ def test_index_maps():
     gt, gb = O.rearrange_codes(fx['codes_top'], fx['codes_bot'], 8)
     assert (gt == fx['grid_top']).all() and (gb == fx['grid_bot']).all()
     assert (O.pixel_shuffle2(fx['pixel_shuffle_in']) == fx['pixel_shuffle_out']).all()
+
+
+@pytest.mark.parametrize('name', ['tiny', 'true'])
+def test_block_steps_match_reference(name):
+    """G2: one body Block (causal prefix, then a cached decode step) and one depth ParallelBlock (no-past token, then four
+    tokens over one past key) of the reference, at a tiny shape and at the ImageNet head geometry (D = 1536, 24 x 64)."""
+    import json
+    from hqtransformer_amd import synth
+    from hqtransformer_amd.spec import Stage2Spec
+    from oracle.hqt_oracle import OracleStage2
+    fx = load('g2_block_step.npz')
+    spec = Stage2Spec(**json.loads(str(fx[f'{name}_spec'])))
+    orc = OracleStage2(spec, synth.stage2_weights(spec, int(fx['weight_seed']), 'fixture'))
+    B, nh, hs = 2, spec.n_heads, spec.head_dim
+    cache = {}
+    yp = orc._block('blocks.0', fx[f'{name}_xp'], cache, True)
+    yn = orc._block('blocks.0', fx[f'{name}_xn'], cache, True)
+    assert np.abs(yp - fx[f'{name}_yp']).max() <= 2e-4 and np.abs(yn - fx[f'{name}_yn']).max() <= 2e-4
+    k, v = cache['blocks.0']                                           # [B, nh, 4, hs]; the reference's `present` = the new token only
+    assert k.shape == (B, nh, 4, hs)
+    assert np.abs(k[:, :, 3:].reshape(B * nh, 1, hs) - fx[f'{name}_k']).max() <= 1e-4
+    assert np.abs(v[:, :, 3:].reshape(B * nh, 1, hs) - fx[f'{name}_v']).max() <= 1e-4
+    dcache = {}
+    y0 = orc._block('depths.0', fx[f'{name}_xd0'], dcache, False)
+    y1 = orc._block('depths.0', fx[f'{name}_xd1'], dcache, False)
+    assert np.abs(y0 - fx[f'{name}_yd0']).max() <= 2e-4 and np.abs(y1 - fx[f'{name}_yd1']).max() <= 2e-4
+    dk, dv = dcache['depths.0']                                        # 1 past + 4 new keys
+    assert np.abs(dk[:, :, 1:].reshape(B * nh, 4, hs) - fx[f'{name}_dk']).max() <= 1e-4
+    assert np.abs(dv[:, :, 1:].reshape(B * nh, 4, hs) - fx[f'{name}_dv']).max() <= 1e-4

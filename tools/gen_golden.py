@@ -25,7 +25,11 @@ sys.path.insert(0, REF)
 _om = types.ModuleType('omegaconf')
 _om.OmegaConf = object
 sys.modules['omegaconf'] = _om
-import hqvae  # noqa: E402  (namespace package)
+# the reference's `hqvae` is a namespace package; this repository's own `hqvae/` import shim (a regular package) would win
+# the import regardless of sys.path order, so the reference tree is bound explicitly
+_hq = types.ModuleType('hqvae')
+_hq.__path__ = [os.path.join(REF, 'hqvae')]
+sys.modules['hqvae'] = _hq
 _pkg = types.ModuleType('hqvae.models')
 _pkg.__path__ = [os.path.join(REF, 'hqvae/models')]
 sys.modules['hqvae.models'] = _pkg
