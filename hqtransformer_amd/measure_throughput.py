@@ -9,7 +9,9 @@ Same dot-list keys and defaults (``Experiment`` dataclass, :34-48), same loop ac
 both, and the same printed lines (``ms/sample (ar: .., decode: ..)``).  Random-init weights, like the reference.
 Differences, stated: the whole batch is decoded in one call instead of ``batch_size`` calls of one image
 (``decode_batch=1`` restores the reference's chunking), and ``decode_precision=exact`` selects the reference's
-fp32 decode arithmetic (default ``fast`` = bf16 MFMA).
+fp32 decode arithmetic (default ``fast`` = bf16 MFMA).  ``inflight=N`` (default 1 = the reference's order) keeps N
+iterations in flight on N lanes (``hqtransformer_amd.pipeline``): same iterations, same accounting of the loop's wall
+time; the per-phase figures then are lane times, which overlap.
 """
 from __future__ import annotations
 
@@ -25,7 +27,7 @@ from .models import ImageGPT2
 from .sampling import rearrange_codes, sampling_ihqgpt
 
 EXPERIMENT_DEFAULTS = dict(f=32, model='huge', d=4, c=16384, batch_size=50, n_loop=6, warmup=1, model_path='',
-                           top_resolution=8, code_levels=2, decode_batch=0, decode_precision='fast', seed=0)
+                           top_resolution=8, code_levels=2, decode_batch=0, decode_precision='fast', seed=0, inflight=1)
 
 
 def iterations_per_loop(batch_size: int) -> int:
@@ -56,13 +58,24 @@ def main(args) -> dict:
     n_iter_per_loop = iterations_per_loop(batch_size)
     n_loop = args.n_loop
 
+    pipe = None
+    if int(args.inflight) > 1:
+        from .pipeline import InflightSampler
+        pipe = InflightSampler(model_ar, lanes=int(args.inflight), device=device)
+
     def loop(loop_idx: int):
         starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
         middles = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
         ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
         torch.cuda.synchronize(device)
         tic = time.time()
-        for i in range(n_iter_per_loop):
+        for i in range(n_iter_per_loop if pipe is not None else 0):
+            pipe.submit(batch_size, random.randint(0, 999), max_seq_len=args.top_resolution * args.top_resolution, use_fp16=True,
+                        precision=args.decode_precision, clamp01=True, softmax_temperature=[1.0 for _ in range(args.code_levels)],
+                        phase_events=(starts[i], middles[i], ends[i]))
+        if pipe is not None:
+            pipe.drain()
+        for i in range(n_iter_per_loop if pipe is None else 0):
             starts[i].record()
             codes_t, codes_b = sampling_ihqgpt(model_ar.stage2, cond=random.randint(0, 999), num_candidates=batch_size,
                                                top_k_top=None, top_p_top=None, top_k_bot=None, top_p_bot=None,

@@ -28,9 +28,10 @@ class InflightSampler:
 
     def submit(self, num_candidates: int, cond, *, seed: Optional[int] = None, max_seq_len: int = 64, use_fp16: bool = True,
                decode: bool = True, precision: Optional[str] = None, clamp01: bool = True, use_graph: bool = True,
-               after=None, **sample_kw) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.cuda.Event]:
+               after=None, phase_events=None, **sample_kw) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.cuda.Event]:
         """Queue one batch on the next lane; returns (codes_top, codes_bot, pixels or None, done_event) immediately.
-        The tensors are valid once ``done_event`` has completed (or after ``drain()``)."""
+        The tensors are valid once ``done_event`` has completed (or after ``drain()``).  ``phase_events``: three timing
+        events recorded on the lane's stream at AR start / AR end / decode end (lane time: phases of different lanes overlap)."""
         lane = self.k % self.n
         self.k += 1
         st = self.streams[lane]
@@ -38,12 +39,18 @@ class InflightSampler:
         # a lane's workspace must never be touched from two streams at once
         st.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(st):
+            if phase_events is not None:
+                phase_events[0].record(st)
             ct, cb = sampling_ihqgpt(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
                                      use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, **sample_kw)
+            if phase_events is not None:
+                phase_events[1].record(st)
             px = None
             if decode:
                 px = self.model.stage1.decode_sequences(ct, cb, precision=precision or ('fast' if use_fp16 else 'exact'),
                                                         clamp01=clamp01, lane=lane)
+            if phase_events is not None:
+                phase_events[2].record(st)
             if after is not None:
                 after(ct, cb, px)                    # e.g. a gather of the finished pixels, queued on the lane's stream
             ev = torch.cuda.Event()

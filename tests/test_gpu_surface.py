@@ -67,6 +67,10 @@ def test_measure_throughput_counterpart(capsys):
     text = capsys.readouterr().out
     assert 'bs500, sampling loops 2-2' in text and 'transformer size:' in text and 'ms/sample (ar:' in text
     assert out['ms_per_sample'] > 0 and abs(out['ms_ar'] + out['ms_decode'] - out['ms_per_sample']) / out['ms_per_sample'] < 0.2
+    # several iterations in flight: same loop accounting, phases are lane times
+    args = parse_dotlist([f'model_path={TINY}', 'batch_size=250', 'n_loop=2', 'warmup=1', 'inflight=3'], mt.EXPERIMENT_DEFAULTS)
+    out3 = mt.main(args)
+    assert 'bs250, sampling loops 2-2' in capsys.readouterr().out and out3['ms_per_sample'] > 0
 
 
 def test_sampling_hqmodel_counterpart_writes_reference_formats(tmp_path):

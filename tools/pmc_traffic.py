@@ -9,7 +9,7 @@ import json
 import re
 import sys
 
-FAMILIES = {'stream_gemm': 'stream_gemm_kernel', 'conv_glds': 'conv_glds_kernel'}
+FAMILIES = {'stream_gemm': ('stream_gemm_kernel',), 'decoder_conv': ('conv3x3_halo_kernel', 'conv_glds_kernel')}
 
 
 def family_sum(path, counter):
@@ -19,7 +19,7 @@ def family_sum(path, counter):
         if not m:
             continue
         for fam, key in FAMILIES.items():
-            if key in m.group(1):
+            if any(k in m.group(1) for k in key):
                 n, s = out.get(fam, (0, 0.0))
                 out[fam] = (n + int(m.group(2)), s + float(m.group(4)))
     return out
