@@ -97,6 +97,8 @@ __device__ inline void ln_partial_stats(const GemmArgs& g, float& ln_s, float& l
 // split that K range into contiguous runs.  gridDim = (N / (32 NT), MB_total / MBW, S).  With S > 1
 // (cross-workgroup split-K) the fp32 partial tile goes to slab z of `slabs` ([S][Mpad][N]) and the
 // epilogue runs in the consumer (LayerNorm combine); with S == 1 the fused epilogue runs here.
+// dynamic LDS of a variant: NW padded partial tiles (32 x 36 floats per 32 x 32 block) + row statistics
+constexpr size_t stream_gemm_lds(int MBW, int NT, int NW) { return (size_t)NW * NT * MBW * 32 * 36 * 4 + (size_t)MBW * 256 + (size_t)NW * 512; }
 // occupancy hint (waves per SIMD): 128 VGPRs let two 8-wave workgroups (or one 16-wave workgroup) share a CU
 constexpr int stream_min_waves(int MBW, int NT, int NW, int U) {
     return (NW == 16 || (MBW * NT == 1 && NW == 8) || 16 * NT * MBW + 4 * U * (NT + MBW) + 40 <= 128) ? 4 : 1;
@@ -104,12 +106,14 @@ constexpr int stream_min_waves(int MBW, int NT, int NW, int U) {
 template <int MBW, int NT, int NW, int U, typename TC, int ABL = 0>   // ABL: ablation switches of tools/micro/bench_stream
 __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = reinterpret_cast<float*>(smem_raw);                  // [NW][NT*32 n][MBW*32 m] as [NT][MBW][m32][n32]
-    constexpr int TILE = NT * MBW * 1024;
+    float* red = reinterpret_cast<float*>(smem_raw);                  // [NW][NT][MBW][m32][RP]: row m holds its 32 n, padded to 36 floats
+    constexpr int TILE = NT * MBW * 1024;                             // outputs per workgroup
+    constexpr int RP = 36;                                            // row pitch: 8 lanes x ds_write_b128 land on 8 distinct 4-bank groups
+    constexpr int TILE_P = NT * MBW * 32 * RP;
     long long stamp[6];
     if (ABL == 9) { stamp[0] = wall_clock64(); stamp[1] = clock64(); }
     // deferred LayerNorm: this thread's share of the partial row statistics (issued first, consumed in the epilogue)
-    float* lnstat = red + (size_t)NW * NT * MBW * 1024;               // [MBW*32][2] (sum, sumsq), then (mean, rstd)
+    float* lnstat = red + (size_t)NW * TILE_P;                        // [MBW*32][2] (sum, sumsq), then (mean, rstd)
     float ln_s = 0.0f, ln_q = 0.0f;
     constexpr int ROWS = MBW * 32, PGROUPS = NW * 64 / ROWS;          // threads per row
     // Variants with registers to spare (MBW >= 2: one workgroup per CU anyway) fetch their share of the partial row
@@ -219,9 +223,31 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
             ln_partial_stats<ROWS, PGROUPS>(g, ln_s, ln_q);
         }
     }
+    // ---- vector epilogue (the AR loop's store modes): a thread finishes 4 consecutive columns of one row.  Its bias,
+    //      column sums and residual row are fetched here, under the reduction, instead of as dependent loads afterwards.
+    const bool vec_epi = S == 1 && (ABL == 0 || ABL == 9) && g.N % 4 == 0 && g.ldc % 4 == 0 &&
+                         (g.store == STORE_RESID || g.store == STORE_PACKED || (g.store == STORE_QKV && g.qkv_D % (32 * NT) == 0) ||
+                          (g.store == STORE_ROWS && g.rows_per_group == 0 && !g.resid && g.batch <= 1));
+    constexpr int VGROUPS = TILE / 4;                                 // 4-column groups per workgroup
+    constexpr int VPT = (VGROUPS + NW * 64 - 1) / (NW * 64);          // groups per thread (1 for the instantiated variants)
+    f32x4 e_bias[VPT], e_cs[VPT], e_res[VPT];
+    if (vec_epi) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int o4 = min((int)(threadIdx.x + j * NW * 64), VGROUPS - 1) * 4;
+            const int n = o4 & 31, ml = (o4 >> 5) & 31, blk = o4 >> 10;
+            const int mb = blk % MBW, t = blk / MBW;
+            const int m = min((mb0 + mb) * 32 + ml, g.M - 1);
+            const int ncol = (ntile0 + t) * 32 + n;
+            const float* zsrc = reinterpret_cast<const float*>(g.A);          // any valid 16 bytes: unconditional loads
+            e_bias[j] = *reinterpret_cast<const f32x4*>(g.bias ? g.bias + ncol : zsrc);
+            e_cs[j] = *reinterpret_cast<const f32x4*>(g.ln_parts ? g.ln_colsum + ncol : zsrc);
+            e_res[j] = *reinterpret_cast<const f32x4*>(g.store == STORE_RESID ? reinterpret_cast<const float*>(g.C) + (size_t)m * g.ldc + ncol : zsrc);
+        }
+    }
     // ---- cross-wave reduction through LDS; C/D map: col = lane & 31 -> m, row = (r&3) + 8 (r>>2) + 4 (lane>>5) -> n
     {
-        float* my = red + (size_t)wave * TILE;
+        float* my = red + (size_t)wave * TILE_P;
         const int h = lane >> 5, c = lane & 31;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const f32x4 v = {acc[t][mb][4 * gq], acc[t][mb][4 * gq + 1], acc[t][mb][4 * gq + 2], acc[t][mb][4 * gq + 3]};
-                    *reinterpret_cast<f32x4*>(my + ((t * MBW + mb) * 32 + c) * 32 + 8 * gq + 4 * h) = v;
+                    *reinterpret_cast<f32x4*>(my + ((t * MBW + mb) * 32 + c) * RP + 8 * gq + 4 * h) = v;
                 }
     }
     if (g.ln_parts) {                                   // fixed-order (deterministic) reduction of the partial statistics
@@ -253,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     }
     if (ABL == 9) stamp[4] = clock64();
     if (ABL == 3) {
-        if (threadIdx.x == 0) reinterpret_cast<float*>(g.C)[blockIdx.x] = red[0] + red[TILE];
+        if (threadIdx.x == 0) reinterpret_cast<float*>(g.C)[blockIdx.x] = red[0] + red[TILE_P];
         return;
     }
     // STORE_QKV destination of this workgroup's 32 columns
@@ -263,13 +289,79 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     TC* const qkv_base = reinterpret_cast<TC*>(qkv_part == 0 ? g.C : (qkv_part == 1 ? g.C2 : g.C3));
     bf16_t* const qkv_vcopy = (g.store == STORE_QKV && qkv_part == 2) ? g.qkv_v_pk : nullptr;
     const int qkv_row_dev = (g.store == STORE_QKV && g.row_offset_dev) ? *g.row_offset_dev : 0;
+    if (vec_epi) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int vo = threadIdx.x + j * NW * 64;
+            const bool live = vo < VGROUPS;
+            const int o4 = min(vo, VGROUPS - 1) * 4;
+            const int n = o4 & 31, ml = (o4 >> 5) & 31, blk = o4 >> 10;
+            const int mb = blk % MBW, t = blk / MBW;
+            const int m = (mb0 + mb) * 32 + ml;
+            const int ncol = (ntile0 + t) * 32 + n;
+            const float* rp = red + (blk * 32 + ml) * RP + n;
+            f32x4 sv = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sv += *reinterpret_cast<const f32x4*>(rp + (size_t)w * TILE_P);
+            float v[4] = {sv[0], sv[1], sv[2], sv[3]};
+            if (g.ln_parts) {
+                const float mean = lnstat[2 * (mb * 32 + ml)], rstd = lnstat[2 * (mb * 32 + ml) + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rstd * (v[e] - mean * e_cs[j][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * g.alpha + (g.bias ? e_bias[j][e] : 0.0f);
+            const bool row_ok = live && m < g.M;
+            if (g.store == STORE_RESID) {
+                // residual producer: fp32 master row, bf16 packed copy for the next GEMM, partial row statistics of that copy
+                float rs = 0.0f, rq = 0.0f;
+                if (row_ok) {
+                    f32x4 x4;
+                    bf16_t hb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x4[e] = e_res[j][e] + v[e];
+                        hb[e] = f32_to_bf16(x4[e]);
+                        const float r = bf16_to_f32(hb[e]);
+                        rs += r; rq += r * r;
+                    }
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + ncol) = x4;
+                    uint2 pk;
+                    pk.x = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+                    pk.y = (unsigned)hb[2] | ((unsigned)hb[3] << 16);
+                    *reinterpret_cast<uint2*>(g.resid_pk + packed_off(m, ncol, g.c_packed_mb)) = pk;
+                }
+#pragma unroll
+                for (int off = 4; off > 0; off >>= 1) { rs += __shfl_xor(rs, off, 64); rq += __shfl_xor(rq, off, 64); }   // 8 lanes share row m
+                if (live && n == 0 && m < g.c_packed_mb * 32) {
+                    float* pp = g.resid_parts + ((size_t)(ntile0 + t) * (g.c_packed_mb * 32) + m) * 2;
+                    pp[0] = rs; pp[1] = rq;
+                }
+                continue;
+            }
+            if (!row_ok) continue;
+            if (g.store == STORE_QKV) {
+                const int nn = ncol - qkv_part_local * g.qkv_D;
+                long long row = m;
+                if (qkv_part > 0) row = (m / g.rows_per_group) * g.group_stride + m % g.rows_per_group + g.row_offset + qkv_row_dev;
+                st4<TC>(qkv_base + row * g.ldc + nn, v);
+                if (qkv_vcopy) st4<bf16_t>(qkv_vcopy + packed_off(m, nn, g.c_packed_mb), v);
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
+            if (g.store == STORE_PACKED) st4<TC>(reinterpret_cast<TC*>(g.C) + packed_off(m, ncol, g.c_packed_mb), v);
+            else st4<TC>(reinterpret_cast<TC*>(g.C) + (long long)m * g.ldc + ncol, v);
+        }
+    } else
     for (int o = threadIdx.x; o < TILE; o += NW * 64) {
         const int n = o & 31, ml = (o >> 5) & 31, blk = o >> 10;
         const int mb = blk % MBW, t = blk / MBW;
         const int m = (mb0 + mb) * 32 + ml;
-        float s = red[o];
+        const int op = (blk * 32 + ml) * RP + n;
+        float s = red[op];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) s += red[(size_t)w * TILE + o];
+        for (int w = 1; w < NW; ++w) s += red[(size_t)w * TILE_P + op];
         const int ncol = (ntile0 + t) * 32 + n;
         if (g.ln_parts) s = lnstat[2 * (mb * 32 + ml) + 1] * (s - lnstat[2 * (mb * 32 + ml)] * g.ln_colsum[ncol]);
         if (g.store == STORE_RESID && S == 1) {
@@ -362,7 +454,7 @@ bool stream_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
 
 template <int MBW, int NT, int NW, int U, typename TC>
 static hipError_t launch_stream_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
-    const size_t smem = (size_t)NW * NT * MBW * 4096 + (size_t)MBW * 256 + (size_t)NW * 512;
+    const size_t smem = stream_gemm_lds(MBW, NT, NW);
     const dim3 grid(g.N / (32 * NT), g.a_packed_mb / MBW, S);
     stream_gemm_kernel<MBW, NT, NW, U, TC><<<grid, NW * 64, smem, st>>>(g, reinterpret_cast<const u32x4*>(wpk), slabs);
     return hipGetLastError();
@@ -429,7 +521,7 @@ hipError_t stream_gemm_configure() {
     hipError_t e;
 #define CFG(MBW, NT, NW, U, TC)                                                                                    \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, TC>),                 \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)NW * NT * MBW * 4096 + (size_t)MBW * 256 + (size_t)NW * 512));      \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_gemm_lds(MBW, NT, NW));      \
     if (e != hipSuccess) return e;
     STREAM_CASES(CFG, bf16_t)
     STREAM_CASES(CFG, float)

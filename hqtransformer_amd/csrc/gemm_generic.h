@@ -81,6 +81,18 @@ struct ALoader {
     }
 };
 
+// four consecutive outputs at once: 16 B (fp32) or 8 B (bf16); p must be aligned accordingly
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    uint2 pk;
+    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = pk;
+}
+
 template <typename TC>
 __device__ __forceinline__ void gemm_store(const GemmArgs& g, int bz, int m, int n, float v) {
     v *= g.alpha;
