@@ -629,7 +629,7 @@ static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float*
     CHK(run_linear(h, c.md, g, bw.qkv, adt, adt, c.st, "gemm_qkv"));
     {
         Timed t(h, "attention", c.st);
-        AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, adt, pk};
+        AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, adt, pk, nullptr};
         HIPCHK(launch_attention(a, c.st));
     }
     g = GemmArgs{};
@@ -680,7 +680,7 @@ static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, fl
     } else {
         CHK(run_linear(h, c.md, g, bw.qkv, DT_BF16, DT_BF16, c.st, "gemm_qkv"));
         Timed t(h, "attention", c.st);
-        AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, DT_BF16, pk};
+        AttnArgs a{h->qbuf, kc, vc, h->abuf, c.B, Tq, h->cfg.n_heads, D / h->cfg.n_heads, Tcache, t_base, t_base_dev, causal, DT_BF16, pk, nullptr};
         HIPCHK(launch_attention(a, c.st));
     }
     g = GemmArgs{};

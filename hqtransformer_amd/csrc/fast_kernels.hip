@@ -125,6 +125,8 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     bool sv_loaded = false;
     const float2* sbase = reinterpret_cast<const float2*>(g.ln_parts ? (const void*)g.ln_parts : g.A) + (blockIdx.y * ROWS + threadIdx.x % ROWS);
     const int snp = g.ln_parts ? g.ln_nparts : 1;
+    // KV-cache row of this step (device-side step state): fetched first, consumed in the epilogue
+    const int qkv_row_dev = (g.store == STORE_QKV && g.row_offset_dev) ? *g.row_offset_dev : 0;
     const int ntile0 = blockIdx.x * NT;
     const int mb0 = blockIdx.y * MBW;
     const int MB = g.a_packed_mb;
@@ -288,7 +290,6 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     const int qkv_part = qkv_part_local + g.qkv_first;
     TC* const qkv_base = reinterpret_cast<TC*>(qkv_part == 0 ? g.C : (qkv_part == 1 ? g.C2 : g.C3));
     bf16_t* const qkv_vcopy = (g.store == STORE_QKV && qkv_part == 2) ? g.qkv_v_pk : nullptr;
-    const int qkv_row_dev = (g.store == STORE_QKV && g.row_offset_dev) ? *g.row_offset_dev : 0;
     if (vec_epi) {
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {

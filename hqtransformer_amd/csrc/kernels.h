@@ -70,6 +70,7 @@ struct AttnArgs {
     int causal;                  // 1: query i sees keys [0, t_base + i]; 0: all t_base + Tq keys
     int dtype;                   // DT_* of q / cache / out
     int out_packed_mb;           // > 0: write out in the packed_off() layout
+    long long* dbg;              // tools/micro only: per-wave clock stamps (NULL in the product)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
 

@@ -244,13 +244,18 @@ template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (
     for (int i = 0; i < 4; ++i) { v[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); v[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
 }
 
+// One wave per (sample, head, query).  hs / 8 adjacent lanes ("chunks") cover one key / value row with 16-byte vectors,
+// so a pass handles 64 / chunks rows and PB passes are fetched together (one memory round trip for K AND V of up to
+// 64 keys at hs = 64).  Scores, probabilities and the output accumulator stay in registers: a group's score is
+// xor-reduced over its chunk lanes (every lane of the group ends up with it), the running maximum / sum are reduced
+// across the row slots, and further key groups are folded in with the online-softmax rescaling.  No LDS, no barriers.
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* ps = reinterpret_cast<float*>(smem_raw) + wave * a.Tmax;      // [Tmax] scores / probabilities of this wave
     const int gid = blockIdx.x * 4 + wave;
     if (gid >= a.B * a.n_heads * a.Tq) return;
+    long long stamp[5];
+    if (a.dbg) stamp[0] = clock64();
     const int qi = gid % a.Tq;
     const int h = (gid / a.Tq) % a.n_heads;
     const int b = gid / (a.Tq * a.n_heads);
@@ -258,13 +263,13 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int chunks = hs >> 3;                  // lanes per row (power of two: hs in {8,16,32,64,128,256})
     const int rows_per_pass = 64 / chunks;
     const int c = lane % chunks, slot = lane / chunks;
-    const int tb = a.t_base + (a.t_base_dev ? *a.t_base_dev : 0);
-    const int nkeys = a.causal ? tb + qi + 1 : tb + a.Tq;
     const T* q = reinterpret_cast<const T*>(a.q) + ((long long)(b * a.Tq + qi)) * D + h * hs + c * 8;
     const T* kc = reinterpret_cast<const T*>(a.kcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
     const T* vc = reinterpret_cast<const T*>(a.vcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
     float qv[8];
-    ld8<T>(q, qv);
+    ld8<T>(q, qv);                               // independent of the step state: in flight while t_base arrives
+    const int tb = a.t_base + (a.t_base_dev ? *a.t_base_dev : 0);
+    const int nkeys = a.causal ? tb + qi + 1 : tb + a.Tq;
     const float scale = 1.0f / sqrtf((float)hs);
     typedef typename std::conditional<sizeof(T) == 2, uint4, float4>::type raw_t;     // 16-B vector of the cache dtype
     constexpr int NRAW = sizeof(T) == 2 ? 1 : 2, PB = 8;                               // passes whose loads are issued together
@@ -279,81 +284,62 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
         }
     };
-    float lmax = -INFINITY;
-    // The value rows of the first key group are fetched together with its key rows (they do not depend on the
-    // scores): one memory round trip instead of two on the decode path (<= rows_per_pass * PB keys).
-    raw_t vfirst[PB][NRAW];
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-        const int j = min(p * rows_per_pass + slot, nkeys - 1);
-        const raw_t* src = reinterpret_cast<const raw_t*>(vc + (long long)j * D);
-#pragma unroll
-        for (int e = 0; e < NRAW; ++e) vfirst[p][e] = src[e];
-    }
-    for (int j0 = 0; j0 < nkeys; j0 += rows_per_pass * PB) {
-        raw_t buf[PB][NRAW];
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {                                  // unconditional (clamped) loads: all in flight at once
-            const int j = min(j0 + p * rows_per_pass + slot, nkeys - 1);
-            const raw_t* src = reinterpret_cast<const raw_t*>(kc + (long long)j * D);
-#pragma unroll
-            for (int e = 0; e < NRAW; ++e) buf[p][e] = src[e];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int j = j0 + p * rows_per_pass + slot;
-            float kv[8];
-            unpack(buf[p], kv);
-            float sc = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sc = fmaf(qv[i], kv[i] * scale, sc);          // scale on K, as layers.py:102
-            for (int off = chunks >> 1; off > 0; off >>= 1) sc += __shfl_xor(sc, off, 64);
-            if (j < nkeys) {
-                if (c == 0) ps[j] = sc;
-                lmax = fmaxf(lmax, sc);
-            }
-        }
-    }
-    lmax = wave_reduce(lmax, OpMax());
-    __builtin_amdgcn_wave_barrier();
-    float lsum = 0.0f;
-    for (int j = lane; j < nkeys; j += 64) { const float e = expf(ps[j] - lmax); ps[j] = e; lsum += e; }
-    lsum = wave_reduce(lsum, OpAdd());
-    for (int j = lane; j < nkeys; j += 64) ps[j] = ps[j] / lsum;
-    __builtin_amdgcn_wave_barrier();
+    float run_max = -INFINITY, run_sum = 0.0f;   // identical in every lane after each group
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
     for (int j0 = 0; j0 < nkeys; j0 += rows_per_pass * PB) {
-        raw_t buf[PB][NRAW];
-        if (j0 == 0) {
+        raw_t kbuf[PB][NRAW], vbuf[PB][NRAW];
 #pragma unroll
-            for (int p = 0; p < PB; ++p)
+        for (int p = 0; p < PB; ++p) {                                  // unconditional (clamped) loads: all in flight at once
+            const long long j = min(j0 + p * rows_per_pass + slot, nkeys - 1);
+            const raw_t* ks = reinterpret_cast<const raw_t*>(kc + j * D);
+            const raw_t* vs = reinterpret_cast<const raw_t*>(vc + j * D);
 #pragma unroll
-                for (int e = 0; e < NRAW; ++e) buf[p][e] = vfirst[p][e];
-        } else {
-#pragma unroll
-            for (int p = 0; p < PB; ++p) {
-                const int j = min(j0 + p * rows_per_pass + slot, nkeys - 1);
-                const raw_t* src = reinterpret_cast<const raw_t*>(vc + (long long)j * D);
-#pragma unroll
-                for (int e = 0; e < NRAW; ++e) buf[p][e] = src[e];
-            }
+            for (int e = 0; e < NRAW; ++e) { kbuf[p][e] = ks[e]; vbuf[p][e] = vs[e]; }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.dbg && j0 == 0) { stamp[1] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+        float sc[PB];
+        float gmax = -INFINITY;
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int j = j0 + p * rows_per_pass + slot;
-            float vv[8];
-            unpack(buf[p], vv);
-            const float pj = j < nkeys ? ps[j] : 0.0f;
+            float kv[8];
+            unpack(kbuf[p], kv);
+            float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = fmaf(pj, vv[i], acc[i]);
+            for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kv[i] * scale, s);            // scale on K, as layers.py:102
+            for (int off = chunks >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            sc[p] = (j0 + p * rows_per_pass + slot < nkeys) ? s : -INFINITY;
+            gmax = fmaxf(gmax, sc[p]);
         }
+        for (int off = chunks; off < 64; off <<= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));     // across the row slots
+        if (a.dbg && j0 == 0) stamp[2] = clock64();
+        const float new_max = fmaxf(run_max, gmax);                     // finite: key j0 is always valid
+        const float rescale = expf(run_max - new_max);                  // 0 for the first group (run_max = -inf)
+        float gsum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] *= rescale;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const float e = expf(sc[p] - new_max);                      // 0 for masked rows
+            gsum += e;
+            float vv[8];
+            unpack(vbuf[p], vv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(e, vv[i], acc[i]);
+        }
+        for (int off = chunks; off < 64; off <<= 1) gsum += __shfl_xor(gsum, off, 64);
+        run_sum = run_sum * rescale + gsum;
+        run_max = new_max;
+        if (a.dbg && j0 == 0) stamp[3] = clock64();
     }
     for (int off = chunks; off < 64; off <<= 1)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off, 64);
+    const float inv = 1.0f / run_sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] *= inv;
     if (slot == 0) {
         const int row = b * a.Tq + qi, col = h * hs + c * 8;
         T* o = a.out_packed_mb ? reinterpret_cast<T*>(a.out) + packed_off(row, col, a.out_packed_mb)
@@ -370,14 +356,18 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             for (int i = 0; i < 8; ++i) st1<T>(o + i, acc[i]);
         }
     }
+    if (a.dbg && lane == 0) {
+        stamp[4] = clock64();
+        long long* d = a.dbg + (long long)gid * 8;
+        d[0] = wall_clock64(); d[1] = stamp[1] - stamp[0]; d[2] = stamp[2] - stamp[0]; d[3] = stamp[3] - stamp[0]; d[4] = stamp[4] - stamp[0];
+    }
 }
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
     const int chunks = a.head_dim / 8;
     if (a.head_dim % 8 != 0 || chunks > 64 || (chunks & (chunks - 1)) != 0) return hipErrorInvalidValue;
-    const size_t smem = (size_t)4 * a.Tmax * sizeof(float);
     const int grid = (a.B * a.n_heads * a.Tq + 3) / 4;
-    if (a.dtype == DT_BF16) attention_kernel<bf16_t><<<grid, 256, smem, st>>>(a);
-    else attention_kernel<float><<<grid, 256, smem, st>>>(a);
+    if (a.dtype == DT_BF16) attention_kernel<bf16_t><<<grid, 256, 0, st>>>(a);
+    else attention_kernel<float><<<grid, 256, 0, st>>>(a);
     return hipGetLastError();
 }
 

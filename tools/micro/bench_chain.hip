@@ -39,7 +39,7 @@ int main() {
     std::vector<bf16_t*> w(nbuf);
     for (auto& p : w) { CK(hipMalloc(&p, (size_t)N * K * 2)); CK(hipMemset(p, 0x3c, (size_t)N * K * 2)); }
     LNArgs ln{x, gam, bet, nullptr, h, M, D, 1, 0, 1e-5f, DT_BF16, 2, nullptr, 0, 0, nullptr, nullptr, 0, nullptr};
-    AttnArgs at{q, kc, vc, o, 64, 1, nh, 64, 128, T - 1, nullptr, 1, DT_BF16, 2};
+    AttnArgs at{q, kc, vc, o, 64, 1, nh, 64, 128, T - 1, nullptr, 1, DT_BF16, 2, nullptr};
     GemmArgs g{};
     g.A = h; g.a_packed_mb = 2; g.M = M; g.N = N; g.K = K; g.batch = 1; g.C = y; g.ldc = N; g.alpha = 1.f; g.store = STORE_ROWS;
     CK(sampler_configure(8192, false));
@@ -81,5 +81,25 @@ int main() {
     }
     t = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_layernorm(ln, st)); CK(launch_attention(at, st)); CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); } });
     printf("LN + attention + GEMM: %.2f us per triple\n", t / n);
+    {   // in-kernel stamps of the attention kernel behind a GEMM (cold caches), by number of keys; device step state like the product
+        long long* dbg; CK(hipMalloc(&dbg, (size_t)64 * nh * 8 * 8));
+        int* tb; CK(hipMalloc(&tb, 4));
+        for (int keys : {1, 8, 32, 64}) {
+            const int tbv = keys - 1;
+            CK(hipMemcpy(tb, &tbv, 4, hipMemcpyHostToDevice));
+            AttnArgs ad = at; ad.t_base = 0; ad.t_base_dev = tb; ad.dbg = dbg;
+            for (int rep = 0; rep < 3; ++rep) { CK(launch_stream_gemm(g, w[rep], DT_BF16, DT_F32, 1, nullptr, st)); CK(launch_attention(ad, st)); }
+            CK(hipStreamSynchronize(st));
+            std::vector<long long> hst((size_t)64 * nh * 8);
+            CK(hipMemcpy(hst.data(), dbg, hst.size() * 8, hipMemcpyDeviceToHost));
+            double s[5] = {0, 0, 0, 0, 0}; long long w0 = hst[0], w1 = hst[0];
+            const int nw = 64 * nh;
+            for (int i = 0; i < nw; ++i) { for (int k = 1; k <= 4; ++k) s[k] += (double)hst[(size_t)i * 8 + k]; w0 = std::min(w0, hst[(size_t)i * 8]); w1 = std::max(w1, hst[(size_t)i * 8]); }
+            AttnArgs plain = at; plain.t_base = keys - 1;
+            const float tt = graph_time(st, 5, [&] { for (int i = 0; i < n; ++i) { CK(launch_attention(plain, st)); CK(launch_stream_gemm(g, w[i], DT_BF16, DT_F32, 1, nullptr, st)); } }) / n - tg;
+            printf("attention %2d keys: %.2f us in the chain; mean cycles from wave start: loads issued %.0f, scores done %.0f, softmax done %.0f, end %.0f; wave ends spread over %.2f us\n",
+                   keys, tt, s[1] / nw, s[2] / nw, s[3] / nw, s[4] / nw, (w1 - w0) / 100.0);
+        }
+    }
     return 0;
 }
