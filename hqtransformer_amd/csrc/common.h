@@ -143,6 +143,11 @@ struct GemmArgs {
     //      (= the predecessor's workgroup count; every workgroup adds 1 to its chain_signal after its last store, behind
     //      an agent-scope release).  Spins are bounded: on give-up chain_err[0] is set and the results are garbage.
     ChainSync chain;
+    // ---- GroupNorm statistics of the OUTPUT, fused into the 3x3 halo conv's epilogue: per-tile partial (sum, sum of
+    //      squares) of the bf16-rounded outputs per group, gn_part_out[((img * tiles_per_img + tile) * gn_out_groups + group) * 2];
+    //      a fixed-order finalize turns them into (mean, rstd).  NULL: not requested.
+    float* gn_part_out;
+    int gn_out_groups;
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

@@ -103,6 +103,8 @@ struct hqt_handle {
     Lin post_quant;
     void* act[4] = {nullptr, nullptr, nullptr, nullptr};   // 3 rotating activation buffers + the normalised/activated copy (FAST)
     double* gn_partial = nullptr;
+    float* gn_tiles = nullptr;                // per-tile output statistics of the last halo conv ([image][tile][32][2])
+    struct { const void* tensor; int tiles; } gn_ready = {nullptr, 0};
     void* zero_page = nullptr;
     size_t act_elems = 0;
     int dec_chunk = 0;
@@ -299,6 +301,9 @@ static int alloc_workspace(hqt_handle* hp) {
             size_t pe = 0;
             for (auto& l : h->dec) pe = std::max(pe, gn_stats_fast_partial_elems(h->dec_chunk, l.res * l.res, l.cin, 32));
             CHK(dev_alloc(h.get(), (void**)&h->gn_partial, pe * sizeof(double), true));
+            size_t te = 0;
+            for (auto& l : h->dec) { const int ro = l.kind == 3 ? 2 * l.res : l.res; te = std::max(te, (size_t)h->dec_chunk * (ro / 8 + 1) * (ro / 16 + 1) * 64); }
+            CHK(dev_alloc(h.get(), (void**)&h->gn_tiles, te * sizeof(float), true));
         }
         const int r = h->dec.front().res;
         size_t attn_c = 0;
@@ -581,7 +586,19 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
             return HQT_OK;
         }
         g.Bw = l.w16;
-        if (mfma_gemm_ok(g, a_dt, DT_BF16, c_dt)) { HIPCHK(launch_mfma_gemm(g, a_dt, DT_BF16, c_dt, st)); return HQT_OK; }
+        if (mfma_gemm_ok(g, a_dt, DT_BF16, c_dt)) {
+            // a 3x3 halo conv also leaves per-tile GroupNorm statistics of its output (every such output is normalised next)
+            if (g.conv_taps == 9 && g.store == STORE_ROWS && h->gn_tiles && conv_halo_ok(g, c_dt) && conv_halo_stats_ok(g.N, 32) &&
+                !getenv("HQT_NO_FUSED_GN")) {
+                g.gn_part_out = h->gn_tiles; g.gn_out_groups = 32;
+                h->gn_ready.tensor = g.C; h->gn_ready.tiles = conv_halo_tiles_per_image(g.H, g.W);
+            } else if (h->gn_ready.tensor == g.C) {
+                h->gn_ready.tensor = nullptr;                           // the tensor is being overwritten by something else
+            }
+            HIPCHK(launch_mfma_gemm(g, a_dt, DT_BF16, c_dt, st));
+            return HQT_OK;
+        }
+        if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
         HIPCHK(launch_gemm_generic(g, a_dt, DT_BF16, c_dt, st));
         return HQT_OK;
     }
@@ -907,6 +924,7 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
     const hqt_config& cf = h->cfg;
     const int adt = md.act_dt();
     const int r = h->dec.front().res, E = cf.s1_embed_dim;
+    h->gn_ready.tensor = nullptr;
     float* gn1 = h->gn;
     float* gn2 = h->gn + (size_t)h->dec_chunk * 64;
     {
@@ -928,7 +946,13 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
     auto norm = [&](const void* src, int C, int hw, float* stats, const float* gamma, const float* beta, int swish,
                     GemmArgs* g) -> int {
         if (md.fast) {
-            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats_fast(src, stats, h->gn_partial, n, hw, C, 32, 1e-6f, st)); }
+            if (h->gn_ready.tensor == src) {     // the producing conv already reduced its tiles: only the fixed-order finalize is left
+                Timed t(h, "gn_stats", st);
+                HIPCHK(launch_gn_finalize_tiles(h->gn_tiles, stats, n, h->gn_ready.tiles, hw, C, 32, 1e-6f, st));
+            } else {
+                Timed t(h, "gn_stats", st);
+                HIPCHK(launch_gn_stats_fast(src, stats, h->gn_partial, n, hw, C, 32, 1e-6f, st));
+            }
             { Timed t(h, "gn_apply", st); HIPCHK(launch_gn_apply(src, tn, stats, gamma, beta, n, hw, C, 32, swish, st)); }
             g->A = tn;
         } else {

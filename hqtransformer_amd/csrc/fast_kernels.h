@@ -24,4 +24,9 @@ hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, in
 // ---- tiled MFMA GEMM / implicit-GEMM conv (decoder, text prefill)
 bool mfma_gemm_ok(const GemmArgs& g, int a_dt, int b_dt, int c_dt);
 hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hipStream_t st);
+// 3x3 halo-tile conv: will launch_mfma_gemm take it for g; can it also emit per-tile GroupNorm statistics of its output
+// (GemmArgs::gn_part_out, [image][tile][group][2] floats); tiles per image
+bool conv_halo_ok(const GemmArgs& g, int c_dt);
+bool conv_halo_stats_ok(int N, int groups);
+int conv_halo_tiles_per_image(int H, int W);
 hipError_t mfma_gemm_configure();

@@ -124,3 +124,5 @@ hipError_t launch_gn_apply(const void* x, void* y, const float* stats, const flo
 hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, int B, int HW, int C, int groups, float eps,
                                 hipStream_t st);
 size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups);
+// statistics from the per-tile partials of a halo conv (fast_kernels.h: conv_halo_stats_ok)
+hipError_t launch_gn_finalize_tiles(const float* partial, float* stats, int B, int tiles, int HW, int C, int groups, float eps, hipStream_t st);

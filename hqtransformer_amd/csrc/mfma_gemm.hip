@@ -603,6 +603,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
         const TC* Rb = reinterpret_cast<const TC*>(g.resid);
         const int c8 = (tid & 15) * 8;                  // 8 consecutive channels per thread, 16 threads per pixel row
         const int nn = n0 + c8;
+        float gs[8], gq[8];                             // fused GroupNorm statistics of this thread's 8 channels x 8 pixels
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
         if (nn < g.N) {                                 // halo_ok(): N % 8 == 0, so a thread's 8 channels are all in or all out
             long long moff[8];
             u32x4 rr[8];
@@ -626,10 +629,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
                 }
                 const u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
                 if (ABL != 5 || o[0] == 0x12345678u) *reinterpret_cast<u32x4*>(Cb + moff[pass]) = o;
+                if (g.gn_part_out) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = bf16_to_f32((bf16_t)(o[e] & 0xffffu)), hi = bf16_to_f32((bf16_t)(o[e] >> 16));
+                        gs[2 * e] += lo; gq[2 * e] += lo * lo; gs[2 * e + 1] += hi; gq[2 * e + 1] += hi * hi;
+                    }
+                }
+            }
+        }
+        if (g.gn_part_out) {                            // uniform branch (kernel argument): barriers are safe here
+            __syncthreads();                            // every staged value has been read
+            float* redw = reinterpret_cast<float*>(lds_raw);                // [16 pixel rows][128 channels][2]; zeros from idle threads
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
+                redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
+            }
+            __syncthreads();
+            const float* red = reinterpret_cast<const float*>(lds_raw);
+            if (tid < 128) {                            // one channel per thread, then its group (cpg consecutive channels = lanes)
+                float sa = 0.0f, sq = 0.0f;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) { sa += red[((rg * 128) + tid) * 2]; sq += red[((rg * 128) + tid) * 2 + 1]; }
+                const int cpg = g.N / g.gn_out_groups;
+                for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
+                const int ch = n0 + tid;
+                if (ch < g.N && (tid & (cpg - 1)) == 0) {
+                    float* pp = g.gn_part_out + (((long long)img * (tiles_x * tiles_y) + trem) * g.gn_out_groups + ch / cpg) * 2;
+                    pp[0] = sa; pp[1] = sq;
+                }
             }
         }
     }
 }
+
+// fused output statistics need whole groups inside a wave: channels per group a power of two <= 64
+bool conv_halo_stats_ok(int N, int groups) {
+    if (groups <= 0 || N % groups != 0) return false;
+    const int cpg = N / groups;
+    return cpg <= 64 && (cpg & (cpg - 1)) == 0 && 128 % cpg == 0;
+}
+int conv_halo_tiles_per_image(int H, int W) { return (H / HALO_TY) * (W / HALO_TX); }
 
 // shapes the halo kernel takes: bf16 3x3 conv, whole 8 x 16 pixel tiles, 64-channel chunks, NHWC bf16 rows that
 // can be stored 16 B at a time (or the fp32 NCHW store of conv_out)
@@ -668,14 +709,22 @@ static hipError_t launch_t(const GemmArgs& g, int c_dt, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hipStream_t st) {
-    (void)a_dt; (void)b_dt;
+static bool big_tile_shape(const GemmArgs& g) {
     const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.batch > 0 ? g.batch : 1);
     static const bool force128 = getenv("HQT_FORCE_TILE128") != nullptr;          // test hook: exercise the big-tile kernels on tiny shapes
     const bool narrow = g.N < 32 && g.M >= 4096 && glds_ok(g);       // conv_out (N = 3): one zero-padded 128-wide n-tile
-    if (narrow || (g.N >= 128 && g.M >= 128 && (tiles128 >= 192 || force128))) {
-        const bool no_halo = getenv("HQT_NO_HALO") != nullptr;                // A/B switch (read per launch): generic implicit GEMM for the 3x3 convs too
-        if (!no_halo && halo_ok(g, c_dt)) {
+    return narrow || (g.N >= 128 && g.M >= 128 && (tiles128 >= 192 || force128));
+}
+// true when launch_mfma_gemm will run the halo-tile kernel for g (the engine asks before requesting fused statistics)
+bool conv_halo_ok(const GemmArgs& g, int c_dt) {
+    const bool no_halo = getenv("HQT_NO_HALO") != nullptr;                    // A/B switch (read per launch): generic implicit GEMM for the 3x3 convs too
+    return big_tile_shape(g) && !no_halo && halo_ok(g, c_dt);
+}
+
+hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hipStream_t st) {
+    (void)a_dt; (void)b_dt;
+    if (big_tile_shape(g)) {
+        if (conv_halo_ok(g, c_dt)) {
             const dim3 grid((g.N + 127) / 128, g.M / (HALO_TY * HALO_TX), 1);
             if (g.store == STORE_NCHW) {
                 if (c_dt == DT_BF16) conv3x3_halo_kernel<bf16_t, true><<<grid, 256, HALO_LDS, st>>>(g);
