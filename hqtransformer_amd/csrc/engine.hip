@@ -591,7 +591,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
             if (g.conv_taps == 9 && g.store == STORE_ROWS && h->gn_tiles && conv_halo_ok(g, c_dt) && conv_halo_stats_ok(g.N, 32) &&
                 !getenv("HQT_NO_FUSED_GN")) {
                 g.gn_part_out = h->gn_tiles; g.gn_out_groups = 32;
-                h->gn_ready.tensor = g.C; h->gn_ready.tiles = conv_halo_tiles_per_image(g.H, g.W);
+                h->gn_ready.tensor = g.C; h->gn_ready.tiles = conv_halo_tiles_per_image(g);
             } else if (h->gn_ready.tensor == g.C) {
                 h->gn_ready.tensor = nullptr;                           // the tensor is being overwritten by something else
             }

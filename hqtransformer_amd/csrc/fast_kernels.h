@@ -28,5 +28,5 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
 // (GemmArgs::gn_part_out, [image][tile][group][2] floats); tiles per image
 bool conv_halo_ok(const GemmArgs& g, int c_dt);
 bool conv_halo_stats_ok(int N, int groups);
-int conv_halo_tiles_per_image(int H, int W);
+int conv_halo_tiles_per_image(const GemmArgs& g);
 hipError_t mfma_gemm_configure();

@@ -415,47 +415,46 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
 // buffers) to write full 256-B NHWC rows with 16-B stores per lane instead of 64 two-byte stores.
 // LDS: patch 2 x 184 rows + filters 2 x 128 rows, 128 B each = 78 KiB -> two workgroups per CU.
 // ---------------------------------------------------------------------------------------------
-constexpr int HALO_TY = 8, HALO_TX = 16, HALO_PITCH = HALO_TX + 2, HALO_ROWS = (HALO_TY + 2) * HALO_PITCH;   // 180
-constexpr int HALO_PIECES = (HALO_ROWS + 7) / 8;                                                             // 23 DMA pieces of 8 rows
-constexpr int HALO_PATCH_BYTES = HALO_PIECES * 8 * 128, HALO_B_BYTES = 128 * 128;
-constexpr int HALO_LDS = 2 * HALO_PATCH_BYTES + 2 * HALO_B_BYTES;
-constexpr int HALO_CPITCH = 128 * 4 + 16;                                                                    // fp32 staging row (bytes)
-static_assert(128 * HALO_CPITCH <= HALO_LDS, "epilogue staging must fit in the operand buffers");
+constexpr int HALO_TX = 16, HALO_PITCH = HALO_TX + 2;
+constexpr int halo_rows(int TY) { return (TY + 2) * HALO_PITCH; }                        // 180 | 324
+constexpr int halo_pieces(int TY) { return (halo_rows(TY) + 7) / 8; }                   // 23 | 41 DMA pieces of 8 rows
+constexpr int halo_patch_bytes(int TY) { return halo_pieces(TY) * 1024; }
+constexpr int halo_npatch(int TY) { return TY == 8 ? 2 : 1; }                           // 16-row tiles keep ONE patch buffer (LDS)
+constexpr int HALO_B_BYTES = 128 * 128;
+constexpr int halo_lds(int TY) { return halo_npatch(TY) * halo_patch_bytes(TY) + 2 * HALO_B_BYTES; }   // 79872 | 74752: two workgroups per CU
+constexpr int HALO_CPITCH = 128 * 4 + 16;                                              // fp32 staging row (bytes)
+static_assert(128 * HALO_CPITCH <= halo_lds(8) && 128 * HALO_CPITCH <= halo_lds(16), "epilogue staging must fit in the operand buffers");
 
-template <typename TC, bool NCHW, int ABL = 0>
+// TY = 8: 8 x 16 pixel tile (128 pixels, each wave 64 pixels x 64 channels), both operand kinds double-buffered.
+// TY = 16: 16 x 16 pixel tile (256 pixels, each wave 128 x 64: twice the MFMAs per barrier and per DMA'd filter
+//          byte, 0.75 instead of 1 fragment read per MFMA); the 324-row patch is single-buffered and re-filled
+//          between channel chunks (the other workgroup of the CU covers that gap); the epilogue stages two halves.
+template <typename TC, bool NCHW, int TY, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
+    constexpr int ROWS = halo_rows(TY), PIECES = halo_pieces(TY), NPATCH = halo_npatch(TY), PATCH_BYTES = halo_patch_bytes(TY);
+    constexpr int FI = TY / 4;                                      // 32-pixel fragments per wave (2 | 4)
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    auto PATCH = [&](int s) -> char* { return lds_raw + (size_t)s * HALO_PATCH_BYTES; };
-    auto BT = [&](int s) -> char* { return lds_raw + 2 * HALO_PATCH_BYTES + (size_t)s * HALO_B_BYTES; };
+    auto PATCH = [&](int s) -> char* { return lds_raw + (size_t)s * PATCH_BYTES; };
+    auto BT = [&](int s) -> char* { return lds_raw + NPATCH * PATCH_BYTES + (size_t)s * HALO_B_BYTES; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
     const int n0 = tile_n * 128;
-    const int tiles_x = g.W / HALO_TX, tiles_y = g.H / HALO_TY;
+    const int tiles_x = g.W / HALO_TX, tiles_y = g.H / TY;
     const int img = tile_m / (tiles_x * tiles_y);
     const int trem = tile_m - img * (tiles_x * tiles_y);
-    const int ty0 = (trem / tiles_x) * HALO_TY, tx0 = (trem % tiles_x) * HALO_TX;
+    const int ty0 = (trem / tiles_x) * TY, tx0 = (trem % tiles_x) * HALO_TX;
     const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
     const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A);
     const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(g.Bw);
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g.zero_page);
 
     // ---- DMA sources.  Patch piece p = wave + 4 t fills patch rows 8 p .. 8 p + 7; lane -> (row q, slot lane & 7),
-    //      source chunk = slot ^ ((q >> 1) & 7) (the same involution the fragment reads apply).
-    constexpr int PPW = (HALO_PIECES + 3) / 4;                      // pieces per wave (6; the last wave has 5)
-    const bf16_t* psrc[PPW];
-#pragma unroll
-    for (int t = 0; t < PPW; ++t) {
-        const int q = (wave + 4 * t) * 8 + (lane >> 3);
-        const int qy = q / HALO_PITCH, qx = q - qy * HALO_PITCH;
-        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
-        const int ch = ((lane & 7) ^ ((q >> 1) & 7)) * 8;
-        psrc[t] = (q < HALO_ROWS && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-                      ? Abase + (((long long)img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * g.Cin + ch
-                      : nullptr;
-    }
+    //      source chunk = slot ^ ((q >> 1) & 7) (the same involution the fragment reads apply).  The addresses are
+    //      rebuilt per channel chunk (once per nine k-tiles) instead of being held in registers.
+    constexpr int PPW = (PIECES + 3) / 4;                           // pieces per wave
     const bf16_t* brow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -466,8 +465,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
     auto issue_patch = [&](int c, int s) {
 #pragma unroll
         for (int t = 0; t < PPW; ++t) {
-            if (wave + 4 * t < HALO_PIECES) {                       // wave-uniform
-                const bf16_t* src = psrc[t] ? psrc[t] + c * 64 : zero;
+            if (wave + 4 * t < PIECES) {                            // wave-uniform
+                const int q = (wave + 4 * t) * 8 + (lane >> 3);
+                const int qy = (q * 3641) >> 16, qx = q - qy * HALO_PITCH;          // q / 18 for q < 328
+                const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+                const int ch = ((lane & 7) ^ ((q >> 1) & 7)) * 8;
+                const bf16_t* src = (q < ROWS && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                                        ? Abase + (((long long)img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * g.Cin + ch + c * 64
+                                        : zero;
                 char* dst = PATCH(s) + (wave + 4 * t) * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -484,18 +489,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
         }
     };
 
-    f32x16 acc[2][2];                                               // [pixel block i][channel block j]
+    f32x16 acc[FI][2];                                              // [pixel block i][channel block j]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // pixel of this lane in fragment i: tile row wm * 64 + i * 32 + fr -> (py, px); patch row of tap (0, 0)
-    int qbase[2];
+    // pixel of this lane in fragment i: tile row (wm TY/2 + 2 i + fr / 16, fr % 16); patch row of tap (0, 0)
+    int qbase[FI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) qbase[i] = (wm * 4 + i * 2 + (fr >> 4)) * HALO_PITCH + (fr & 15);
+    for (int i = 0; i < FI; ++i) qbase[i] = (wm * (TY / 2) + i * 2 + (fr >> 4)) * HALO_PITCH + (fr & 15);
     int brd[2];                                                     // filter fragment rows
 #pragma unroll
     for (int j = 0; j < 2; ++j) brd[j] = wn * 64 + j * 32 + fr;
@@ -503,19 +508,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
     auto compute = [&](int ps, int bs, int tapoff) {
         const char* Pb = PATCH(ps);
         const char* Bb = BT(bs);
-        int qa[2], sw[2];
+        int qa[FI], sw[FI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { qa[i] = (qbase[i] + tapoff) * 128; sw[i] = ((qbase[i] + tapoff) >> 1) & 7; }
+        for (int i = 0; i < FI; ++i) { qa[i] = (qbase[i] + tapoff) * 128; sw[i] = ((qbase[i] + tapoff) >> 1) & 7; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 2 + fh;
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[FI], bfr[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Pb + qa[i] + ((c ^ sw[i]) << 4));
+            for (int i = 0; i < FI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Pb + qa[i] + ((c ^ sw[i]) << 4));
 #pragma unroll
             for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + brd[j] * 128 + ((c ^ ((brd[j] >> 1) & 7)) << 4));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
@@ -529,22 +534,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
     issue_b(0, 0);
     __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
     int kt = 0;
+#pragma unroll 1
     for (int c = 0; c < NC; ++c) {
-        for (int tap = 0; tap < 9; ++tap, ++kt) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++kt) {               // rolled: unrolled nine-fold the LDS addresses alone cost > 100 VGPRs
             if (kt + 1 < KT && ABL != 2) {
                 const int tn = tap == 8 ? 0 : tap + 1, cn = tap == 8 ? c + 1 : c;
                 issue_b(tn * g.Cin + cn * 64, (kt + 1) & 1);
-                if (tap == 0 && c + 1 < NC) issue_patch(c + 1, (c + 1) & 1);
+                if (NPATCH == 2 && tap == 0 && c + 1 < NC) issue_patch(c + 1, (c + 1) & 1);
             }
             const int t3 = (tap * 11) >> 5;            // tap / 3 for tap < 9
-            if (ABL != 3 || kt == 0) compute(c & 1, kt & 1, t3 * HALO_PITCH + (tap - 3 * t3));
+            if (ABL != 3 || kt == 0) compute(NPATCH == 2 ? (c & 1) : 0, kt & 1, t3 * HALO_PITCH + (tap - 3 * t3));
+            __syncthreads();
+        }
+        if (NPATCH == 1 && c + 1 < NC && ABL != 2) {   // every wave is past its last read of the patch: refill it in place
+            issue_patch(c + 1, 0);
             __syncthreads();
         }
     }
     if (ABL == 1) {
         float sacc = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -558,9 +569,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
         TC* Cb = reinterpret_cast<TC*>(g.C);
         const long long hw = (long long)g.H * g.W;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = wm * 64 + i * 32 + fr;
-            const long long pix = (long long)(ty0 + (r >> 4)) * g.W + tx0 + (r & 15);
+        for (int i = 0; i < FI; ++i) {
+            const int py = wm * (TY / 2) + i * 2 + (fr >> 4);
+            const long long pix = (long long)(ty0 + py) * g.W + tx0 + (fr & 15);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -574,45 +585,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
         }
         return;
     }
+    // Staged store, 128 pixels (8 tile rows = the pixels of one wave row wm) at a time: fp32 tile through the dead operand
+    // buffers, then full 256-B NHWC rows with 16-B stores per lane.
     char* stage = lds_raw;                              // [128 pixels][HALO_CPITCH] fp32; every operand read is behind the last barrier
-    if (ABL == 6) { float sacc = 0.0f;
+    TC* Cb = reinterpret_cast<TC*>(g.C);
+    const TC* Rb = reinterpret_cast<const TC*>(g.resid);
+    const int c8 = (tid & 15) * 8;                      // 8 consecutive channels per thread, 16 threads per pixel row
+    const int nn = n0 + c8;
+    float gs[8], gq[8];                                 // fused GroupNorm statistics of this thread's channels
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+    constexpr int HALVES = TY / 8;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+    for (int half = 0; half < HALVES; ++half) {
+        if (half > 0) __syncthreads();                  // the previous half has been read back
+        if (ABL != 6 && (HALVES == 1 || wm == half)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc; }
-    if (ABL != 6)
+            for (int i = 0; i < FI; ++i) {
+                const int r = (HALVES == 1 ? wm * 64 : 0) + i * 32 + fr;           // pixel within the staged 128
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wm * 64 + i * 32 + fr;
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int nl = wn * 64 + j * 32 + 8 * q4 + 4 * fh;
-                const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
-                *reinterpret_cast<f32x4*>(stage + r * HALO_CPITCH + nl * 4) = v;
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int nl = wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                        const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                        *reinterpret_cast<f32x4*>(stage + r * HALO_CPITCH + nl * 4) = v;
+                    }
             }
-    }
-    __syncthreads();
-    if (ABL == 7) return;
-    {
-        TC* Cb = reinterpret_cast<TC*>(g.C);
-        const TC* Rb = reinterpret_cast<const TC*>(g.resid);
-        const int c8 = (tid & 15) * 8;                  // 8 consecutive channels per thread, 16 threads per pixel row
-        const int nn = n0 + c8;
-        float gs[8], gq[8];                             // fused GroupNorm statistics of this thread's 8 channels x 8 pixels
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+        }
+        __syncthreads();
+        if (ABL == 7) continue;
         if (nn < g.N) {                                 // halo_ok(): N % 8 == 0, so a thread's 8 channels are all in or all out
             long long moff[8];
             u32x4 rr[8];
 #pragma unroll
             for (int pass = 0; pass < 8; ++pass) {      // residual rows first: eight 16-B loads in flight, not one per pass
                 const int r = pass * 16 + (tid >> 4);
-                moff[pass] = (pix0 + (long long)(r >> 4) * g.W + (r & 15)) * g.ldc + nn;
+                moff[pass] = (pix0 + (long long)(half * 8 + (r >> 4)) * g.W + (r & 15)) * g.ldc + nn;
                 if (Rb) rr[pass] = *reinterpret_cast<const u32x4*>(Rb + moff[pass]);
             }
 #pragma unroll
@@ -632,33 +641,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
                 if (g.gn_part_out) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float lo = bf16_to_f32((bf16_t)(o[e] & 0xffffu)), hi = bf16_to_f32((bf16_t)(o[e] >> 16));
-                        gs[2 * e] += lo; gq[2 * e] += lo * lo; gs[2 * e + 1] += hi; gq[2 * e + 1] += hi * hi;
+                        const float rl = bf16_to_f32((bf16_t)(o[e] & 0xffffu)), rh = bf16_to_f32((bf16_t)(o[e] >> 16));
+                        gs[2 * e] += rl; gq[2 * e] += rl * rl; gs[2 * e + 1] += rh; gq[2 * e + 1] += rh * rh;
                     }
                 }
             }
         }
-        if (g.gn_part_out) {                            // uniform branch (kernel argument): barriers are safe here
-            __syncthreads();                            // every staged value has been read
-            float* redw = reinterpret_cast<float*>(lds_raw);                // [16 pixel rows][128 channels][2]; zeros from idle threads
+    }
+    if (g.gn_part_out && ABL != 7) {                    // uniform branch (kernel argument): barriers are safe here
+        __syncthreads();                                // every staged value has been read
+        float* redw = reinterpret_cast<float*>(lds_raw);                    // [16 pixel rows][128 channels][2]; zeros from idle threads
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
-                redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
-            }
-            __syncthreads();
-            const float* red = reinterpret_cast<const float*>(lds_raw);
-            if (tid < 128) {                            // one channel per thread, then its group (cpg consecutive channels = lanes)
-                float sa = 0.0f, sq = 0.0f;
+        for (int e = 0; e < 8; ++e) {
+            redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
+            redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
+        }
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(lds_raw);
+        if (tid < 128) {                                // one channel per thread, then its group (cpg consecutive channels = lanes)
+            float sa = 0.0f, sq = 0.0f;
 #pragma unroll
-                for (int rg = 0; rg < 16; ++rg) { sa += red[((rg * 128) + tid) * 2]; sq += red[((rg * 128) + tid) * 2 + 1]; }
-                const int cpg = g.N / g.gn_out_groups;
-                for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
-                const int ch = n0 + tid;
-                if (ch < g.N && (tid & (cpg - 1)) == 0) {
-                    float* pp = g.gn_part_out + (((long long)img * (tiles_x * tiles_y) + trem) * g.gn_out_groups + ch / cpg) * 2;
-                    pp[0] = sa; pp[1] = sq;
-                }
+            for (int rg = 0; rg < 16; ++rg) { sa += red[((rg * 128) + tid) * 2]; sq += red[((rg * 128) + tid) * 2 + 1]; }
+            const int cpg = g.N / g.gn_out_groups;
+            for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
+            const int ch = n0 + tid;
+            if (ch < g.N && (tid & (cpg - 1)) == 0) {
+                float* pp = g.gn_part_out + (((long long)img * (tiles_x * tiles_y) + trem) * g.gn_out_groups + ch / cpg) * 2;
+                pp[0] = sa; pp[1] = sq;
             }
         }
     }
@@ -670,14 +679,23 @@ bool conv_halo_stats_ok(int N, int groups) {
     const int cpg = N / groups;
     return cpg <= 64 && (cpg & (cpg - 1)) == 0 && 128 % cpg == 0;
 }
-int conv_halo_tiles_per_image(int H, int W) { return (H / HALO_TY) * (W / HALO_TX); }
+// 16-row tiles when the grid still fills the chip twice over (two workgroups per CU x 256 CUs), else 8-row tiles
+int conv_halo_tile_rows(const GemmArgs& g) {
+    const char* fe = getenv("HQT_HALO_TY");                                          // tuning / test hook (read per launch): 8 or 16
+    const int forced = fe ? atoi(fe) : 0;
+    if (g.H % 16 != 0) return 8;
+    if (forced == 8 || forced == 16) return forced;
+    const long long tiles16 = (long long)(g.M / 256) * ((g.N + 127) / 128);
+    return tiles16 >= 1024 ? 16 : 8;
+}
+int conv_halo_tiles_per_image(const GemmArgs& g) { return (g.H / conv_halo_tile_rows(g)) * (g.W / HALO_TX); }
 
 // shapes the halo kernel takes: bf16 3x3 conv, whole 8 x 16 pixel tiles, 64-channel chunks, NHWC bf16 rows that
 // can be stored 16 B at a time (or the fp32 NCHW store of conv_out)
 static bool halo_ok(const GemmArgs& g, int c_dt) {
     if (g.conv_taps != 9 || !g.zero_page || g.gn_stats || g.a_packed_mb || (g.batch > 1)) return false;
     if (g.Cin % 64 != 0 || g.ldb % 8 != 0 || g.K != 9 * g.Cin) return false;
-    if (g.H % HALO_TY != 0 || g.W % HALO_TX != 0 || g.M % (g.H * g.W) != 0) return false;
+    if (g.H % 8 != 0 || g.W % HALO_TX != 0 || g.M % (g.H * g.W) != 0) return false;
     if (g.act != ACT_NONE) return false;               // swish lives in the GroupNorm pass; keeps the epilogue code small
     if (g.store == STORE_NCHW) return !g.resid;
     return g.store == STORE_ROWS && g.rows_per_group == 0 && c_dt == DT_BF16 && g.ldc % 8 == 0 && g.N % 8 == 0;
@@ -725,13 +743,17 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
     (void)a_dt; (void)b_dt;
     if (big_tile_shape(g)) {
         if (conv_halo_ok(g, c_dt)) {
-            const dim3 grid((g.N + 127) / 128, g.M / (HALO_TY * HALO_TX), 1);
+            const int ty = conv_halo_tile_rows(g);
+            const dim3 grid((g.N + 127) / 128, g.M / (ty * HALO_TX), 1);
+#define LAUNCH_HALO(TC, NCHW_)                                                                              \
+            if (ty == 16) conv3x3_halo_kernel<TC, NCHW_, 16><<<grid, 256, halo_lds(16), st>>>(g);           \
+            else conv3x3_halo_kernel<TC, NCHW_, 8><<<grid, 256, halo_lds(8), st>>>(g);
             if (g.store == STORE_NCHW) {
-                if (c_dt == DT_BF16) conv3x3_halo_kernel<bf16_t, true><<<grid, 256, HALO_LDS, st>>>(g);
-                else conv3x3_halo_kernel<float, true><<<grid, 256, HALO_LDS, st>>>(g);
+                if (c_dt == DT_BF16) { LAUNCH_HALO(bf16_t, true) } else { LAUNCH_HALO(float, true) }
             } else {
-                conv3x3_halo_kernel<bf16_t, false><<<grid, 256, HALO_LDS, st>>>(g);
+                LAUNCH_HALO(bf16_t, false)
             }
+#undef LAUNCH_HALO
             return hipGetLastError();
         }
         if (glds_ok(g)) {
@@ -766,8 +788,11 @@ hipError_t mfma_gemm_configure() {
     CFG(bf16_t, true, 2) CFG(bf16_t, true, 4) CFG(float, true, 2) CFG(float, true, 4)
 #undef CFG
 #define CFGH(TC, NCHW_)                                                                                             \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<TC, NCHW_>),                             \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);                                      \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<TC, NCHW_, 8>),                          \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(8));                                   \
+    if (e != hipSuccess) return e;                                                                                      \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<TC, NCHW_, 16>),                         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(16));                                  \
     if (e != hipSuccess) return e;
     CFGH(bf16_t, false) CFGH(bf16_t, true) CFGH(float, true)
 #undef CFGH

@@ -296,19 +296,27 @@ def test_decode_fast_halo_conv_matches_generic_implicit_gemm():
     r = np.random.default_rng(42)
     ct, cb = r.integers(0, 256, (5, 8, 8)), r.integers(0, 256, (5, 16, 16))
     os.environ['HQT_FORCE_TILE128'] = '1'
+    halo = {}
     try:
         eng = engine_s1(spec, weights, 5)
-        halo = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
+        for ty in ('8', '16'):                      # 8 x 16 and 16 x 16 pixel tiles (the latter: single patch buffer, two-half epilogue)
+            os.environ['HQT_HALO_TY'] = ty
+            halo[ty] = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
+        os.environ['HQT_NO_FUSED_GN'] = '1'         # statistics by the separate pass instead of the conv epilogue
+        unfused = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
         os.environ['HQT_NO_HALO'] = '1'
         generic = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
     finally:
-        os.environ.pop('HQT_NO_HALO', None)
-        del os.environ['HQT_FORCE_TILE128']
+        for k in ('HQT_NO_HALO', 'HQT_HALO_TY', 'HQT_NO_FUSED_GN', 'HQT_FORCE_TILE128'):
+            os.environ.pop(k, None)
     want = O.OracleStage1(spec, weights).decode_code(ct, cb)
-    eh, eg = np.abs(halo - want), np.abs(generic - want)
-    assert eh.max() <= 0.1 and eh.mean() <= 1.25 * eg.mean() + 1e-3, (eh.max(), eh.mean(), eg.mean())
-    d = np.abs(halo - generic)                      # ~1 bf16 ulp of an O(1) pixel on average, no outliers (a wrong tap or border would be O(1))
-    assert d.max() <= 0.06 and d.mean() <= 8e-3, (d.max(), d.mean())
+    eg = np.abs(generic - want)
+    for ty, px in list(halo.items()) + [('16, separate GroupNorm statistics', unfused)]:
+        eh = np.abs(px - want)
+        assert eh.max() <= 0.1 and eh.mean() <= 1.25 * eg.mean() + 1e-3, (ty, eh.max(), eh.mean(), eg.mean())
+        d = np.abs(px - generic)                    # ~1 bf16 ulp of an O(1) pixel on average, no outliers (a wrong tap or border would be O(1))
+        assert d.max() <= 0.06 and d.mean() <= 8e-3, (ty, d.max(), d.mean())
+    assert np.array_equal(halo['8'], halo['16']) or np.abs(halo['8'] - halo['16']).max() <= 0.06
 
 
 def test_decode_batch_chunking_and_ragged():
