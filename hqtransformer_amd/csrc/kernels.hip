@@ -14,7 +14,7 @@ __device__ __forceinline__ T wave_reduce(T v, Op op) {
     return v;
 }
 template <typename T, typename Op>
-__device__ __forceinline__ T block_reduce(T v, Op op, T* scratch /* >= 4 */) {
+__device__ __forceinline__ T block_reduce(T v, Op op, T* scratch /* >= blockDim.x / 64 */) {
     v = wave_reduce(v, op);
     const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
@@ -394,14 +394,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
+// NT threads per logits row: 1024 (16 waves, 4 per SIMD) hides the latency of the exp / log / divide / Philox chains that a
+// lone 4-wave workgroup per CU exposes (25 -> ~10 us per launch at V = 8192); 256 for small vocabularies.
+template <int NT>
+__global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    // layout: double dsum[256]; float redf[4]; int redi[4]; unsigned hist[256]; int sel[4]; float lp[V];
+    // layout: double dsum[NT]; float redf[16]; int redi[16]; unsigned hist[256]; int sel[4]; float lp[V];
     //         (top-p only) float skey[n2]; unsigned short sidx[n2]; unsigned char keep[V]
     double* dsum = reinterpret_cast<double*>(smem_raw);
-    float* redf = reinterpret_cast<float*>(dsum + 256);
-    int* redi = reinterpret_cast<int*>(redf + 4);
-    unsigned* hist = reinterpret_cast<unsigned*>(redi + 4);
+    float* redf = reinterpret_cast<float*>(dsum + NT);
+    int* redi = reinterpret_cast<int*>(redf + 16);
+    unsigned* hist = reinterpret_cast<unsigned*>(redi + 16);
     int* sel = reinterpret_cast<int*>(hist + 256);
     float* lp = reinterpret_cast<float*>(sel + 4);
     const int V = a.V, tid = threadIdx.x;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
     const long long nidx = (((long long)step * 5 + draw) * a.B + b) * V;
 
     // ---- temperature (logits /= T, hierarchical_ar.py:763,779) and raw-logit dump
-    for (int i = tid; i < V; i += 256) {
+    for (int i = tid; i < V; i += NT) {
         const float v = lg[i];
         if (a.logits_out) a.logits_out[nidx + i] = v;
         lp[i] = v / a.temperature;
@@ -428,10 +431,10 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
         uint32_t prefix = 0;
         int remaining = a.top_k;
         for (int shift = 24; shift >= 0; shift -= 8) {
-            hist[tid] = 0;
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const uint32_t himask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
-            for (int i = tid; i < V; i += 256) {
+            for (int i = tid; i < V; i += NT) {
                 const uint32_t o = f2ord(lp[i]);
                 if ((o & himask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
             }
@@ -450,19 +453,19 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
             remaining = sel[1];
             __syncthreads();
         }
-        for (int i = tid; i < V; i += 256)
+        for (int i = tid; i < V; i += NT)
             if (f2ord(lp[i]) < prefix) lp[i] = -INFINITY;
         __syncthreads();
     }
 
     // ---- softmax (fp32): p = exp(l - max) / sum
     float m = -INFINITY;
-    for (int i = tid; i < V; i += 256) m = fmaxf(m, lp[i]);
+    for (int i = tid; i < V; i += NT) m = fmaxf(m, lp[i]);
     m = block_reduce(m, OpMax(), redf);
     float s = 0.0f;
-    for (int i = tid; i < V; i += 256) { const float e = expf(lp[i] - m); lp[i] = e; s += e; }
+    for (int i = tid; i < V; i += NT) { const float e = expf(lp[i] - m); lp[i] = e; s += e; }
     s = block_reduce(s, OpAdd(), redf);
-    for (int i = tid; i < V; i += 256) lp[i] = lp[i] / s;
+    for (int i = tid; i < V; i += NT) lp[i] = lp[i] / s;
     __syncthreads();
 
     // ---- top-p (sampling.py:22-37): descending sort, prefix sums accumulated in double and rounded
@@ -470,14 +473,14 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
     float renorm = 1.0f;
     const bool use_p = a.top_p > 0.0f;
     if (use_p) {
-        for (int i = tid; i < n2; i += 256) {
+        for (int i = tid; i < n2; i += NT) {
             skey[i] = i < V ? lp[i] : -1.0f;
             sidx[i] = (unsigned short)i;
         }
         __syncthreads();
         for (int k2 = 2; k2 <= n2; k2 <<= 1) {
             for (int j = k2 >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < n2; i += 256) {
+                for (int i = tid; i < n2; i += NT) {
                     const int ixj = i ^ j;
                     if (ixj > i) {
                         const float ka = skey[i], kb = skey[ixj];
@@ -490,14 +493,14 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
                 __syncthreads();
             }
         }
-        const int chunk = n2 / 256;
+        const int chunk = (n2 + NT - 1) / NT;
         double local = 0.0;
         for (int c = 0; c < chunk; ++c) { const int j = tid * chunk + c; if (j < V) local += (double)skey[j]; }
         dsum[tid] = local;
         __syncthreads();
         if (tid == 0) {
             double run = 0.0;
-            for (int t = 0; t < 256; ++t) { const double v = dsum[t]; dsum[t] = run; run += v; }
+            for (int t = 0; t < NT; ++t) { const double v = dsum[t]; dsum[t] = run; run += v; }
         }
         __syncthreads();
         double run = dsum[tid];
@@ -510,13 +513,13 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
             }
         }
         first = block_reduce(first, OpMin(), redi);
-        for (int i = tid; i < V; i += 256) keep[i] = 0;
+        for (int i = tid; i < V; i += NT) keep[i] = 0;
         __syncthreads();
-        for (int j = tid; j < V; j += 256)
+        for (int j = tid; j < V; j += NT)
             if (j <= first) keep[sidx[j]] = 1;           // position `first` itself is kept (shifted mask)
         __syncthreads();
         float ks = 0.0f;
-        for (int i = tid; i < V; i += 256) { if (!keep[i]) lp[i] = 0.0f; ks += lp[i]; }
+        for (int i = tid; i < V; i += NT) { if (!keep[i]) lp[i] = 0.0f; ks += lp[i]; }
         renorm = block_reduce(ks, OpAdd(), redf);
         __syncthreads();
     }
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
     const uint64_t seed = a.state->seed;                 // per-call values live in device memory: the captured graph is call-independent
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const uint64_t grow = (uint64_t)(a.state->sample_offset + b);
-    for (int i4 = tid; i4 * 4 < V; i4 += 256) {
+    for (int i4 = tid; i4 * 4 < V; i4 += NT) {
         float q[4];
         if (a.noise) {
 #pragma unroll
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
     if ((tid & 63) == 0) { redf[tid >> 6] = best; redi[tid >> 6] = besti; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < NT / 64; ++w)
             if (redf[w] > best || (redf[w] == best && redi[w] < besti)) { best = redf[w]; besti = redi[w]; }
         a.out[((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
     }
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256) void sampler_kernel(SamplerArgs a, int n2) {
 static size_t sampler_smem(int V, bool use_p, int& n2) {
     n2 = 256;
     while (n2 < V) n2 <<= 1;
-    size_t sz = 256 * sizeof(double) + 4 * sizeof(float) + 4 * sizeof(int) + 256 * sizeof(unsigned) + 4 * sizeof(int) +
+    size_t sz = 1024 * sizeof(double) + 16 * sizeof(float) + 16 * sizeof(int) + 256 * sizeof(unsigned) + 4 * sizeof(int) +
                 (size_t)V * sizeof(float);
     if (use_p) sz += (size_t)n2 * sizeof(float) + (size_t)n2 * sizeof(unsigned short) + (size_t)V;
     return (sz + 15) & ~(size_t)15;
@@ -580,8 +583,11 @@ hipError_t sampler_configure(int V, bool use_top_p) {
     const size_t smem = sampler_smem(V, use_top_p, n2);
     if (smem > 160 * 1024 || (use_top_p && V > 65536)) return hipErrorInvalidValue;
     if (smem > g_sampler_configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<256>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<1024>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         g_sampler_configured = smem;
     }
@@ -591,7 +597,8 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
     int n2;
     const size_t smem = sampler_smem(a.V, a.top_p > 0.0f, n2);
     if (smem > g_sampler_configured) return hipErrorInvalidValue;     // sampler_configure must run first
-    sampler_kernel<<<a.R, 256, smem, st>>>(a, n2);
+    if (a.V >= 4096) sampler_kernel<1024><<<a.R, 1024, smem, st>>>(a, n2);
+    else sampler_kernel<256><<<a.R, 256, smem, st>>>(a, n2);
     return hipGetLastError();
 }
 

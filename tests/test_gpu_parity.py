@@ -222,6 +222,26 @@ def test_imagenet_head_geometry_vs_oracle(B):
         assert err <= 0.1, f'FAST logits differ from the oracle by {err} (B={B}, graph={graph})'
 
 
+@pytest.mark.parametrize('opts', [((None, None), (None, None), (1.0, 1.0)), ((2048, 100), (1.0, 0.9), (0.95, 0.8))])
+def test_full_vocabulary_sampler_vs_oracle(opts):
+    """V = 8192 (the ImageNet vocabulary) takes the 1024-thread sampler: temperature, radix-select top-k, sorted top-p with
+    the double prefix, argmax(p / q) -- codes bit-exact and logits <= 2e-4 against the oracle on a small model."""
+    tk, tp, T = opts
+    spec = Stage2Spec(embed_dim=64, n_layers=1, n_heads=2, n_layers_depth=1, vocab_top=8192, vocab_bot=8192, vocab_txt=64,
+                      ctx_len_img=64, ctx_len_txt=16, n_classes=10, cond=1, embedding=0)
+    weights = synth.stage2_weights(spec, 51, 'fixture')
+    B, n = 3, 3
+    noise = synth.exp_noise(52, n, B, spec.vocab_top)
+    cond = np.array([1, 5, 9])
+    want = O.OracleStage2(spec, weights).sample(cond, B, n, noise, tk, tp, T, return_logits=True)
+    eng = engine_s2(spec, weights, B)
+    for graph in (False, True):
+        ct, cb, lg = eng.sample(B, torch.from_numpy(cond), n, precision=PRECISION_EXACT, top_k=tk, top_p=tp, temperature=T,
+                                noise=torch.from_numpy(noise), return_logits=True, use_graph=graph)
+        assert np.abs(np_(lg) - want[2]).max() <= LOGIT_TOL
+        assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all()
+
+
 # ----------------------------------------------------------------------------------------- stage 1
 def test_decode_64_exact_vs_reference_fixture():
     fx = load('g5_decode_64.npz')
