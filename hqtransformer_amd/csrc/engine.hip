@@ -726,7 +726,9 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     const size_t esz = c.md.act_sz();
     const size_t kv_layer = (size_t)cf.max_batch * h->Tmax * D * esz;
     const int* tb_dev = body_tbase_from_state ? &h->state->t_base : nullptr;
-    const bool dln_body = dln_ok(h, c, h->body[0], B * Tq_body);          // the caller's embedding kernel filled xpk / parts
+    // deferred LayerNorm needs the packed copy + row statistics of x from the caller's embedding kernel: embed_step emits
+    // them (decode steps, Tq = 1); the text prefill's embed_text does not, so the prefill pass takes the classic path
+    const bool dln_body = Tq_body == 1 && dln_ok(h, c, h->body[0], B * Tq_body);
     for (int l = 0; l < cf.n_layers; ++l) {
         void* kc = (char*)h->kcache + l * kv_layer;
         void* vc = (char*)h->vcache + l * kv_layer;

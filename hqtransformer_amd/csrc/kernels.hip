@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LNArgs a) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= a.M) return;
     const int D = a.D;
-    float* x = a.x + ((long long)m * a.in_rows_per_group + a.in_row_offset) * D;
+    const long long in_row = (long long)m * a.in_rows_per_group + a.in_row_offset;      // ln_f of the prefill reads the last token of each sample
+    float* x = a.x + in_row * D;
     constexpr int MAXV = 8;                       // D <= 2048 in registers; wider rows fall back to re-reading
     float4 v[MAXV], gmv[MAXV], btv[MAXV];      // affine parameters are fetched with the row, ahead of the reductions
     float s = 0.0f;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LNArgs a) {
             if (a.n_slabs > 0) {                  // fold in the split-K partial sums (+bias) of the previous GEMM
                 if (a.slab_bias) { const float4 bb = *reinterpret_cast<const float4*>(a.slab_bias + vi * 4); t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
                 for (int sl = 0; sl < a.n_slabs; ++sl) {
-                    const float4 p = *reinterpret_cast<const float4*>(a.slabs + ((long long)sl * a.slab_rows + m) * D + vi * 4);
+                    const float4 p = *reinterpret_cast<const float4*>(a.slabs + ((long long)sl * a.slab_rows + in_row) * D + vi * 4);   // slabs are indexed like x
                     t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
                 }
                 *reinterpret_cast<float4*>(x + vi * 4) = t;

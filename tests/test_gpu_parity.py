@@ -109,6 +109,18 @@ def test_tiny_txt_prefill():
                                 return_logits=True, use_graph=graph)
         assert np.abs(np_(lg)[fx['keep_steps']] - fx['logits']).max() <= LOGIT_TOL
         assert (np_(ct) == fx['codes_top']).all() and (np_(cb) == fx['codes_bot']).all()
+    # FAST arithmetic through the same prefill (bf16, MFMA): teacher-forced on the reference's codes, logits within the
+    # bf16 budget -- on a workspace deliberately filled with NaNs first (a prefill that read a stale packed activation
+    # buffer once passed on freshly zeroed memory)
+    junk = torch.full((64 << 20,), float('nan'), device=dev())
+    del junk
+    eng2 = engine_s2(spec, weights, 4)
+    ft, fb = torch.from_numpy(fx['codes_top'].copy()), torch.from_numpy(fx['codes_bot'].copy())
+    for graph in (False, True):
+        _, _, lf = eng2.sample(B, torch.from_numpy(txt), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise), force_top=ft,
+                               force_bot=fb, return_logits=True, use_graph=graph)
+        err = np.abs(np_(lf)[fx['keep_steps']] - fx['logits']).max()
+        assert err <= 0.15, f'FAST text-conditional logits differ from the reference by {err}'
 
 
 def test_ragged_batches_and_b1_vs_oracle(tiny_cls):

@@ -113,3 +113,25 @@ def test_lanes_share_weights_and_are_bit_identical(model):
     # ownership: the parent handle refuses to go away while a clone lives
     eng = model.stage2.engine(B, n)
     assert eng.lib.hqt_destroy(eng.h) != 0 and b'clone' in eng.lib.hqt_last_error()
+
+
+def test_txt2img_counterpart_writes_reference_format(tmp_path):
+    """sampling_hqmodel_txt2img counterpart on the tiny text-conditional config: synthetic prompt ids, and real captions
+    through the tokenizer front-end (tiny own vocabulary); one pickle of float32 [B, 3, H, W] in [0, 1] per batch."""
+    import json
+    from hqtransformer_amd import sampling_hqmodel_txt2img as st
+    tiny_txt = os.path.join(ROOT, 'configs', 'tiny-txt.yaml')
+    out1 = tmp_path / 'syn'
+    st.main(['-r', str(out1), '-m', tiny_txt, '--batch_size', '2', '--synthetic-prompts', '3', '--top-k', '50'])
+    a = pickle.load(open(out1 / 'samples_(1_2).pkl', 'rb'))
+    b = pickle.load(open(out1 / 'samples_(2_2).pkl', 'rb'))
+    assert a.dtype == np.float32 and a.shape == (2, 3, 64, 64) and b.shape == (1, 3, 64, 64) and a.min() >= 0 and a.max() <= 1
+    vocab = {'[UNK]': 0, 'a</w>': 1, 'c': 2, 'a': 3, 't</w>': 4, 'ca': 5, 'cat</w>': 6, 'd': 7, 'o': 8, 'g</w>': 9, 'do': 10, 'dog</w>': 11}
+    (tmp_path / 'v.json').write_text(json.dumps(vocab))
+    (tmp_path / 'm.txt').write_text('#version: 0.2\nc a\nca t</w>\nd o\ndo g</w>\n')
+    (tmp_path / 'caps.txt').write_text('x.jpg\ta cat\ny.jpg\ta dog\n')
+    out2 = tmp_path / 'cap'
+    st.main(['-r', str(out2), '-m', tiny_txt, '--batch_size', '2', '--captions', str(tmp_path / 'caps.txt'),
+             '--tokenizer-vocab', str(tmp_path / 'v.json'), '--tokenizer-merges', str(tmp_path / 'm.txt'), '--top-k', '50'])
+    c = pickle.load(open(out2 / 'samples_(1_2).pkl', 'rb'))
+    assert c.shape == (2, 3, 64, 64) and np.isfinite(c).all() and np.abs(c[0] - c[1]).max() > 0      # different prompts, different images

@@ -115,3 +115,24 @@ def test_rearrange_codes_matches_einops_fixture():
     fx = load('g6_index_maps.npz')
     gt, gb = rearrange_codes(torch.from_numpy(fx['codes_top']), torch.from_numpy(fx['codes_bot']), 8)
     assert (gt.numpy() == fx['grid_top']).all() and (gb.numpy() == fx['grid_bot']).all()
+
+
+def test_text_front_end(tmp_path):
+    """Tokenizer front-end of the text-conditional path (hqvae/datasets/__init__.py:145-151): lower-casing char-BPE,
+    [PAD] special token, padding and truncation to context_length -- on a tiny own vocabulary (the reference's 16k
+    vocabulary is not copied into this repository)."""
+    import json
+    from hqtransformer_amd import text as T
+    vocab = {'[UNK]': 0, 'a</w>': 1, 'c': 2, 'a': 3, 't</w>': 4, 'ca': 5, 'cat</w>': 6, 'd': 7, 'o': 8, 'g</w>': 9, 'do': 10,
+             'dog</w>': 11, 'n': 12}
+    (tmp_path / 'v.json').write_text(json.dumps(vocab))
+    (tmp_path / 'm.txt').write_text('#version: 0.2\nc a\nca t</w>\nd o\ndo g</w>\n')
+    tok = T.build_tokenizer(str(tmp_path / 'v.json'), str(tmp_path / 'm.txt'), context_length=6)
+    pad = tok.token_to_id('[PAD]')
+    assert pad == 13                                              # appended behind the vocabulary
+    ids = T.encode(tok, ['A cat', 'a dog a cat a dog a cat a dog', 'zzz'])
+    assert ids.dtype == torch.int64 and ids.tolist() == [[1, 6, pad, pad, pad, pad], [1, 11, 1, 6, 1, 11], [0, 0, 0, pad, pad, pad]]
+    (tmp_path / 'val_list.txt').write_text('img/0.jpg\ta cat\nimg/1.jpg\ta dog\n\n')
+    (tmp_path / 'plain.txt').write_text('a cat\na dog\n')
+    assert T.read_captions(str(tmp_path / 'val_list.txt')) == ['a cat', 'a dog'] == T.read_captions(str(tmp_path / 'plain.txt'))
+    assert T.find_reference_vocab(str(tmp_path)) is None
