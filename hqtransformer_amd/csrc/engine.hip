@@ -126,6 +126,10 @@ struct hqt_handle {
 
 static int dev_alloc(hqt_handle* h, void** p, size_t bytes, bool workspace) {
     HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+    // test hook: HQT_POISON_WORKSPACE=1 fills every workspace buffer with 0xFF (NaN as fp32 / bf16, -1 as int64) so that
+    // a read of something no kernel wrote shows up instead of passing on freshly zeroed memory
+    static const bool poison = getenv("HQT_POISON_WORKSPACE") != nullptr;
+    if (poison && workspace && bytes) HIPCHK(hipMemset(*p, 0xFF, bytes));
     h->owned.push_back(*p);
     if (workspace) h->workspace_bytes += bytes;
     return HQT_OK;
