@@ -772,25 +772,28 @@ __global__ void gn_finalize_kernel(const double* partial, float* stats, int nchu
     stats[(long long)bg * 2] = (float)mean;
     stats[(long long)bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
-// (mean, rstd) from the per-tile partials a halo conv left behind: fixed order over the tiles, double accumulation
-__global__ void gn_finalize_tiles_kernel(const float* partial, float* stats, int tiles, int groups, double count, float eps, int n) {
-    const int bg = blockIdx.x * blockDim.x + threadIdx.x;     // b * groups + g
-    if (bg >= n) return;
+// (mean, rstd) from the per-tile partials a halo conv left behind: one wave per (image, group); lane l sums tiles
+// l, l + 64, ... in order and the lanes are combined by the fixed xor tree -> bit-reproducible, double accumulation
+__global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* partial, float* stats, int tiles, int groups, double count, float eps) {
+    const int bg = blockIdx.x;                                  // b * groups + g
     const int b = bg / groups, g = bg % groups;
     double a = 0.0, q = 0.0;
-    for (int t = 0; t < tiles; ++t) {
+    for (int t = threadIdx.x; t < tiles; t += 64) {
         const float* p = partial + (((long long)b * tiles + t) * groups + g) * 2;
         a += (double)p[0];
         q += (double)p[1];
     }
-    const double mean = a / count;
-    const double var = fmax(q / count - mean * mean, 0.0);
-    stats[(long long)bg * 2] = (float)mean;
-    stats[(long long)bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    a = wave_reduce(a, OpAdd());
+    q = wave_reduce(q, OpAdd());
+    if (threadIdx.x == 0) {
+        const double mean = a / count;
+        const double var = fmax(q / count - mean * mean, 0.0);
+        stats[(long long)bg * 2] = (float)mean;
+        stats[(long long)bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 hipError_t launch_gn_finalize_tiles(const float* partial, float* stats, int B, int tiles, int HW, int C, int groups, float eps, hipStream_t st) {
-    const int n = B * groups;
-    gn_finalize_tiles_kernel<<<(n + 63) / 64, 64, 0, st>>>(partial, stats, tiles, groups, (double)HW * (C / groups), eps, n);
+    gn_finalize_tiles_kernel<<<B * groups, 64, 0, st>>>(partial, stats, tiles, groups, (double)HW * (C / groups), eps);
     return hipGetLastError();
 }
 size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups) {
