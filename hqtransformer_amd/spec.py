@@ -31,6 +31,11 @@ class Stage2Spec:
     embedding: int            # EMB_*
     gelu_approx: bool = False
     ratio_bot2top: int = 4
+    levels: int = 2           # code levels: 2 = iHQGPT (1 + 4 codes per position), 3 = HQTransformer 'parallel-add' (1 + 4 + 16)
+
+    @property
+    def codes_per_pos(self) -> int:  # hqtransformer.py:187-194
+        return 1 + 4 + (16 if self.levels == 3 else 0)
 
     @property
     def head_dim(self) -> int:
@@ -55,6 +60,7 @@ class Stage1Spec:
     use_init_downsample: bool = True
     use_mid_block: bool = True
     use_attn: bool = True
+    code_levels: int = 2      # 2 = SimRQGAN2Generator (concat), 3 = HQVAEGenerator (additive pixel-shuffle pyramid)
 
     @property
     def z_res(self) -> int:   # layers.py:330-331
@@ -65,11 +71,20 @@ class Stage1Spec:
 def stage2_spec_from_config(cfg) -> Stage2Spec:
     """Mirrors the argument plumbing of ``ImageGPT2.__init__`` (``hqvae/models/__init__.py:123-137``)."""
     s2 = cfg.stage2
-    if 'hq-transformer' not in s2.type:
+    levels = 2
+    if 'multilevel-hq' in s2.type:          # HQTransformer (hqvae/models/__init__.py:138-145)
+        vs = list(s2.vocab_sizes_img)
+        if len(vs) != 3 or len(set(vs)) != 1:
+            raise NotImplementedError('multilevel-hq: three levels with one vocabulary size are built')
+        if s2.decoding_type != 'parallel-add':
+            raise NotImplementedError(f"decoding_type '{s2.decoding_type}': only 'parallel-add' is built (the released level-3 config)")
+        levels = 3
+    elif 'hq-transformer' not in s2.type:
         raise ValueError(f"stage2.type '{s2.type}' is not on the HQ-Transformer sampling path")
-    model_type = s2.type.split('/')[-1] if '/' in s2.type else 'top2bot'
-    if model_type != 'parallel':
-        raise NotImplementedError(f"model_type '{model_type}': only 'parallel' is built (SURVEY.md §0 item 2)")
+    else:
+        model_type = s2.type.split('/')[-1] if '/' in s2.type else 'top2bot'
+        if model_type != 'parallel':
+            raise NotImplementedError(f"model_type '{model_type}': only 'parallel' is built (SURVEY.md §0 item 2)")
     hp = s2.hparams
     hp_dec = s2.hparams_dec
     if hp_dec is None:  # hierarchical_ar.py:150-153
@@ -78,7 +93,7 @@ def stage2_spec_from_config(cfg) -> Stage2Spec:
         n_layers_depth, dec_dim, dec_heads = hp_dec.n_layers, hp_dec.embed_dim, hp_dec.n_heads
     if dec_dim != hp.embed_dim or dec_heads != hp.n_heads:
         raise NotImplementedError('depth head with its own width is not used by any released config')
-    if hp.embedding_type == 'reduce':
+    if hp.embedding_type == 'reduce' and levels == 2:
         emb = EMB_REDUCE
     elif hp.embedding_type == 'transformer1':
         emb = EMB_TRANSFORMER1
@@ -86,31 +101,37 @@ def stage2_spec_from_config(cfg) -> Stage2Spec:
         raise NotImplementedError(f"embedding_type '{hp.embedding_type}'")
     if hp.position_embedding != '1d' or hp.use_random_order:
         raise NotImplementedError('position_embedding 2d / use_random_order are not used by any released config')
-    if s2.ratio_bot2top != 4:
+    if levels == 2 and s2.ratio_bot2top != 4:
         raise NotImplementedError('ratio_bot2top != 4')
     if not (hp.mlp_bias and hp.attn_bias):
         raise NotImplementedError('bias-free blocks')
     cond = COND_CLS if s2.use_cls_cond else (COND_TXT if s2.use_txt_cond else COND_NONE)
-    return Stage2Spec(embed_dim=hp.embed_dim, n_layers=hp.n_layers, n_heads=hp.n_heads,
-                      n_layers_depth=n_layers_depth, vocab_top=s2.vocab_size_img, vocab_bot=s2.vocab_size_img,
+    vocab = list(s2.vocab_sizes_img)[0] if levels == 3 else s2.vocab_size_img
+    return Stage2Spec(levels=levels, embed_dim=hp.embed_dim, n_layers=hp.n_layers, n_heads=hp.n_heads,
+                      n_layers_depth=n_layers_depth, vocab_top=vocab, vocab_bot=vocab,
                       vocab_txt=s2.vocab_size_txt, ctx_len_img=hp.ctx_len_img, ctx_len_txt=hp.ctx_len_txt,
                       n_classes=(hp.n_classes or 0), cond=cond, embedding=emb,
-                      gelu_approx=bool(hp.gelu_use_approx), ratio_bot2top=s2.ratio_bot2top)
+                      gelu_approx=bool(hp.gelu_use_approx), ratio_bot2top=(s2.ratio_bot2top or 4))
 
 
 def stage1_spec_from_config(cfg) -> Stage1Spec:
     s1 = cfg.stage1
-    if s1.type != 'simrqgan2':
-        raise NotImplementedError(f"stage1.type '{s1.type}': only 'simrqgan2' is built")
+    if s1.type not in ('simrqgan2', 'hqvae'):
+        raise NotImplementedError(f"stage1.type '{s1.type}': 'simrqgan2' and 'hqvae' are built")
     aux = s1.hparams_aux
     if aux is None or aux.upsample != 'pixelshuffle' or aux.decoding_type != 'concat':
         raise NotImplementedError('only upsample=pixelshuffle (kernel 2), decoding_type=concat is built')
+    code_levels = 2
+    if s1.type == 'hqvae':                  # HQVAEGenerator (generator.py:451-515): additive pyramid, decoding_type is not read by decode
+        code_levels = int(aux.code_levels or 2)
+        if code_levels != 3:
+            raise NotImplementedError('hqvae: code_levels = 3 is built')
     hp = s1.hparams
     return Stage1Spec(ch=hp.ch, ch_mult=list(hp.ch_mult), num_res_blocks=hp.num_res_blocks,
                       attn_resolutions=list(hp.attn_resolutions), resolution=hp.resolution,
                       z_channels=hp.z_channels, embed_dim=s1.embed_dim, n_embed=s1.n_embed, out_ch=hp.out_ch,
                       use_init_downsample=bool(hp.use_init_downsample), use_mid_block=bool(hp.use_mid_block),
-                      use_attn=bool(hp.use_attn))
+                      use_attn=bool(hp.use_attn), code_levels=code_levels)
 
 
 def _block_shapes(prefix: str, D: int, out: Dict[str, Tuple[int, ...]]) -> None:
@@ -140,6 +161,27 @@ def stage2_param_shapes(s: Stage2Spec) -> 'OrderedDict[str, Tuple[int, ...]]':
         out['ln_txt.bias'] = (D,)
     else:
         out['sos'] = (1, 1, D)
+    if s.levels == 3:                       # HQTransformer (hqtransformer.py:24-205); 'transformer1' has no emb_blocks
+        for li in range(3):
+            out[f'tok_emb_levels.{li}.weight'] = (s.vocab_top, D)
+        out['pos_emb_emb.weight'] = (21, D)
+        out['pos_emb_top.weight'] = (s.ctx_len_img, D)
+        for i in range(s.n_layers):
+            _block_shapes(f'blocks.{i}', D, out)
+        out['ln_f.weight'] = (D,)
+        out['ln_f.bias'] = (D,)
+        for li in range(3):
+            out[f'tok_emb_depth_levels.{li}.weight'] = (s.vocab_top, D)
+        out['pos_emb_depths.0.weight'] = (4, D)
+        out['pos_emb_depths.1.weight'] = (16, D)
+        for j in range(s.n_layers_depth):
+            _block_shapes(f'depths.{j}', D, out)
+        for li in range(3):
+            out[f'ln_levels.{li}.weight'] = (D,)
+            out[f'ln_levels.{li}.bias'] = (D,)
+        for li in range(3):
+            out[f'head_levels.{li}.weight'] = (s.vocab_top, D)
+        return out
     out['tok_emb_top.weight'] = (s.vocab_top, D)
     if s.embedding == EMB_REDUCE:
         out['tok_emb_bot.weight'] = (s.vocab_bot, D // s.ratio_bot2top)
@@ -166,7 +208,7 @@ def stage2_param_shapes(s: Stage2Spec) -> 'OrderedDict[str, Tuple[int, ...]]':
 
 
 # Stage-2 tensors the sampling path never reads (kept out of device memory, accepted on load).
-STAGE2_UNUSED = ('tok_emb_bot_depth.weight', 'head_txt.weight', 'ln_txt.weight', 'ln_txt.bias')
+STAGE2_UNUSED = ('tok_emb_bot_depth.weight', 'tok_emb_depth_levels.2.weight', 'head_txt.weight', 'ln_txt.weight', 'ln_txt.bias')
 
 
 @dataclass
@@ -206,9 +248,14 @@ def decoder_plan(s: Stage1Spec) -> List[DecoderLayer]:
 def stage1_param_shapes(s: Stage1Spec) -> 'OrderedDict[str, Tuple[int, ...]]':
     """Tensors ``decode_code`` reads (generator.py:312-367): two codebooks, the 1x1 post-quant conv, the decoder."""
     out: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
-    out['quantize_t.embedding'] = (s.n_embed, s.embed_dim * 4)
-    out['quantize_b.embedding'] = (s.n_embed, s.embed_dim)
-    out['post_quant_conv_b.weight'] = (s.z_channels, 2 * s.embed_dim, 1, 1)
+    if s.code_levels == 3:                  # HQVAEGenerator (generator.py:478-506): dims E*16, E*4, E; 1x1 conv from E channels
+        for ci in range(3):
+            out[f'quantizers.{ci}.embedding'] = (s.n_embed, s.embed_dim * 4 ** (2 - ci))
+        out['post_quant_conv_b.weight'] = (s.z_channels, s.embed_dim, 1, 1)
+    else:
+        out['quantize_t.embedding'] = (s.n_embed, s.embed_dim * 4)
+        out['quantize_b.embedding'] = (s.n_embed, s.embed_dim)
+        out['post_quant_conv_b.weight'] = (s.z_channels, 2 * s.embed_dim, 1, 1)
     out['post_quant_conv_b.bias'] = (s.z_channels,)
     for l in decoder_plan(s):
         if l.kind in ('conv3', 'upconv'):

@@ -204,6 +204,94 @@ class OracleStage2:
         return codes_top, codes_bot
 
 
+class OracleStage2L3(OracleStage2):
+    """HQTransformer 'parallel-add' sampling, three code levels: hqtransformer.py:409-635 and
+    sampling.py:240-307.  Per top position 1 + 4 + 16 codes; the depth transformer runs three sub-steps over 1, 4 and 16
+    tokens, each seeing every earlier and current token (the 'parallel' mask of layers.py:154-178 is all-ones on the
+    rows a sampling sub-step evaluates); 'transformer1' has no embedding blocks (hqtransformer.py:36-54), so the body
+    input is the mean of the 21 code embeddings."""
+
+    # raster order of the 16 level-2 tokens: index (H1 H2 W1 W2) -> parent cell (H1 W1), child (H2 W2)
+    _L2_PARENT = np.array([(i // 8) * 2 + (i % 4) // 2 for i in range(16)])
+
+    def _embed3(self, c0: np.ndarray, c1: np.ndarray, c2: np.ndarray, pos: int) -> np.ndarray:
+        """hqtransformer.py:466-488: mean over the 21 embedded codes (+ position of the embedding slot; + top position)."""
+        w = self.w
+        e0 = w['tok_emb_levels.0.weight'][c0] + w['pos_emb_top.weight'][pos]         # [B, D]
+        e1 = w['tok_emb_levels.1.weight'][c1]                                        # [B, 4, D]
+        e2 = w['tok_emb_levels.2.weight'][c2]                                        # [B, 16, D]
+        h = np.concatenate([e0[:, None, :], e1, e2], axis=1) + w['pos_emb_emb.weight'][None]
+        return h.mean(axis=1, dtype=F32)[:, None, :].astype(F32)
+
+    def sample(self, cond, batch: int, n_steps: int, noise: np.ndarray,
+               top_k: Sequence[Optional[int]] = (None, None, None), top_p: Sequence[Optional[float]] = (None, None, None),
+               temperature: Sequence[float] = (1.0, 1.0, 1.0), force: Optional[Sequence[np.ndarray]] = None,
+               return_logits: bool = False):
+        """sampling_hqtransformer (sampling.py:240-307).  ``noise`` [n_steps, 21, B, V], draw order level 0, the four
+        level-1 slots, the sixteen level-2 tokens in (H1 H2 W1 W2) raster order (hqtransformer.py:553-560,616-627).
+        ``force`` = (codes0 [B, n], codes1 [B, n, 4], codes2 [B, n, 16]) teacher-forces what is fed back.
+        Returns (codes0, codes1, codes2[, logits [n_steps, 21, B, V]])."""
+        w, s = self.w, self.s
+        B = batch
+        if s.cond == 1:
+            sos = w['sos.weight'][np.asarray(cond, np.int64).reshape(-1)][:, None, :]
+        elif s.cond == 2:
+            sos = w['tok_emb_txt.weight'][np.asarray(cond, np.int64)] + w['pos_emb_txt.weight'][None, :s.ctx_len_txt]
+        else:
+            sos = np.repeat(w['sos'], B, axis=0)
+        cache: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
+        c0 = np.zeros((B, n_steps), np.int64)
+        c1 = np.zeros((B, n_steps, 4), np.int64)
+        c2 = np.zeros((B, n_steps, 16), np.int64)
+        logits_out = np.zeros((n_steps, 21, B, s.vocab_top), F32) if return_logits else None
+        for cnt in range(n_steps):
+            if cnt == 0:
+                xs = sos.astype(F32)
+            else:
+                f = force if force is not None else (c0, c1, c2)
+                xs = self._embed3(f[0][:, cnt - 1], f[1][:, cnt - 1], f[2][:, cnt - 1], cnt - 1)
+            for i in range(s.n_layers):
+                xs = self._block(f'blocks.{i}', xs, cache, causal_new=True)
+            hs = layer_norm(xs, w['ln_f.weight'], w['ln_f.bias'])
+            if hs.shape[1] > 1:                                                          # hqtransformer.py:522-523
+                hs = hs[:, s.idx_pred - 1:s.idx_pred, :]
+            dcache: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
+
+            def depth(xd, level):
+                for j in range(s.n_layers_depth):
+                    xd = self._block(f'depths.{j}', xd, dcache, causal_new=False)
+                return linear(layer_norm(xd, w[f'ln_levels.{level}.weight'], w[f'ln_levels.{level}.bias']), w[f'head_levels.{level}.weight'])
+
+            # level 0 (hqtransformer.py:518-524)
+            l0 = depth((hs + w['sos_depth']).astype(F32), 0)[:, 0]
+            d0, _ = sample_filtered(l0, noise[cnt, 0], temperature[0], top_k[0], top_p[0])
+            c0[:, cnt] = d0
+            fed0 = force[0][:, cnt] if force is not None else d0
+            # level 1: four tokens = emb(top code) + positions 0..3 (:526-536 with cnt == 1)
+            x1 = (w['tok_emb_depth_levels.0.weight'][fed0][:, None, :] + w['pos_emb_depths.0.weight'][None, :4]).astype(F32)
+            l1 = depth(x1, 1)                                                            # [B, 4, V]
+            d1 = np.zeros((B, 4), np.int64)
+            for k in range(4):
+                d1[:, k], _ = sample_filtered(l1[:, k], noise[cnt, 1 + k], temperature[1], top_k[1], top_p[1])
+            c1[:, cnt] = d1
+            fed1 = force[1][:, cnt] if force is not None else d1
+            # level 2: sixteen tokens in (H1 H2 W1 W2) raster order; token i carries its parent's level-1 embedding,
+            # position i of pos_emb_depths[1], and the top code's embedding ('add', :537-551)
+            e1 = w['tok_emb_depth_levels.1.weight'][fed1]                                # [B, 4, D], parents in (H1 W1) order
+            x2 = (e1[:, self._L2_PARENT, :] + w['pos_emb_depths.1.weight'][None, :16] +
+                  w['tok_emb_depth_levels.0.weight'][fed0][:, None, :]).astype(F32)
+            l2 = depth(x2, 2)                                                            # [B, 16, V]
+            for k in range(16):
+                c2[:, cnt, k], _ = sample_filtered(l2[:, k], noise[cnt, 5 + k], temperature[2], top_k[2], top_p[2])
+            if return_logits:
+                logits_out[cnt, 0] = l0
+                logits_out[cnt, 1:5] = l1.transpose(1, 0, 2)
+                logits_out[cnt, 5:21] = l2.transpose(1, 0, 2)
+        if return_logits:
+            return c0, c1, c2, logits_out
+        return c0, c1, c2
+
+
 # ----------------------------------------------------------------------------- stage 1 (A9-A12)
 def conv2d(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
     """nn.Conv2d stride 1, 'same' zero padding, kernel 1 or 3, NCHW (stage1/modules/layers.py:40-44,88-98)."""
@@ -300,6 +388,24 @@ class OracleStage1:
         h = swish(self._gn('decoder.norm_out', h))
         return self._conv('decoder.conv_out', h)
 
+    def decode_codes3(self, codes: Sequence[Optional[np.ndarray]]) -> np.ndarray:
+        """HQVAEGenerator.decode_code (generator.py:577-599): codes = [top [B, r/4, r/4], mid [B, r/2, r/2], bottom [B, r, r]]
+        (None = zero quant of that level); quant = PS(PS(q0) + q1) + q2, then post_quant_conv_b and the decoder."""
+        w, s = self.w, self.s
+        ref = next(c for c in codes if c is not None)
+        B = ref.shape[0]
+        quant = None
+        for hi, code in enumerate(codes):
+            r = s.z_res // 2 ** (2 - hi)
+            dim = s.embed_dim * 4 ** (2 - hi)
+            q = (w[f'quantizers.{hi}.embedding'][code].transpose(0, 3, 1, 2) if code is not None
+                 else np.zeros((B, dim, r, r), F32))
+            quant = q if quant is None else (quant + q).astype(F32)
+            if hi < 2:
+                quant = pixel_shuffle2(quant)
+        z = self._conv('post_quant_conv_b', quant.astype(F32))
+        return self.decoder(z)
+
     def decode_code(self, code_t: Optional[np.ndarray], code_b: Optional[np.ndarray]) -> np.ndarray:
         """code_t int64 [B, r/2, r/2] or None, code_b int64 [B, r, r] or None -> fp32 [B, 3, H, W], unclamped.
         A missing level contributes a zero quant (generator.py:328-358)."""
@@ -321,6 +427,14 @@ class OracleStage1:
 def postprocess(pixels: np.ndarray) -> np.ndarray:
     """clamp(0.5 x + 0.5, 0, 1) -- measure_throughput/__main__.py:113, sampling_hqmodel.py:198-199."""
     return np.clip(F32(0.5) * pixels + F32(0.5), 0.0, 1.0).astype(F32)
+
+
+def rearrange_codes3(c0: np.ndarray, c1: np.ndarray, c2: np.ndarray, top_res: int):
+    """sampling_hqmodel.py:150-153: 'B (H W) -> B H W' and 'B (H W) (kh kw) -> B (H kh) (W kw)' with kh = 2 and 4."""
+    B, K = c0.shape[0], top_res
+    return (c0.reshape(B, K, K),
+            c1.reshape(B, K, K, 2, 2).transpose(0, 1, 3, 2, 4).reshape(B, 2 * K, 2 * K),
+            c2.reshape(B, K, K, 4, 4).transpose(0, 1, 3, 2, 4).reshape(B, 4 * K, 4 * K))
 
 
 def rearrange_codes(codes_top: np.ndarray, codes_bot: np.ndarray, top_res: int) -> Tuple[np.ndarray, np.ndarray]:

@@ -155,3 +155,35 @@ def test_block_steps_match_reference(name):
     dk, dv = dcache['depths.0']                                        # 1 past + 4 new keys
     assert np.abs(dk[:, :, 1:].reshape(B * nh, 4, hs) - fx[f'{name}_dk']).max() <= 1e-4
     assert np.abs(dv[:, :, 1:].reshape(B * nh, 4, hs) - fx[f'{name}_dv']).max() <= 1e-4
+
+
+@pytest.mark.parametrize('si', [0, 1])
+def test_l3_sampling_bit_exact(si):
+    """G7: three-level HQTransformer 'parallel-add' sampling (1 + 4 + 16 codes per position), 64 positions, B = 3."""
+    from hqtransformer_amd.spec import Stage2Spec
+    from oracle.hqt_oracle import OracleStage2L3
+    fx = load('g7_l3_tiny_cls.npz')
+    spec = Stage2Spec(**json.loads(str(fx['spec'])))
+    assert {k: tuple(v) for k, v in json.loads(str(fx['ref_shapes'])).items()} == dict(stage2_param_shapes(spec))
+    orc = OracleStage2L3(spec, synth.stage2_weights(spec, int(fx['weight_seed']), 'fixture'))
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = np.maximum(np.random.default_rng([int(fx['noise_seed']), 0x9e3779b9]).standard_exponential((n, 21, B, spec.vocab_top), dtype=np.float32),
+                       np.float32(1e-30))
+    tk, tp, T = json.loads(str(fx['settings']))[si]
+    c0, c1, c2, lg = orc.sample(np.full(B, 7), B, n, noise, tk, tp, T, return_logits=True)
+    assert np.abs(lg[fx['keep_steps']] - fx[f'logits_{si}']).max() <= 2e-4
+    assert (c0 == fx[f'codes0_{si}']).all() and (c1 == fx[f'codes1_{si}']).all() and (c2 == fx[f'codes2_{si}']).all()
+    assert float(fx[f'margin_{si}']) > 1.00005         # every draw is decided by a margin an fp32-accurate implementation resolves
+
+
+def test_l3_decode_pixels():
+    """G8: HQVAEGenerator.decode_code([top, mid, bottom]) -- additive pixel-shuffle pyramid + decoder."""
+    from hqtransformer_amd.spec import Stage1Spec
+    from oracle.hqt_oracle import OracleStage1
+    fx = load('g8_l3_decode.npz')
+    spec = Stage1Spec(**json.loads(str(fx['spec'])))
+    assert {k: tuple(v) for k, v in json.loads(str(fx['ref_shapes'])).items()} == dict(stage1_param_shapes(spec))
+    orc = OracleStage1(spec, synth.stage1_weights(spec, int(fx['weight_seed']), 'fixture'))
+    assert np.abs(orc.decode_codes3([fx['code_t'], fx['code_m'], fx['code_b']]) - fx['pixels']).max() <= 1e-4
+    assert np.abs(orc.decode_codes3([fx['code_t'][:1], None, None]) - fx['pixels_top_only']).max() <= 1e-4
+    assert np.abs(orc.decode_codes3([None, None, fx['code_b'][:1]]) - fx['pixels_bot_only']).max() <= 1e-4
