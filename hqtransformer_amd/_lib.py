@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'mfma_gemm.hip']
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 PRECISION_EXACT, PRECISION_FAST = 0, 1
 
@@ -45,6 +45,7 @@ class hqt_config(C.Structure):
         ('s1_n_embed', C.c_int32), ('s1_out_ch', C.c_int32),
         ('s1_use_init_downsample', C.c_int32), ('s1_use_mid_block', C.c_int32), ('s1_use_attn', C.c_int32),
         ('max_batch', C.c_int32), ('max_steps', C.c_int32),
+        ('code_levels', C.c_int32),
     ]
 
 
@@ -54,6 +55,15 @@ class hqt_sample_opts(C.Structure):
         ('top_k_top', C.c_int32), ('top_k_bot', C.c_int32),
         ('top_p_top', C.c_float), ('top_p_bot', C.c_float),
         ('temperature_top', C.c_float), ('temperature_bot', C.c_float),
+        ('seed', C.c_uint64), ('sample_offset', C.c_int64),
+        ('use_graph', C.c_int32),
+    ]
+
+
+class hqt_sample_opts_l3(C.Structure):
+    _fields_ = [
+        ('precision', C.c_int32), ('n_steps', C.c_int32),
+        ('top_k', C.c_int32 * 3), ('top_p', C.c_float * 3), ('temperature', C.c_float * 3),
         ('seed', C.c_uint64), ('sample_offset', C.c_int64),
         ('use_graph', C.c_int32),
     ]
@@ -71,6 +81,9 @@ SYMBOLS = {
     'hqt_sample': (C.c_int, [_VP, C.c_int, _I64P, C.POINTER(hqt_sample_opts), _F32P, _I64P, _I64P, _F32P, _I64P, _I64P, _VP]),
     'hqt_decode': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
     'hqt_decode_seq': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
+    'hqt_sample_l3': (C.c_int, [_VP, C.c_int, _I64P, C.POINTER(hqt_sample_opts_l3), _F32P, _I64P, _I64P, _I64P, _F32P, _I64P, _I64P, _I64P, _VP]),
+    'hqt_decode_l3': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
+    'hqt_decode_seq_l3': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
     'hqt_param_count': (C.c_int64, [_VP, C.c_int]),
     'hqt_workspace_bytes': (C.c_int64, [_VP]),
     'hqt_timing_enable': (C.c_int, [_VP, C.c_int]),

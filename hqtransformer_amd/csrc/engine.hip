@@ -98,6 +98,8 @@ struct hqt_handle {
     struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
     StepState* state = nullptr;
     int64_t *cond_buf = nullptr, *codes_top = nullptr, *codes_bot = nullptr;   // call-independent homes of cond / the drawn codes
+    int64_t* codes_l2 = nullptr;              // third level: [B, max_steps, 16]
+    Lin head_l2;                              // head_levels.2 (three-level models; head_top / head_bot hold levels 0 / 1)
     // ---- stage 1
     std::vector<DecLayer> dec;
     Lin post_quant;
@@ -262,18 +264,20 @@ static int alloc_workspace(hqt_handle* hp) {
         const size_t D = c.embed_dim;
         const int Tp = c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1;    // rows of the widest body pass
         h->Tmax = (c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 0) + c.max_steps;
-        const size_t rows = (B * (size_t)std::max(Tp, 4) + 31) / 32 * 32;
+        const int Tdepth = c.code_levels == 3 ? 16 : 4;      // rows per sample of the widest depth sub-step
+        const int Kdepth = c.code_levels == 3 ? 21 : 5;      // keys of the depth cache
+        const size_t rows = (B * (size_t)std::max(Tp, Tdepth) + 31) / 32 * 32;
         CHK(dev_alloc(h.get(), (void**)&h->x, rows * D * 4, true));
-        CHK(dev_alloc(h.get(), (void**)&h->xd, B * 4 * D * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->xd, B * Tdepth * D * 4, true));
         CHK(dev_alloc(h.get(), &h->hbuf, rows * D * 4, true));
         CHK(dev_alloc(h.get(), &h->qbuf, rows * D * 4, true));
         CHK(dev_alloc(h.get(), &h->abuf, rows * D * 4, true));
         CHK(dev_alloc(h.get(), &h->mbuf, rows * 4 * D * 4, true));
-        CHK(dev_alloc(h.get(), (void**)&h->logits, B * 4 * (size_t)c.vocab_top * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->logits, B * Tdepth * (size_t)c.vocab_top * 4, true));
         const size_t kv = (size_t)c.n_layers * B * h->Tmax * D * 4;
         CHK(dev_alloc(h.get(), &h->kcache, kv, true));
         CHK(dev_alloc(h.get(), &h->vcache, kv, true));
-        const size_t dkv = (size_t)c.n_layers_depth * B * 5 * D * 4;
+        const size_t dkv = (size_t)c.n_layers_depth * B * Kdepth * D * 4;
         CHK(dev_alloc(h.get(), &h->dk, dkv, true));
         CHK(dev_alloc(h.get(), &h->dv, dkv, true));
         h->splitk_elems = (size_t)16 * rows * (size_t)std::max<size_t>(4 * D, (size_t)c.vocab_top);
@@ -282,6 +286,7 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), (void**)&h->cond_buf, B * (size_t)std::max(1, c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1) * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->codes_top, B * (size_t)c.max_steps * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->codes_bot, B * (size_t)c.max_steps * 4 * 8, true));
+        if (c.code_levels == 3) CHK(dev_alloc(h.get(), (void**)&h->codes_l2, B * (size_t)c.max_steps * 16 * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->xpk, rows * D * 2, true));
         CHK(dev_alloc(h.get(), (void**)&h->xdpk, rows * D * 2, true));
         CHK(dev_alloc(h.get(), (void**)&h->parts, (D / 32 + 1) * rows * 2 * 4, true));
@@ -477,6 +482,8 @@ static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int k
     return make_lin(h, l, wt, b, O, I * taps, false);
 }
 
+static std::string key2(const hqt_handle* h, const char* name);
+
 extern "C" int hqt_finalize_weights(hqt_handle* h) {
     if (!h) return fail(HQT_ERR_INVALID, "null handle");
     if (h->finalized) return HQT_OK;
@@ -490,28 +497,43 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
         for (int i = 0; i < c.n_layers_depth; ++i) CHK(load_block(h, "stage2.depths." + std::to_string(i), h->depth[i]));
         const float* w;
         const int64_t D = c.embed_dim;
-        CHK(get_w(h, "stage2.head_top.weight", {c.vocab_top, D}, &w));
+        const bool l3 = c.code_levels == 3;
+        CHK(get_w(h, key2(h, "head_top.weight"), {c.vocab_top, D}, &w));
         CHK(make_lin(h, h->head_top, w, nullptr, c.vocab_top, D, true));
-        CHK(get_w(h, "stage2.head_bot.weight", {c.vocab_bot, D}, &w));
+        CHK(get_w(h, key2(h, "head_bot.weight"), {c.vocab_bot, D}, &w));
         CHK(make_lin(h, h->head_bot, w, nullptr, c.vocab_bot, D, true));
+        if (l3) {
+            CHK(get_w(h, "stage2.head_levels.2.weight", {c.vocab_top, D}, &w));
+            CHK(make_lin(h, h->head_l2, w, nullptr, c.vocab_top, D, true));
+        }
         // presence/shape checks of the remaining tensors happen here so that sample() cannot fail late
         const float* t;
         CHK(get_w(h, "stage2.ln_f.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_f.bias", {D}, &t));
-        CHK(get_w(h, "stage2.ln_top.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_top.bias", {D}, &t));
-        CHK(get_w(h, "stage2.ln_bot.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_bot.bias", {D}, &t));
+        CHK(get_w(h, key2(h, "ln_top.weight"), {D}, &t)); CHK(get_w(h, key2(h, "ln_top.bias"), {D}, &t));
+        CHK(get_w(h, key2(h, "ln_bot.weight"), {D}, &t)); CHK(get_w(h, key2(h, "ln_bot.bias"), {D}, &t));
         CHK(get_w(h, "stage2.sos_depth", {1, 1, D}, &t));
-        CHK(get_w(h, "stage2.tok_emb_top.weight", {c.vocab_top, D}, &t));
-        CHK(get_w(h, "stage2.tok_emb_bot.weight", {c.vocab_bot, c.embedding_type == HQT_EMB_REDUCE ? D / 4 : D}, &t));
-        if (c.embedding_type == HQT_EMB_TRANSFORMER1) CHK(get_w(h, "stage2.pos_emb_emb.weight", {5, D}, &t));
+        CHK(get_w(h, key2(h, "tok_emb_top.weight"), {c.vocab_top, D}, &t));
+        CHK(get_w(h, key2(h, "tok_emb_bot.weight"), {c.vocab_bot, c.embedding_type == HQT_EMB_REDUCE ? D / 4 : D}, &t));
+        if (c.embedding_type == HQT_EMB_TRANSFORMER1) CHK(get_w(h, "stage2.pos_emb_emb.weight", {l3 ? 21 : 5, D}, &t));
         CHK(get_w(h, "stage2.pos_emb_top.weight", {c.ctx_len_img, D}, &t));
-        CHK(get_w(h, "stage2.tok_emb_top_depth.weight", {c.vocab_top, D}, &t));
-        CHK(get_w(h, "stage2.pos_emb_depth.weight", {5, D}, &t));
+        CHK(get_w(h, key2(h, "tok_emb_top_depth.weight"), {c.vocab_top, D}, &t));
+        CHK(get_w(h, key2(h, "pos_emb_depth.weight"), {l3 ? 4 : 5, D}, &t));
+        if (l3) {
+            CHK(get_w(h, "stage2.tok_emb_levels.2.weight", {c.vocab_top, D}, &t));
+            CHK(get_w(h, "stage2.tok_emb_depth_levels.1.weight", {c.vocab_top, D}, &t));
+            CHK(get_w(h, "stage2.pos_emb_depths.1.weight", {16, D}, &t));
+            CHK(get_w(h, "stage2.ln_levels.2.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_levels.2.bias", {D}, &t));
+        }
         {
             const float *g1, *b1;
-            CHK(get_w(h, "stage2.ln_top.weight", {D}, &g1)); CHK(get_w(h, "stage2.ln_top.bias", {D}, &b1));
+            CHK(get_w(h, key2(h, "ln_top.weight"), {D}, &g1)); CHK(get_w(h, key2(h, "ln_top.bias"), {D}, &b1));
             CHK(fold_ln(h, h->head_top, g1, b1));
-            CHK(get_w(h, "stage2.ln_bot.weight", {D}, &g1)); CHK(get_w(h, "stage2.ln_bot.bias", {D}, &b1));
+            CHK(get_w(h, key2(h, "ln_bot.weight"), {D}, &g1)); CHK(get_w(h, key2(h, "ln_bot.bias"), {D}, &b1));
             CHK(fold_ln(h, h->head_bot, g1, b1));
+            if (l3) {
+                CHK(get_w(h, "stage2.ln_levels.2.weight", {D}, &g1)); CHK(get_w(h, "stage2.ln_levels.2.bias", {D}, &b1));
+                CHK(fold_ln(h, h->head_l2, g1, b1));
+            }
             HIPCHK(hipDeviceSynchronize());
             HIPCHK(hipFree(h->fold_tmp));
             h->fold_tmp = nullptr;
@@ -525,9 +547,16 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
     if (c.has_stage1) {
         const int E = c.s1_embed_dim;
         const float* t;
-        CHK(get_w(h, "stage1.quantize_t.embedding", {c.s1_n_embed, 4 * E}, &t));
-        CHK(get_w(h, "stage1.quantize_b.embedding", {c.s1_n_embed, E}, &t));
-        CHK(load_conv(h, "post_quant_conv_b", c.s1_z_channels, 2 * E, 1, h->post_quant));
+        if (c.code_levels == 3) {                // HQVAEGenerator: additive pyramid, E channels into the 1x1 conv
+            CHK(get_w(h, "stage1.quantizers.0.embedding", {c.s1_n_embed, 16 * E}, &t));
+            CHK(get_w(h, "stage1.quantizers.1.embedding", {c.s1_n_embed, 4 * E}, &t));
+            CHK(get_w(h, "stage1.quantizers.2.embedding", {c.s1_n_embed, E}, &t));
+            CHK(load_conv(h, "post_quant_conv_b", c.s1_z_channels, E, 1, h->post_quant));
+        } else {
+            CHK(get_w(h, "stage1.quantize_t.embedding", {c.s1_n_embed, 4 * E}, &t));
+            CHK(get_w(h, "stage1.quantize_b.embedding", {c.s1_n_embed, E}, &t));
+            CHK(load_conv(h, "post_quant_conv_b", c.s1_z_channels, 2 * E, 1, h->post_quant));
+        }
         for (auto& l : h->dec) {
             if (l.kind == 0 || l.kind == 3) CHK(load_conv(h, l.name, l.cout, l.cin, 3, l.conv1));
             else if (l.kind == 1) {
@@ -622,9 +651,30 @@ struct SampleCtx {
     int64_t *out_top, *out_bot;
     hipStream_t st;
     Mode md;
+    // three-level calls (hqt_sample_l3): per-level sampler settings and the third level's code buffers
+    int levels = 2;
+    int top_k[3] = {0, 0, 0};
+    float top_p[3] = {0.f, 0.f, 0.f}, temperature[3] = {1.f, 1.f, 1.f};
+    const int64_t* feed_l2 = nullptr;
+    int64_t* out_l2 = nullptr;
 };
 
-static const float* W(hqt_handle* h, const char* name) { return h->w[std::string("stage2.") + name].d; }
+// State-dict key of a stage-2 tensor: the code below names tensors as iHQGPT does; the three-level HQTransformer keeps
+// the same roles under indexed names (hqtransformer.py:24-205).
+static std::string key2(const hqt_handle* h, const char* name) {
+    std::string n(name);
+    if (h->cfg.code_levels == 3) {
+        static const char* const tr[][2] = {
+            {"tok_emb_top.weight", "tok_emb_levels.0.weight"}, {"tok_emb_bot.weight", "tok_emb_levels.1.weight"},
+            {"tok_emb_top_depth.weight", "tok_emb_depth_levels.0.weight"}, {"pos_emb_depth.weight", "pos_emb_depths.0.weight"},
+            {"ln_top.weight", "ln_levels.0.weight"}, {"ln_top.bias", "ln_levels.0.bias"},
+            {"ln_bot.weight", "ln_levels.1.weight"}, {"ln_bot.bias", "ln_levels.1.bias"},
+            {"head_top.weight", "head_levels.0.weight"}, {"head_bot.weight", "head_levels.1.weight"}};
+        for (auto& t : tr) if (n == t[0]) { n = t[1]; break; }
+    }
+    return "stage2." + n;
+}
+static const float* W(hqt_handle* h, const char* name) { return h->w[key2(h, name)].d; }
 
 static int run_ln(hqt_handle* h, hipStream_t st, float* x, const float* g, const float* b, const float* add, void* y, int M,
                   int D, int in_rpg, int in_off, int out_dt, int out_pk) {
@@ -806,6 +856,77 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     return HQT_OK;
 }
 
+// One top position of the three-level HQTransformer after the body input x is ready (hqtransformer.py:409-635): body
+// blocks, ln_f, then three depth sub-steps over 1, 4 and 16 tokens.  Every sub-step's tokens see all earlier and current
+// depth tokens (the 'parallel' mask of layers.py:154-178 restricted to the rows being evaluated is all-ones), so the
+// attention kernel runs non-causally over t_base + Tq keys of a 21-row cache.
+static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int body_t_base, bool body_tbase_from_state) {
+    const hqt_config& cf = h->cfg;
+    const int D = cf.embed_dim, B = c.B, V = cf.vocab_top;
+    const int adt = c.md.act_dt();
+    const size_t esz = c.md.act_sz();
+    const size_t kv_layer = (size_t)cf.max_batch * h->Tmax * D * esz;
+    const int* tb_dev = body_tbase_from_state ? &h->state->t_base : nullptr;
+    const bool dln_body = Tq_body == 1 && dln_ok(h, c, h->body[0], B * Tq_body);
+    for (int l = 0; l < cf.n_layers; ++l) {
+        void* kc = (char*)h->kcache + l * kv_layer;
+        void* vc = (char*)h->vcache + l * kv_layer;
+        if (dln_body) CHK(run_block_dln(h, c, h->body[l], h->x, h->xpk, h->parts, &h->nparts, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
+        else CHK(run_block(h, c, h->body[l], h->x, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
+    }
+    const Lin* heads[3] = {&h->head_top, &h->head_bot, &h->head_l2};
+    const char* ln_names[3][2] = {{"ln_top.weight", "ln_top.bias"}, {"ln_bot.weight", "ln_bot.bias"}, {"ln_levels.2.weight", "ln_levels.2.bias"}};
+    const int Tqs[3] = {1, 4, 16}, tbase[3] = {0, 1, 5}, draw0[3] = {0, 1, 5};
+    int64_t* outs[3] = {c.out_top, c.out_bot, c.out_l2};
+    const size_t dkv_layer = (size_t)cf.max_batch * 21 * D * esz;
+    for (int lv = 0; lv < 3; ++lv) {
+        const int Tq = Tqs[lv], M = B * Tq;
+        const bool dln = dln_ok(h, c, h->depth[0], M) && heads[lv]->wpk_ln;
+        const int pk = (c.md.fast && M <= 256 && heads[lv]->wpk) ? packed_mb(M) : 0;
+        if (lv == 0) {            // ln_f on the last token of each sample, + sos_depth -> depth input of level 0
+            Timed t(h, "layernorm", c.st);
+            LNArgs ln{h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, 1e-5f, DT_F32, 0,
+                      h->pend.slabs, h->pend.S, h->pend.rows, h->pend.bias, dln ? h->xdpk : nullptr, dln ? packed_mb(B) : 0, h->partsd};
+            h->pend.slabs = nullptr; h->pend.S = 0;
+            HIPCHK(launch_layernorm(ln, c.st));
+        } else if (lv == 1) {     // emb(top code) + positions 0..3
+            Timed t(h, "embed", c.st);
+            HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
+                                      h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st));
+        } else {                  // parent's level-1 embedding + position i + emb(top code), 16 tokens
+            Timed t(h, "embed", c.st);
+            HIPCHK(launch_depth_embed_l2(c.feed_top, c.feed_bot, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"),
+                                         h->w["stage2.tok_emb_depth_levels.1.weight"].d, h->w["stage2.pos_emb_depths.1.weight"].d,
+                                         h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st));
+        }
+        h->npartsd = 1;
+        for (int l = 0; l < cf.n_layers_depth; ++l) {
+            void* kc = (char*)h->dk + l * dkv_layer;
+            void* vc = (char*)h->dv + l * dkv_layer;
+            if (dln) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, Tq, kc, vc, 21, tbase[lv], nullptr, 0));
+            else CHK(run_block(h, c, h->depth[l], h->xd, Tq, kc, vc, 21, tbase[lv], nullptr, 0));
+        }
+        GemmArgs g{};
+        if (dln) {                // ln_levels[lv] folded into head_levels[lv]
+            g.A = h->xdpk; g.a_packed_mb = pk; g.ln_parts = h->partsd; g.ln_nparts = h->npartsd; g.ln_colsum = heads[lv]->colsum; g.ln_eps = 1e-5f;
+        } else {
+            const float* lg = lv < 2 ? W(h, ln_names[lv][0]) : h->w["stage2.ln_levels.2.weight"].d;
+            const float* lb = lv < 2 ? W(h, ln_names[lv][1]) : h->w["stage2.ln_levels.2.bias"].d;
+            CHK(run_ln(h, c.st, h->xd, lg, lb, nullptr, h->hbuf, M, D, 1, 0, adt, pk));
+            g.A = h->hbuf; g.a_packed_mb = pk;
+        }
+        g.M = M; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
+        CHK(run_linear(h, c.md, g, *heads[lv], adt, DT_F32, c.st, "gemm_head"));
+        {
+            Timed t(h, "sampler", c.st);
+            SamplerArgs sa{h->logits, M, V, Tq, B, c.temperature[lv], c.top_k[lv], c.top_p[lv], c.noise, draw0[lv],
+                           h->state, c.o.n_steps, outs[lv], c.logits_out, 21};
+            HIPCHK(launch_sampler(sa, c.st));
+        }
+    }
+    return HQT_OK;
+}
+
 static int run_decode_step(hqt_handle* h, const SampleCtx& c) {      // one KV-cached position, Tq = 1
     const hqt_config& cf = h->cfg;
     {
@@ -816,9 +937,11 @@ static int run_decode_step(hqt_handle* h, const SampleCtx& c) {      // one KV-c
                     cf.embedding_type == HQT_EMB_TRANSFORMER1 ? W(h, "pos_emb_emb.weight") : nullptr,
                     c.feed_top, c.feed_bot, h->x, nullptr, 0, h->parts};
         if (dln_ok(h, c, h->body[0], c.B)) { e.xpk = h->xpk; e.pk_mb = packed_mb(c.B); h->nparts = 1; }
+        if (c.levels == 3) { e.levels = 3; e.tok_l2 = h->w["stage2.tok_emb_levels.2.weight"].d; e.codes_l2 = c.feed_l2; }
         HIPCHK(launch_embed_step(e, c.st));
     }
-    CHK(run_position(h, c, 1, 0, true));
+    if (c.levels == 3) CHK(run_position_l3(h, c, 1, 0, true));
+    else CHK(run_position(h, c, 1, 0, true));
     HIPCHK(launch_advance_step(h->state, 1, c.st));
     return HQT_OK;
 }
@@ -832,6 +955,7 @@ extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_s
     if (!h->finalized) return fail(HQT_ERR_STATE, "hqt_finalize_weights has not run");
     const hqt_config& cf = h->cfg;
     if (!cf.has_stage2) return fail(HQT_ERR_STATE, "handle was created without stage 2");
+    if (cf.code_levels == 3) return fail(HQT_ERR_STATE, "three-level model: use hqt_sample_l3");
     if (B < 1 || B > cf.max_batch) return fail(HQT_ERR_INVALID, "B=%d outside [1, max_batch=%d]", B, cf.max_batch);
     if (opts->n_steps < 1 || opts->n_steps > cf.max_steps) return fail(HQT_ERR_INVALID, "n_steps=%d outside [1, %d]", opts->n_steps, cf.max_steps);
     if (cf.cond_type != HQT_COND_NONE && !cond) return fail(HQT_ERR_INVALID, "cond is required for class/text conditioning");
@@ -856,6 +980,47 @@ extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_s
     return HQT_OK;
 }
 
+extern "C" int hqt_sample_l3(hqt_handle* h, int B, const int64_t* cond, const hqt_sample_opts_l3* opts, const float* noise,
+                             const int64_t* force0, const int64_t* force1, const int64_t* force2, float* logits_out,
+                             int64_t* out0, int64_t* out1, int64_t* out2, void* stream) {
+    if (!h || !opts || !out0 || !out1 || !out2) return fail(HQT_ERR_INVALID, "null argument");
+    if (!h->finalized) return fail(HQT_ERR_STATE, "hqt_finalize_weights has not run");
+    const hqt_config& cf = h->cfg;
+    if (!cf.has_stage2 || cf.code_levels != 3) return fail(HQT_ERR_STATE, "handle does not hold a three-level stage 2");
+    if (B < 1 || B > cf.max_batch) return fail(HQT_ERR_INVALID, "B=%d outside [1, max_batch=%d]", B, cf.max_batch);
+    if (opts->n_steps < 1 || opts->n_steps > cf.max_steps) return fail(HQT_ERR_INVALID, "n_steps=%d outside [1, %d]", opts->n_steps, cf.max_steps);
+    if (cf.cond_type != HQT_COND_NONE && !cond) return fail(HQT_ERR_INVALID, "cond is required for class/text conditioning");
+    float pmax = 0.f;
+    for (int i = 0; i < 3; ++i) {
+        if (!(opts->temperature[i] > 0.f)) return fail(HQT_ERR_INVALID, "temperatures must be > 0");
+        pmax = std::max(pmax, opts->top_p[i]);
+    }
+    if (pmax > 0.f && cf.vocab_top > 8192) return fail(HQT_ERR_INVALID, "top-p needs vocab <= 8192");
+    HIPCHK(hipSetDevice(h->device));
+    SampleCtx c;
+    c.levels = 3;
+    c.B = B; c.cond = cond ? h->cond_buf : nullptr; c.noise = noise;
+    c.o = hqt_sample_opts{};                        // the shared loop reads n_steps / seed / offsets / graph flag from here
+    c.o.precision = opts->precision; c.o.n_steps = opts->n_steps; c.o.seed = opts->seed; c.o.sample_offset = opts->sample_offset;
+    c.o.use_graph = opts->use_graph;
+    c.o.top_k_top = opts->top_k[0]; c.o.top_k_bot = opts->top_k[1]; c.o.top_p_top = opts->top_p[0]; c.o.top_p_bot = std::max(opts->top_p[1], opts->top_p[2]);
+    c.o.temperature_top = opts->temperature[0]; c.o.temperature_bot = opts->temperature[1];
+    for (int i = 0; i < 3; ++i) { c.top_k[i] = opts->top_k[i]; c.top_p[i] = opts->top_p[i]; c.temperature[i] = opts->temperature[i]; }
+    c.feed_top = force0 ? force0 : h->codes_top;
+    c.feed_bot = force1 ? force1 : h->codes_bot;
+    c.feed_l2 = force2 ? force2 : h->codes_l2;
+    c.logits_out = logits_out; c.out_top = h->codes_top; c.out_bot = h->codes_bot; c.out_l2 = h->codes_l2;
+    c.st = (hipStream_t)stream;
+    c.md.fast = opts->precision == HQT_PRECISION_FAST;
+    if (cond) HIPCHK(hipMemcpyAsync(h->cond_buf, cond, (size_t)B * (cf.cond_type == HQT_COND_TEXT ? cf.ctx_len_txt : 1) * 8, hipMemcpyDefault, c.st));
+    const int rc_run = sample_run(h, c);
+    if (rc_run != HQT_OK) return rc_run;
+    HIPCHK(hipMemcpyAsync(out0, h->codes_top, (size_t)B * opts->n_steps * 8, hipMemcpyDeviceToDevice, c.st));
+    HIPCHK(hipMemcpyAsync(out1, h->codes_bot, (size_t)B * opts->n_steps * 4 * 8, hipMemcpyDeviceToDevice, c.st));
+    HIPCHK(hipMemcpyAsync(out2, h->codes_l2, (size_t)B * opts->n_steps * 16 * 8, hipMemcpyDeviceToDevice, c.st));
+    return HQT_OK;
+}
+
 static int sample_run(hqt_handle* h, const SampleCtx& c) {
     const hqt_config& cf = h->cfg;
     const hqt_sample_opts* opts = &c.o;
@@ -869,7 +1034,8 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
     if (cf.cond_type == HQT_COND_TEXT) {     // 64-token causal prefill (sampling.py:187-190, layers.py:107-111)
         const int T = cf.ctx_len_txt;
         HIPCHK(launch_embed_text(cond, W(h, "tok_emb_txt.weight"), W(h, "pos_emb_txt.weight"), h->x, B, T, cf.embed_dim, c.st));
-        CHK(run_position(h, c, T, 0, false));
+        if (c.levels == 3) CHK(run_position_l3(h, c, T, 0, false));
+        else CHK(run_position(h, c, T, 0, false));
         HIPCHK(launch_advance_step(h->state, T, c.st));
         first = 1;
     }
@@ -878,7 +1044,9 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
     if (opts->use_graph && !h->timing) {
         std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)(cond != nullptr), (uint64_t)noise, (uint64_t)c.feed_top, (uint64_t)c.feed_bot,
                                      (uint64_t)logits_out, (uint64_t)opts->precision,
-                                     (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot};
+                                     (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot,
+                                     (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2]};
+        { uint32_t f3[2]; memcpy(f3, &c.top_p[2], 4); memcpy(f3 + 1, &c.temperature[2], 4); key.push_back(f3[0]); key.push_back(f3[1]); }
         uint32_t f[4];
         memcpy(f, &opts->top_p_top, 4); memcpy(f + 1, &opts->top_p_bot, 4);
         memcpy(f + 2, &opts->temperature_top, 4); memcpy(f + 3, &opts->temperature_bot, 4);
@@ -925,25 +1093,32 @@ static void with_gn(GemmArgs& g, const float* stats, const float* gamma, const f
     g.gn_stats = stats; g.gn_gamma = gamma; g.gn_beta = beta; g.gn_groups = 32; g.gn_swish = swish;
 }
 
-static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64_t* code_b, int seq_layout, float* out,
-                        int clamp01, const Mode& md, hipStream_t st) {
+static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64_t* code_m, const int64_t* code_b, int seq_layout,
+                        float* out, int clamp01, const Mode& md, hipStream_t st) {
     const hqt_config& cf = h->cfg;
     const int adt = md.act_dt();
     const int r = h->dec.front().res, E = cf.s1_embed_dim;
     h->gn_ready.tensor = nullptr;
     float* gn1 = h->gn;
     float* gn2 = h->gn + (size_t)h->dec_chunk * 64;
+    const bool l3 = cf.code_levels == 3;
     {
         Timed t(h, "quant_gather", st);
-        QuantArgs q{code_t, code_b, seq_layout, W1(h, "quantize_t.embedding"), W1(h, "quantize_b.embedding"), h->quant, n, r, E, adt};
-        HIPCHK(launch_quant_gather(q, st));
+        if (l3) {
+            QuantArgs3 q{code_t, code_m, code_b, seq_layout, W1(h, "quantizers.0.embedding"), W1(h, "quantizers.1.embedding"),
+                         W1(h, "quantizers.2.embedding"), h->quant, n, r, E, adt};
+            HIPCHK(launch_quant_gather3(q, st));
+        } else {
+            QuantArgs q{code_t, code_b, seq_layout, W1(h, "quantize_t.embedding"), W1(h, "quantize_b.embedding"), h->quant, n, r, E, adt};
+            HIPCHK(launch_quant_gather(q, st));
+        }
     }
     void* cur = h->act[0];
     void* t1 = h->act[1];
     void* t2 = h->act[2];
     void* tn = h->act[3];
     {
-        GemmArgs g = conv_args(h->quant, n, r, 2 * E, 1, 0, cur, cf.s1_z_channels);
+        GemmArgs g = conv_args(h->quant, n, r, l3 ? E : 2 * E, 1, 0, cur, cf.s1_z_channels);
         CHK(run_linear(h, md, g, h->post_quant, adt, adt, st, "conv1x1"));
     }
     // GroupNorm(+swish) in front of a conv.  EXACT: statistics pass, then the normalisation is applied inside
@@ -1037,33 +1212,44 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
     return HQT_OK;
 }
 
-static int decode_impl(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_b, int seq_layout, float* out,
-                       int clamp01, int precision, void* stream) {
+static int decode_impl(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_m, const int64_t* code_b, int seq_layout, float* out,
+                       int clamp01, int precision, void* stream, int levels) {
     if (!h || !out) return fail(HQT_ERR_INVALID, "null argument");
     if (!h->finalized) return fail(HQT_ERR_STATE, "hqt_finalize_weights has not run");
     if (!h->cfg.has_stage1) return fail(HQT_ERR_STATE, "handle was created without stage 1");
-    if (!code_t && !code_b) return fail(HQT_ERR_INVALID, "code_t and code_b are both NULL");
+    if ((h->cfg.code_levels == 3) != (levels == 3)) return fail(HQT_ERR_STATE, "stage 1 has %d code levels: use the matching decode entry point", h->cfg.code_levels == 3 ? 3 : 2);
+    if (!code_t && !code_b && !code_m) return fail(HQT_ERR_INVALID, "every code grid is NULL");
     if (B < 1) return fail(HQT_ERR_INVALID, "B must be >= 1");
     HIPCHK(hipSetDevice(h->device));
     Mode md;
     md.fast = precision == HQT_PRECISION_FAST;
-    const int r = h->dec.front().res, rt = r / 2;
+    const int r = h->dec.front().res;
+    const int rt = levels == 3 ? r / 4 : r / 2, rm = r / 2;
     const size_t out_per = (size_t)h->cfg.s1_out_ch * h->dec.back().res * h->dec.back().res;
     for (int b0 = 0; b0 < B; b0 += h->dec_chunk) {
         const int n = std::min(h->dec_chunk, B - b0);
         const int64_t* ct = code_t ? code_t + (size_t)b0 * rt * rt : nullptr;
-        const int64_t* cb = code_b ? code_b + (size_t)b0 * r * r : nullptr;       // both layouts hold r*r codes per image
-        CHK(decode_chunk(h, n, ct, cb, seq_layout, out + (size_t)b0 * out_per, clamp01, md, (hipStream_t)stream));
+        const int64_t* cm = code_m ? code_m + (size_t)b0 * rm * rm : nullptr;       // every layout holds rm*rm / r*r codes per image
+        const int64_t* cb = code_b ? code_b + (size_t)b0 * r * r : nullptr;
+        CHK(decode_chunk(h, n, ct, cm, cb, seq_layout, out + (size_t)b0 * out_per, clamp01, md, (hipStream_t)stream));
     }
     return HQT_OK;
 }
 extern "C" int hqt_decode(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_b, float* out, int clamp01,
                           int precision, void* stream) {
-    return decode_impl(h, B, code_t, code_b, 0, out, clamp01, precision, stream);
+    return decode_impl(h, B, code_t, nullptr, code_b, 0, out, clamp01, precision, stream, 2);
 }
 extern "C" int hqt_decode_seq(hqt_handle* h, int B, const int64_t* codes_top, const int64_t* codes_bot, float* out,
                               int clamp01, int precision, void* stream) {
-    return decode_impl(h, B, codes_top, codes_bot, 1, out, clamp01, precision, stream);
+    return decode_impl(h, B, codes_top, nullptr, codes_bot, 1, out, clamp01, precision, stream, 2);
+}
+extern "C" int hqt_decode_l3(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_m, const int64_t* code_b, float* out,
+                             int clamp01, int precision, void* stream) {
+    return decode_impl(h, B, code_t, code_m, code_b, 0, out, clamp01, precision, stream, 3);
+}
+extern "C" int hqt_decode_seq_l3(hqt_handle* h, int B, const int64_t* codes0, const int64_t* codes1, const int64_t* codes2, float* out,
+                                 int clamp01, int precision, void* stream) {
+    return decode_impl(h, B, codes0, codes1, codes2, 1, out, clamp01, precision, stream, 3);
 }
 
 // ------------------------------------------------------------------------------------------ introspection

@@ -24,6 +24,11 @@ struct EmbedArgs {
     bf16_t* xpk;                 // optional: bf16 copy in the packed_off() layout (pk_mb) + row statistics (FAST deferred LN)
     int pk_mb;
     float* parts;                // [1][32 pk_mb][2] (sum, sumsq) of the bf16 copy
+    // three code levels (HQTransformer, hqtransformer.py:466-488): mean over 1 + 4 + 16 tokens; tok_top / tok_bot are then
+    // tok_emb_levels.0 / .1, pos_emb has 21 rows
+    int levels;                  // 0 or 2: two levels; 3: three
+    const float* tok_l2;         // [V, D] tok_emb_levels.2
+    const int64_t* codes_l2;     // [B, n_steps, 16]
 };
 hipError_t launch_embed_step(const EmbedArgs& a, hipStream_t st);
 
@@ -81,13 +86,19 @@ struct SamplerArgs {
     int top_k;                   // <= 0: none
     float top_p;                 // <= 0: none
     const float* noise;          // [n_steps, 5, B, V] or NULL
-    int draw0;                   // first draw index of slot 0 (0 for top, 1 for bottom)
+    int draw0;                   // first draw index of slot 0 (0 for top, 1 for bottom; 5 for the third level)
     const StepState* state;      // step, Philox seed and global row offset of the current call
     int n_steps;
     int64_t* out;                // top: [B, n_steps]; bottom: [B, n_steps, 4]
-    float* logits_out;           // optional [n_steps, 5, B, V]
+    float* logits_out;           // optional [n_steps, draws, B, V]
+    int draws;                   // draws per top position: 5 (two levels; 0 means 5) or 21 (three levels) -- noise / logits_out stride
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
+// depth sub-step 2 of the three-level model (hqtransformer.py:537-551): token i (raster (H1 H2 W1 W2)) =
+// tok1[codes1[b, step, parent(i)]] + pos[i] + tok0[codes0[b, step]], 16 rows per sample
+hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state, const float* tok0,
+                                 const float* tok1, const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts,
+                                 hipStream_t st);
 // raises the dynamic-LDS limit of the sampler for (V, top-p) outside any stream capture
 hipError_t sampler_configure(int V, bool use_top_p);
 
@@ -108,6 +119,18 @@ struct QuantArgs {
     int out_dtype;
 };
 hipError_t launch_quant_gather(const QuantArgs& a, hipStream_t st);
+// Three-level additive pyramid (HQVAEGenerator.decode_code, generator.py:577-599): quant[b, Y, X, c] =
+//   emb0[code_t[Y/4, X/4]][4 (4c + 2 (Y%2) + X%2) + 2 ((Y/2)%2) + (X/2)%2] + emb1[code_m[Y/2, X/2]][4c + 2 (Y%2) + X%2] + emb2[code_b[Y, X]][c]
+// (two PixelShuffle(2) steps written out); NULL level = zeros; seq_layout = the sampler's [B, n], [B, n, 4], [B, n, 16].
+struct QuantArgs3 {
+    const int64_t *code_t, *code_m, *code_b;
+    int seq_layout;
+    const float *emb0, *emb1, *emb2;   // [n_embed, 16E], [n_embed, 4E], [n_embed, E]
+    void* quant;                       // NHWC [B, r, r, E]
+    int B, r, E;
+    int out_dtype;
+};
+hipError_t launch_quant_gather3(const QuantArgs3& a, hipStream_t st);
 
 // GroupNorm statistics over NHWC x: stats[b][g] = (mean, rstd)
 hipError_t launch_gn_stats(const void* x, int dtype, float* stats, int B, int HW, int C, int groups, float eps,

@@ -84,6 +84,18 @@ __global__ __launch_bounds__(256) void embed_step_kernel(EmbedArgs a) {
             const float top = a.tok_top[ct * D + d] + a.pos_top[(long long)p * D + d];
             x[d] = top + a.tok_bot[cb[d & 3] * Dq + (d >> 2)];
         }
+    } else if (a.levels == 3) {                  // three levels: mean over the 21 tokens (hqtransformer.py:466-488)
+        long long c2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c2[k] = a.codes_l2[((long long)b * a.n_steps + p) * 16 + k];
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            float s = (a.tok_top[ct * D + d] + a.pos_top[(long long)p * D + d]) + a.pos_emb[d];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += a.tok_bot[cb[k] * D + d] + a.pos_emb[(1 + k) * D + d];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += a.tok_l2[c2[k] * D + d] + a.pos_emb[(5 + k) * D + d];
+            x[d] = s / 21.0f;
+        }
     } else {                                     // 'transformer1': mean over the 5 tokens (:535-544)
         for (int d = threadIdx.x; d < D; d += blockDim.x) {
             float s = (a.tok_top[ct * D + d] + a.pos_top[(long long)p * D + d]) + a.pos_emb[d];
@@ -123,6 +135,25 @@ __global__ __launch_bounds__(256) void depth_embed_kernel(const int64_t* codes_t
 hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
                               const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st) {
     depth_embed_kernel<<<B * 4, 256, 0, st>>>(codes_top, n_steps, state, tok, pos, x, D, xpk, pk_mb, parts);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void depth_embed_l2_kernel(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state,
+                                                             const float* tok0, const float* tok1, const float* pos, float* x, int D,
+                                                             bf16_t* xpk, int pk_mb, float* parts) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, b = row >> 4, i = row & 15;
+    const int parent = (i >> 3) * 2 + ((i & 3) >> 1);                  // (H1 H2 W1 W2) raster -> (H1 W1)
+    const long long c0 = codes0[(long long)b * n_steps + state->step];
+    const long long c1 = codes1[((long long)b * n_steps + state->step) * 4 + parent];
+    for (int d = threadIdx.x; d < D; d += blockDim.x)
+        x[(long long)row * D + d] = (tok1[c1 * D + d] + pos[(long long)i * D + d]) + tok0[c0 * D + d];
+    if (xpk) { __syncthreads(); emit_packed_row(x + (long long)row * D, row, D, xpk, pk_mb, parts, red); }
+}
+hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state, const float* tok0,
+                                 const float* tok1, const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts,
+                                 hipStream_t st) {
+    depth_embed_l2_kernel<<<B * 16, 256, 0, st>>>(codes0, codes1, n_steps, state, tok0, tok1, pos, x, D, xpk, pk_mb, parts);
     return hipGetLastError();
 }
 
@@ -417,7 +448,8 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
     const int step = a.state->step;
     const int draw = a.draw0 + slot;
     const float* lg = a.logits + (long long)r * V;
-    const long long nidx = (((long long)step * 5 + draw) * a.B + b) * V;
+    const int draws = a.draws > 0 ? a.draws : 5;
+    const long long nidx = (((long long)step * draws + draw) * a.B + b) * V;
 
     // ---- temperature (logits /= T, hierarchical_ar.py:763,779) and raw-logit dump
     for (int i = tid; i < V; i += NT) {
@@ -538,7 +570,7 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
             for (int e = 0; e < 4; ++e) q[e] = (i4 * 4 + e < V) ? a.noise[nidx + i4 * 4 + e] : 1.0f;
         } else {
             uint32_t rnd[4];
-            philox4x32_10((uint32_t)i4, (uint32_t)(step * 5 + draw), (uint32_t)grow, (uint32_t)(grow >> 32), k0, k1, rnd);
+            philox4x32_10((uint32_t)i4, (uint32_t)(step * draws + draw), (uint32_t)grow, (uint32_t)(grow >> 32), k0, k1, rnd);
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[e] = -logf(((float)(rnd[e] >> 8) + 0.5f) * (1.0f / 16777216.0f));
         }
@@ -631,6 +663,38 @@ hipError_t launch_quant_gather(const QuantArgs& a, hipStream_t st) {
     const int grid = a.B * a.r * a.r;
     if (a.out_dtype == DT_BF16) quant_gather_kernel<bf16_t><<<grid, 256, 0, st>>>(a);
     else quant_gather_kernel<float><<<grid, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void quant_gather3_kernel(QuantArgs3 a) {
+    const int pix = blockIdx.x;                      // b * r * r + Y * r + X
+    const int r = a.r, rm = r / 2, rt = r / 4, E = a.E;
+    const int b = pix / (r * r), Y = (pix / r) % r, X = pix % r;
+    long long c0 = -1, c1 = -1, c2 = -1;
+    if (a.code_t) c0 = a.code_t[((long long)b * rt + (Y >> 2)) * rt + (X >> 2)];      // same index in both layouts
+    if (a.code_m) {
+        if (a.seq_layout) c1 = a.code_m[(((long long)b * rt + (Y >> 2)) * rt + (X >> 2)) * 4 + ((Y >> 1) & 1) * 2 + ((X >> 1) & 1)];
+        else c1 = a.code_m[((long long)b * rm + (Y >> 1)) * rm + (X >> 1)];
+    }
+    if (a.code_b) {
+        if (a.seq_layout) c2 = a.code_b[(((long long)b * rt + (Y >> 2)) * rt + (X >> 2)) * 16 + (Y & 3) * 4 + (X & 3)];
+        else c2 = a.code_b[((long long)b * r + Y) * r + X];
+    }
+    TO* out = reinterpret_cast<TO*>(a.quant) + (long long)pix * E;
+    const int sub = (Y & 1) * 2 + (X & 1), subm = ((Y >> 1) & 1) * 2 + ((X >> 1) & 1);
+    for (int c = threadIdx.x; c < E; c += blockDim.x) {
+        float v = 0.0f;                                  // reference order: (PS(PS(q0) + q1)) + q2
+        if (c0 >= 0) v = a.emb0[c0 * 16 * E + 4 * (4 * c + sub) + subm];
+        if (c1 >= 0) v += a.emb1[c1 * 4 * E + 4 * c + sub];
+        if (c2 >= 0) v += a.emb2[c2 * E + c];
+        st1<TO>(out + c, v);
+    }
+}
+hipError_t launch_quant_gather3(const QuantArgs3& a, hipStream_t st) {
+    const int grid = a.B * a.r * a.r;
+    if (a.out_dtype == DT_BF16) quant_gather3_kernel<bf16_t><<<grid, 256, 0, st>>>(a);
+    else quant_gather3_kernel<float><<<grid, 256, 0, st>>>(a);
     return hipGetLastError();
 }
 

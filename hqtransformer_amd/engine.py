@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import PRECISION_EXACT, PRECISION_FAST, hqt_config, hqt_sample_opts
+from ._lib import PRECISION_EXACT, PRECISION_FAST, hqt_config, hqt_sample_opts, hqt_sample_opts_l3
 from .spec import Stage1Spec, Stage2Spec
 
 
@@ -30,6 +30,8 @@ def make_config(s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], max_batch: i
         c.vocab_top, c.vocab_bot, c.vocab_txt = s2.vocab_top, s2.vocab_bot, s2.vocab_txt
         c.ctx_len_img, c.ctx_len_txt, c.n_classes = s2.ctx_len_img, s2.ctx_len_txt, s2.n_classes
         c.cond_type, c.embedding_type, c.gelu_approx = s2.cond, s2.embedding, int(s2.gelu_approx)
+    if (s2 is not None and getattr(s2, 'levels', 2) == 3) or (s1 is not None and getattr(s1, 'code_levels', 2) == 3):
+        c.code_levels = 3
     if s1 is not None:
         c.has_stage1 = 1
         c.s1_ch, c.s1_n_mult = s1.ch, len(s1.ch_mult)
@@ -160,6 +162,77 @@ class Engine:
         if return_logits:
             return out_top, out_bot, logits
         return out_top, out_bot
+
+    # ------------------------------------------------------------------ three code levels (hqt_sample_l3 / hqt_decode_l3)
+    def sample3(self, batch: int, cond: Optional[torch.Tensor], n_steps: int, *, precision: int = PRECISION_FAST,
+                top_k: Sequence[Optional[int]] = (None, None, None), top_p: Sequence[Optional[float]] = (None, None, None),
+                temperature: Sequence[float] = (1.0, 1.0, 1.0), noise: Optional[torch.Tensor] = None, seed: int = 0,
+                sample_offset: int = 0, force: Optional[Sequence[torch.Tensor]] = None, return_logits: bool = False,
+                use_graph: bool = True):
+        """Three-level sampling: returns (codes0 [B, n], codes1 [B, n, 4], codes2 [B, n, 16][, logits [n, 21, B, V]])."""
+        dev = self.device
+        B, V = int(batch), self.s2.vocab_top
+        o = hqt_sample_opts_l3()
+        o.precision, o.n_steps = int(precision), int(n_steps)
+        for i in range(3):
+            o.top_k[i] = int(top_k[i]) if top_k[i] else 0
+            o.top_p[i] = float(top_p[i]) if top_p[i] else 0.0
+            o.temperature[i] = float(temperature[i])
+        o.seed, o.sample_offset, o.use_graph = int(seed) & (2 ** 64 - 1), int(sample_offset), int(bool(use_graph))
+
+        def prep(t, shape, dtype, what):
+            if t is None:
+                return None
+            t = torch.as_tensor(t).to(device=dev, dtype=dtype).contiguous()
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f'{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
+            return t
+        if self.s2.cond == 1:
+            cond = prep(cond, (B,), torch.int64, 'cond')
+        elif self.s2.cond == 2:
+            cond = prep(cond, (B, self.s2.ctx_len_txt), torch.int64, 'cond')
+        else:
+            cond = None
+        noise = prep(noise, (n_steps, 21, B, V), torch.float32, 'noise')
+        f = [None, None, None]
+        if force is not None:
+            f = [prep(force[0], (B, n_steps), torch.int64, 'force[0]'), prep(force[1], (B, n_steps, 4), torch.int64, 'force[1]'),
+                 prep(force[2], (B, n_steps, 16), torch.int64, 'force[2]')]
+        outs = [torch.empty(shp, dtype=torch.int64, device=dev) for shp in ((B, n_steps), (B, n_steps, 4), (B, n_steps, 16))]
+        logits = torch.empty((n_steps, 21, B, V), dtype=torch.float32, device=dev) if return_logits else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.hqt_sample_l3(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(f[0]), _ptr(f[1]), _ptr(f[2]),
+                                              _ptr(logits), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), C.c_void_p(stream)))
+        self._keep = (cond, noise, f)
+        return (outs[0], outs[1], outs[2], logits) if return_logits else tuple(outs)
+
+    def decode3(self, codes: Sequence[Optional[torch.Tensor]], *, precision: int = PRECISION_EXACT, clamp01: bool = False,
+                seq_layout: bool = False) -> torch.Tensor:
+        """``HQVAEGenerator.decode_code([t, m, b])``; ``seq_layout``: the sampler's [B, n], [B, n, 4], [B, n, 16]."""
+        dev = self.device
+        ref = next((c for c in codes if c is not None), None)
+        if ref is None or len(codes) != 3:
+            raise ValueError('decode3 takes three code tensors, at least one not None')
+        B = int(ref.shape[0])
+        r = self.s1.z_res
+        n = (r // 4) ** 2
+        want = ((B, n), (B, n, 4), (B, n, 16)) if seq_layout else ((B, r // 4, r // 4), (B, r // 2, r // 2), (B, r, r))
+        cs = []
+        for c, w in zip(codes, want):
+            if c is not None:
+                c = c.to(device=dev, dtype=torch.int64).contiguous()
+                if tuple(c.shape) != w:
+                    raise ValueError(f'code grid: expected {w}, got {tuple(c.shape)}')
+            cs.append(c)
+        H = self.s1.resolution
+        out = torch.empty((B, self.s1.out_ch, H, H), dtype=torch.float32, device=dev)
+        fn = self.lib.hqt_decode_seq_l3 if seq_layout else self.lib.hqt_decode_l3
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(fn(self.h, B, _ptr(cs[0]), _ptr(cs[1]), _ptr(cs[2]), _ptr(out), int(clamp01), int(precision), C.c_void_p(stream)))
+        self._keep_dec = cs
+        return out
 
     # ------------------------------------------------------------------ stage 1
     def decode(self, code_t: Optional[torch.Tensor], code_b: Optional[torch.Tensor], *, precision: int = PRECISION_EXACT,

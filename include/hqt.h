@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HQT_ABI_VERSION 1
+#define HQT_ABI_VERSION 2
 
 typedef enum {
     HQT_OK = 0,
@@ -70,6 +70,10 @@ typedef struct {
     /* sizing */
     int32_t max_batch;              /* largest B of any later call; workspaces are sized once */
     int32_t max_steps;              /* largest number of top positions per call (<= ctx_len_img) */
+    /* three code levels: stage 2 = HQTransformer 'multilevel-hq' / 'parallel-add'
+     * (hqvae/models/stage2/hqtransformer.py:24-205, one vocabulary size for all levels = vocab_top), stage 1 =
+     * HQVAEGenerator with code_levels = 3 (generator.py:451-515).  0 or 2: the two-level models above. */
+    int32_t code_levels;
 } hqt_config;
 
 /* Sampling options = the keyword arguments of sampling_ihqgpt (hqvae/utils/sampling.py:164-177).
@@ -124,6 +128,32 @@ int hqt_clone(hqt_handle* src, hqt_handle** out);
 int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_sample_opts* opts, const float* noise,
                const int64_t* force_top, const int64_t* force_bot, float* logits_out,
                int64_t* out_top, int64_t* out_bot, void* stream);
+
+/* Three-level counterparts.  hqt_sample_l3 replaces sampling_hqtransformer + HQTransformer.sampling_step
+ * (hqvae/utils/sampling.py:240-307, hqtransformer.py:409-635): per top position 1 + 4 + 16 codes.
+ *   noise / logits_out  fp32 [n_steps, 21, B, V], draw order level 0, level-1 slots 0..3, level-2 tokens 0..15 in
+ *                       (H1 H2 W1 W2) raster order (= kh * 4 + kw of the 4x4 block)
+ *   force0/1/2          optional teacher forcing, int64 [B, n_steps] / [B, n_steps, 4] / [B, n_steps, 16]
+ *   out0/1/2            int64 [B, n_steps], [B, n_steps, 4], [B, n_steps, 16]
+ * hqt_decode_l3 replaces HQVAEGenerator.decode_code([t, m, b]) (generator.py:577-599): code grids [B, r/4, r/4],
+ * [B, r/2, r/2], [B, r, r] (any may be NULL = zero quant); hqt_decode_seq_l3 takes the sampler's own outputs and folds
+ * the rearranges of sampling_hqmodel.py:150-153 into the lookup. */
+typedef struct {
+    int32_t precision, n_steps;
+    int32_t top_k[3];
+    float top_p[3];
+    float temperature[3];
+    uint64_t seed;
+    int64_t sample_offset;
+    int32_t use_graph;
+} hqt_sample_opts_l3;
+int hqt_sample_l3(hqt_handle* h, int B, const int64_t* cond, const hqt_sample_opts_l3* opts, const float* noise,
+                  const int64_t* force0, const int64_t* force1, const int64_t* force2, float* logits_out,
+                  int64_t* out0, int64_t* out1, int64_t* out2, void* stream);
+int hqt_decode_l3(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_m, const int64_t* code_b, float* out_pixels,
+                  int clamp01, int precision, void* stream);
+int hqt_decode_seq_l3(hqt_handle* h, int B, const int64_t* codes0, const int64_t* codes1, const int64_t* codes2, float* out_pixels,
+                      int clamp01, int precision, void* stream);
 
 /* hqt_decode -- replaces SimRQGAN2Generator.decode_code (generator.py:323-367: codebook lookup
  * quantizer.py:179-186, PixelShuffle, concat, post_quant_conv_b, Decoder.forward layers.py:385-410).

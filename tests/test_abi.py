@@ -35,8 +35,9 @@ def test_abi_version_and_error_paths_without_gpu(lib):
 
 def test_struct_layout_matches_header():
     import ctypes as C
-    assert C.sizeof(_lib.hqt_config) == 4 * (1 + 1 + 4 + 3 + 3 + 3 + 1 + 2 + 8 + 1 + 1 + 4 + 5 + 3 + 2)
+    assert C.sizeof(_lib.hqt_config) == 4 * (1 + 1 + 4 + 3 + 3 + 3 + 1 + 2 + 8 + 1 + 1 + 4 + 5 + 3 + 2 + 1)
     assert C.sizeof(_lib.hqt_sample_opts) == 56
+    assert C.sizeof(_lib.hqt_sample_opts_l3) == 72 and _lib.hqt_sample_opts_l3.seed.offset == 48
 
 
 def test_no_cpu_fallback():

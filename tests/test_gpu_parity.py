@@ -377,3 +377,74 @@ def test_error_reporting(tiny_cls):
     e2 = Engine(spec, None, dev(), 2)
     with pytest.raises(HqtError):
         e2.finalize()                                                 # missing weights
+
+
+# ----------------------------------------------------------------------------------------- three code levels
+def test_l3_sampling_vs_reference_fixture_and_oracle():
+    """Three-level HQTransformer ('parallel-add', 1 + 4 + 16 codes per position) through hqt_sample_l3: EXACT codes bit-exact
+    and logits <= 2e-4 against fixture G7 generated from the reference, eager and graph; FAST teacher-forced logits
+    within the bf16 budget."""
+    fx = load('g7_l3_tiny_cls.npz')
+    spec = Stage2Spec(**json.loads(str(fx['spec'])))
+    weights = synth.stage2_weights(spec, int(fx['weight_seed']), 'fixture')
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = np.maximum(np.random.default_rng([int(fx['noise_seed']), 0x9e3779b9]).standard_exponential((n, 21, B, spec.vocab_top), dtype=np.float32),
+                       np.float32(1e-30))
+    eng = engine_s2(spec, weights, 4)
+    for si, (tk, tp, T) in enumerate(json.loads(str(fx['settings']))):
+        for graph in (False, True):
+            c0, c1, c2, lg = eng.sample3(B, torch.full((B,), 7), n, precision=PRECISION_EXACT, top_k=tk, top_p=tp, temperature=T,
+                                         noise=torch.from_numpy(noise), return_logits=True, use_graph=graph)
+            assert np.abs(np_(lg)[fx['keep_steps']] - fx[f'logits_{si}']).max() <= LOGIT_TOL
+            assert (np_(c0) == fx[f'codes0_{si}']).all() and (np_(c1) == fx[f'codes1_{si}']).all() and (np_(c2) == fx[f'codes2_{si}']).all()
+    force = [torch.from_numpy(fx[f'codes{i}_0'].copy()) for i in range(3)]
+    ex = eng.sample3(B, torch.full((B,), 7), 16, precision=PRECISION_EXACT, noise=torch.from_numpy(noise[:16]),
+                     force=[f[:, :16] for f in force], return_logits=True, use_graph=False)
+    for graph in (False, True):
+        fa = eng.sample3(B, torch.full((B,), 7), 16, precision=PRECISION_FAST, noise=torch.from_numpy(noise[:16]),
+                         force=[f[:, :16] for f in force], return_logits=True, use_graph=graph)
+        err = (fa[3] - ex[3]).abs().max().item()
+        assert err <= 0.15, f'FAST three-level logits differ from EXACT by {err}'
+
+
+def test_l3_wide_batch_vs_oracle():
+    """B = 64 at D = 256: the third level runs 1024-row GEMMs (tiled MFMA path in FAST), levels 0 / 1 the streaming GEMMs."""
+    spec = Stage2Spec(embed_dim=256, n_layers=1, n_heads=4, n_layers_depth=1, vocab_top=512, vocab_bot=512, vocab_txt=64,
+                      ctx_len_img=64, ctx_len_txt=16, n_classes=10, cond=1, embedding=0, levels=3)
+    weights = synth.stage2_weights(spec, 71, 'fixture')
+    B, n = 64, 3
+    noise = np.maximum(np.random.default_rng([72, 1]).standard_exponential((n, 21, B, 512), dtype=np.float32), np.float32(1e-30))
+    cond = np.arange(B) % 10
+    want = O.OracleStage2L3(spec, weights).sample(cond, B, n, noise, (None, 64, 32), (None, 0.9, None), (1.0, 0.9, 0.8), return_logits=True)
+    eng = engine_s2(spec, weights, B)
+    got = eng.sample3(B, torch.from_numpy(cond), n, precision=PRECISION_EXACT, top_k=(None, 64, 32), top_p=(None, 0.9, None),
+                      temperature=(1.0, 0.9, 0.8), noise=torch.from_numpy(noise), return_logits=True, use_graph=False)
+    assert np.abs(np_(got[3]) - want[3]).max() <= LOGIT_TOL
+    assert all((np_(got[i]) == want[i]).all() for i in range(3))
+    force = [torch.from_numpy(w) for w in want[:3]]
+    for graph in (False, True):
+        fa = eng.sample3(B, torch.from_numpy(cond), n, precision=PRECISION_FAST, top_k=(None, 64, 32), top_p=(None, 0.9, None),
+                         temperature=(1.0, 0.9, 0.8), noise=torch.from_numpy(noise), force=force, return_logits=True, use_graph=graph)
+        err = np.abs(np_(fa[3]) - want[3]).max()
+        assert err <= 0.15, f'FAST three-level logits differ from the oracle by {err} (graph={graph})'
+
+
+def test_l3_decode_vs_reference_fixture():
+    fx = load('g8_l3_decode.npz')
+    spec = Stage1Spec(**json.loads(str(fx['spec'])))
+    weights = synth.stage1_weights(spec, int(fx['weight_seed']), 'fixture')
+    eng = engine_s1(spec, weights, 2)
+    ct, cm, cb = (torch.from_numpy(fx[k]) for k in ('code_t', 'code_m', 'code_b'))
+    px = np_(eng.decode3([ct, cm, cb], precision=PRECISION_EXACT))
+    assert np.abs(px - fx['pixels']).max() <= PIXEL_TOL
+    assert np.abs(np_(eng.decode3([ct[:1], None, None])) - fx['pixels_top_only']).max() <= PIXEL_TOL
+    assert np.abs(np_(eng.decode3([None, None, cb[:1]])) - fx['pixels_bot_only']).max() <= PIXEL_TOL
+    # sampler layout: [B, n], [B, n, 4], [B, n, 16] with the rearranges folded into the lookup
+    K = ct.shape[1]
+    s0 = ct.reshape(2, K * K)
+    s1 = cm.reshape(2, K, 2, K, 2).permute(0, 1, 3, 2, 4).reshape(2, K * K, 4)
+    s2 = cb.reshape(2, K, 4, K, 4).permute(0, 1, 3, 2, 4).reshape(2, K * K, 16)
+    assert (np_(eng.decode3([s0, s1, s2], seq_layout=True)) == px).all()
+    fast = np_(eng.decode3([ct, cm, cb], precision=PRECISION_FAST))
+    d = np.abs(fast - fx['pixels'])
+    assert d.max() <= 0.1 and d.mean() <= 1e-2
