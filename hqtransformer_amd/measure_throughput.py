@@ -24,7 +24,7 @@ import torch
 
 from .config import load_config, parse_dotlist
 from .models import ImageGPT2
-from .sampling import rearrange_codes, sampling_ihqgpt
+from .sampling import rearrange_codes, rearrange_codes3, sampling_hqtransformer, sampling_ihqgpt
 
 EXPERIMENT_DEFAULTS = dict(f=32, model='huge', d=4, c=16384, batch_size=50, n_loop=6, warmup=1, model_path='',
                            top_resolution=8, code_levels=2, decode_batch=0, decode_precision='fast', seed=0, inflight=1)
@@ -41,8 +41,8 @@ def load_model(result_path: str) -> ImageGPT2:
 
 def main(args) -> dict:
     torch.set_grad_enabled(False)
-    if args.code_levels != 2:
-        raise NotImplementedError('code_levels=3 (HQTransformer 3-level path) is not built yet (SURVEY.md §8f rank 1)')
+    if args.code_levels not in (2, 3):
+        raise NotImplementedError('code_levels must be 2 or 3')
     random.seed(args.seed)
     model_ar = load_model(args.model_path)
     device = torch.device('cuda')
@@ -60,6 +60,8 @@ def main(args) -> dict:
 
     pipe = None
     if int(args.inflight) > 1:
+        if args.code_levels == 3:
+            raise NotImplementedError('inflight > 1 with code_levels=3')
         from .pipeline import InflightSampler
         pipe = InflightSampler(model_ar, lanes=int(args.inflight), device=device)
 
@@ -75,7 +77,21 @@ def main(args) -> dict:
                         phase_events=(starts[i], middles[i], ends[i]))
         if pipe is not None:
             pipe.drain()
-        for i in range(n_iter_per_loop if pipe is None else 0):
+        for i in range(n_iter_per_loop if (pipe is None and args.code_levels == 3) else 0):     # measure_throughput/__main__.py:116-138
+            starts[i].record()
+            codes_levels = sampling_hqtransformer(model_ar.stage2, num_candidates=batch_size, cond=random.randint(0, 999),
+                                                  top_k=[None] * 3, top_p=[None] * 3, softmax_temperature=[1.0] * 3, use_fp16=True,
+                                                  is_tqdm=False, max_seq_len=args.top_resolution * args.top_resolution, model_stage1=None)
+            middles[i].record()
+            if args.decode_batch and args.decode_batch < batch_size:
+                grids = rearrange_codes3(codes_levels, args.top_resolution)
+                pixels = torch.cat([model_ar.stage1.decode_code([g[j:j + args.decode_batch] for g in grids], precision=args.decode_precision)
+                                    for j in range(0, batch_size, args.decode_batch)], dim=0)
+                _ = (0.5 * pixels + 0.5).clamp(0, 1)
+            else:
+                _ = model_ar.stage1.decode_sequences(codes_levels, precision=args.decode_precision, clamp01=True)
+            ends[i].record()
+        for i in range(n_iter_per_loop if (pipe is None and args.code_levels == 2) else 0):
             starts[i].record()
             codes_t, codes_b = sampling_ihqgpt(model_ar.stage2, cond=random.randint(0, 999), num_candidates=batch_size,
                                                top_k_top=None, top_p_top=None, top_k_bot=None, top_p_bot=None,

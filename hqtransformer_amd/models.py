@@ -103,7 +103,8 @@ class _Stage:
 
 
 class HQTransformerStage2(_Stage):
-    """Counterpart of ``iHQGPT`` (``hqvae/models/stage2/hierarchical_ar.py:23-216``) for model_type 'parallel'."""
+    """Counterpart of ``iHQGPT`` (``hqvae/models/stage2/hierarchical_ar.py:23-216``) for model_type 'parallel' and, with
+    ``spec.levels == 3``, of the three-level ``HQTransformer`` 'parallel-add' (``hqvae/models/stage2/hqtransformer.py``)."""
 
     def __init__(self, spec: Stage2Spec, seed: int = 0):
         super().__init__(stage2_param_shapes(spec), synth.stage2_weights(spec, seed, 'bench'))
@@ -115,6 +116,7 @@ class HQTransformerStage2(_Stage):
         self.n_layers = spec.n_layers
         self.n_layers_depth = spec.n_layers_depth
         self.model_type = 'parallel'
+        self.code_level = spec.levels               # HQTransformer.code_level (hqtransformer.py:185)
 
     # attributes sampling.py:183-192 and the notebook read
     @property
@@ -164,21 +166,28 @@ class HQVAEStage1(_Stage):
             self._engine = e
         return self._lane(e, lane)
 
-    def decode_code(self, code_t: Optional[torch.Tensor], code_b: Optional[torch.Tensor], precision: Optional[str] = None,
+    def decode_code(self, code_t, code_b: Optional[torch.Tensor] = None, precision: Optional[str] = None,
                     clamp01: bool = False, lane: int = 0) -> torch.Tensor:
         """``SimRQGAN2Generator.decode_code`` (generator.py:323-367): int64 code grids -> fp32 [B, 3, H, W],
         unclamped; either level may be None (zero quant).  ``precision`` 'exact' (fp32, the reference's
         arithmetic for this call) or 'fast' (bf16 MFMA); defaults to ``self.precision``."""
+        if isinstance(code_t, (list, tuple)):        # HQVAEGenerator.decode_code([t, m, b]) (generator.py:577-599)
+            codes = list(code_t)
+            ref = next(c for c in codes if c is not None)
+            prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
+            return self.engine(int(ref.shape[0]), lane).decode3(codes, precision=prec, clamp01=clamp01)
         assert code_t is not None or code_b is not None
         ref = code_t if code_t is not None else code_b
         prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
         return self.engine(int(ref.shape[0]), lane).decode(code_t, code_b, precision=prec, clamp01=clamp01)
 
-    def decode_sequences(self, codes_top: torch.Tensor, codes_bot: torch.Tensor, precision: Optional[str] = None,
+    def decode_sequences(self, codes_top, codes_bot: Optional[torch.Tensor] = None, precision: Optional[str] = None,
                          clamp01: bool = False, lane: int = 0) -> torch.Tensor:
         """Decode the sampler's own outputs ([B, HW], [B, HW, 4]); the two rearranges of
         sampling_hqmodel.py:119-120 are folded into the codebook-gather addressing."""
         prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
+        if isinstance(codes_top, (list, tuple)):     # three levels: [B, L], [B, L, 4], [B, L, 16]
+            return self.engine(int(codes_top[0].shape[0]), lane).decode3(list(codes_top), precision=prec, clamp01=clamp01, seq_layout=True)
         return self.engine(int(codes_top.shape[0]), lane).decode(codes_top, codes_bot, precision=prec, clamp01=clamp01, seq_layout=True)
 
 

@@ -83,6 +83,64 @@ def sampling_ihqgpt(model,
                       noise=noise, seed=seed or 0, sample_offset=sample_offset, force_top=force_top, use_graph=use_graph)
 
 
+def sampling_hqtransformer(model,
+                           num_candidates: int,
+                           cond,
+                           top_k: Optional[List[float]] = None,
+                           top_p: Optional[List[float]] = None,
+                           softmax_temperature: List[float] = [1.0, 1.0, 1.0],
+                           is_tqdm: bool = True,
+                           use_fp16: bool = True,
+                           max_seq_len: int = 256,
+                           model_stage1=None,
+                           noise: Optional[torch.Tensor] = None,
+                           sample_offset: int = 0,
+                           seed: Optional[int] = None,
+                           use_graph: bool = True,
+                           lane: int = 0):
+    """Counterpart of ``hqvae.utils.sampling.sampling_hqtransformer`` (sampling.py:240-307) for the three-level
+    HQTransformer: returns ``[codes0 int64 [B, L], codes1 [B, L, 4], codes2 [B, L, 16]]`` on the model's GPU.
+    ``top_k`` / ``top_p`` / ``softmax_temperature`` are per-level lists (None = no cut-off); ``cond`` as in
+    ``sampling_ihqgpt``.  Extensions: ``noise`` fp32 [L, 21, B, V], ``seed`` / ``sample_offset``, ``lane``."""
+    spec = model.spec
+    if spec.levels != 3:
+        raise ValueError('sampling_hqtransformer needs the three-level HQTransformer (stage2.type multilevel-hq)')
+    if model.use_txt_cond:
+        cond = torch.as_tensor(cond)
+        if cond.dim() != 2:
+            raise ValueError('text conditioning expects cond of shape [B, ctx_len_txt]')
+        B = int(cond.shape[0])
+    else:
+        B = int(num_candidates)
+        if model.use_cls_cond:
+            if isinstance(cond, int):
+                cond = torch.full((B,), int(cond), dtype=torch.int64)
+            else:
+                cond = torch.as_tensor(cond).reshape(-1)
+                if cond.numel() == 1:
+                    cond = cond.repeat(B)
+            if int(cond.min()) < 0 or int(cond.max()) >= spec.n_classes:
+                raise IndexError('index out of range in self')
+        else:
+            cond = None
+    top_k = list(top_k) if top_k is not None else [None, None, None]
+    top_p = list(top_p) if top_p is not None else [None, None, None]
+    eng = model.engine(B, max_seq_len, lane)
+    if seed is None and noise is None:
+        seed = _seed_from_torch()
+    return list(eng.sample3(B, cond, max_seq_len, precision=PRECISION_FAST if use_fp16 else PRECISION_EXACT, top_k=top_k, top_p=top_p,
+                            temperature=softmax_temperature, noise=noise, seed=seed or 0, sample_offset=sample_offset, use_graph=use_graph))
+
+
+def rearrange_codes3(codes: List[torch.Tensor], top_resolution: int):
+    """'B (H W) -> B H W' and 'B (H W) (kerH kerW) -> B (H kerH) (W kerW)' with kerH = 2 and 4
+    (``sampling_hqmodel.py:150-153``, ``measure_throughput/__main__.py:128-130``)."""
+    B, K = codes[0].shape[0], top_resolution
+    return (codes[0].reshape(B, K, K),
+            codes[1].reshape(B, K, K, 2, 2).permute(0, 1, 3, 2, 4).reshape(B, 2 * K, 2 * K),
+            codes[2].reshape(B, K, K, 4, 4).permute(0, 1, 3, 2, 4).reshape(B, 4 * K, 4 * K))
+
+
 def rearrange_codes(codes_top: torch.Tensor, codes_bot: torch.Tensor, top_resolution: int):
     """'B (H W) -> B H W' and 'B (H W) (kerH kerW) -> B (H kerH) (W kerW)' with kerH = kerW = 2
     (``sampling_hqmodel.py:119-120``, ``measure_throughput/__main__.py:106-107``) as pure views."""

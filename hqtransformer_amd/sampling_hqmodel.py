@@ -20,7 +20,7 @@ import torch
 
 from .config import load_config
 from .models import ImageGPT2
-from .sampling import sampling_ihqgpt
+from .sampling import sampling_hqtransformer, sampling_ihqgpt
 from .utils import set_seed
 
 
@@ -74,8 +74,8 @@ def save_pickle(fname, data):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.code_level != 2:
-        raise NotImplementedError('--code-level 3 (HQTransformer 3-level path) is not built yet (SURVEY.md §8f rank 1)')
+    if args.code_level not in (2, 3):
+        raise NotImplementedError('--code-level must be 2 or 3')
     set_seed(args.seed)
     os.makedirs(args.result_path, exist_ok=True)
     model = load_model(args.model_path).eval()
@@ -85,6 +85,14 @@ def main(argv=None):
         for num_batches in range(per_class // n):
             targets = torch.ones(n, dtype=torch.long) * cls_idx
             temps = [args.temperature * (args.temperature_decay ** i) for i in range(args.code_level)]
+            if args.code_level == 3:                 # sampling_hqmodel.py:131-153,201-214
+                codes = sampling_hqtransformer(model.stage2, cond=cls_idx, num_candidates=n, top_k=[args.top_k] * 3, top_p=[args.top_p] * 3,
+                                               softmax_temperature=temps, use_fp16=True, is_tqdm=False,
+                                               max_seq_len=args.top_resolution * args.top_resolution, model_stage1=model.stage1)
+                pixels = model.stage1.decode_sequences(codes, precision=args.decode_precision, clamp01=True)
+                save_pickle(os.path.join(args.result_path, f'samples_({cls_idx + 1}_{num_batches}).pkl'), pixels.cpu().numpy())
+                np.savez(os.path.join(args.result_path, f'targets_({cls_idx + 1}_{num_batches}).npz'), targets=targets.cpu().numpy())
+                continue
             codes_t, codes_b = sampling_ihqgpt(model.stage2, cond=cls_idx, num_candidates=n, top_k_top=args.top_k,
                                                top_p_top=args.top_p, top_k_bot=args.top_k, top_p_bot=args.top_p,
                                                softmax_temperature=temps, use_fp16=True, is_tqdm=False,

@@ -1,1 +1,1 @@
-from hqtransformer_amd.sampling import sampling_ihqgpt, rearrange_codes  # noqa: F401
+from hqtransformer_amd.sampling import sampling_ihqgpt, sampling_hqtransformer, rearrange_codes, rearrange_codes3  # noqa: F401

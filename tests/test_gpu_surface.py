@@ -135,3 +135,36 @@ def test_txt2img_counterpart_writes_reference_format(tmp_path):
              '--tokenizer-vocab', str(tmp_path / 'v.json'), '--tokenizer-merges', str(tmp_path / 'm.txt'), '--top-k', '50'])
     c = pickle.load(open(out2 / 'samples_(1_2).pkl', 'rb'))
     assert c.shape == (2, 3, 64, 64) and np.isfinite(c).all() and np.abs(c[0] - c[1]).max() > 0      # different prompts, different images
+
+
+def test_three_level_surface_matches_the_oracle(tmp_path, capsys):
+    """ImageGPT2 from a multilevel-hq / hqvae config: sampling_hqtransformer + stage1.decode_code([t, m, b]) against the
+    CPU oracle, and the harness / driver counterparts in their code_levels = 3 modes."""
+    from hqtransformer_amd import measure_throughput as mt, sampling_hqmodel as sh
+    from hqtransformer_amd.sampling import rearrange_codes3, sampling_hqtransformer
+    l3 = os.path.join(ROOT, 'configs', 'tiny-l3.yaml')
+    m = ImageGPT2(load_config(l3), seed=9).to('cuda').eval()
+    s2, s1 = m.stage2.spec, m.stage1.spec
+    assert s2.levels == 3 and s1.code_levels == 3 and m.stage2.code_level == 3
+    B, n = 3, 16
+    noise = np.maximum(np.random.default_rng(5).standard_exponential((n, 21, B, s2.vocab_top), dtype=np.float32), np.float32(1e-30))
+    codes = sampling_hqtransformer(m.stage2, num_candidates=B, cond=123, top_k=[100, 50, None], top_p=[0.9, None, None],
+                                   softmax_temperature=[1.0, 0.9, 0.8], use_fp16=False, is_tqdm=False, max_seq_len=n,
+                                   noise=torch.from_numpy(noise))
+    assert [tuple(c.shape) for c in codes] == [(B, n), (B, n, 4), (B, n, 16)] and all(c.dtype == torch.int64 and c.is_cuda for c in codes)
+    w2 = {k: v.numpy() for k, v in m.stage2.state_dict().items()}
+    w1 = {k: v.numpy() for k, v in m.stage1.state_dict().items()}
+    want = O.OracleStage2L3(s2, w2).sample(np.full(B, 123), B, n, noise, (100, 50, None), (0.9, None, None), (1.0, 0.9, 0.8))
+    assert all((c.cpu().numpy() == w).all() for c, w in zip(codes, want))
+    grids = rearrange_codes3(codes, 4)
+    px = m.stage1.decode_code(list(grids))
+    ref = O.OracleStage1(s1, w1).decode_codes3(list(O.rearrange_codes3(*want, 4)))
+    assert tuple(px.shape) == (B, 3, 64, 64) and np.abs(px.cpu().numpy() - ref).max() <= 1e-4
+    assert np.abs(m.stage1.decode_sequences(codes, clamp01=True).cpu().numpy() - O.postprocess(ref)).max() <= 1e-4
+    out = mt.main(parse_dotlist([f'model_path={l3}', 'batch_size=500', 'n_loop=2', 'warmup=1', 'code_levels=3', 'top_resolution=4'],
+                                mt.EXPERIMENT_DEFAULTS))
+    assert 'ms/sample (ar:' in capsys.readouterr().out and out['ms_per_sample'] > 0
+    sh.main(['-r', str(tmp_path), '-m', l3, '--batch-size', '2', '--num-classes', '1', '--samples-per-class', '2', '--code-level', '3',
+             '--top-k', '100', '--top-resolution', '4'])
+    pxs = pickle.load(open(tmp_path / 'samples_(1_0).pkl', 'rb'))
+    assert pxs.dtype == np.float32 and pxs.shape == (2, 3, 64, 64) and pxs.min() >= 0 and pxs.max() <= 1
