@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 from hqtransformer_amd import synth  # noqa: E402
 from hqtransformer_amd.config import load_config  # noqa: E402
 from hqtransformer_amd.models import ImageGPT2  # noqa: E402
-from hqtransformer_amd.sampling import sampling_ihqgpt  # noqa: E402
+from hqtransformer_amd.sampling import sampling_hqtransformer, sampling_ihqgpt  # noqa: E402
 from hqtransformer_amd.spec import decoder_plan, work_per_image  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
@@ -65,25 +65,32 @@ def cpu_baseline(cfg, s2, s1, batch):
     """Reference CPU path as restated by the oracle (fp32 numpy/OpenBLAS on all host cores), bounded sample:
     2 top positions of the AR loop at the bench batch + the decode of 1 image, scaled to images/s with the
     reference harness's accounting (64 positions per image batch, decode per image)."""
-    from oracle.hqt_oracle import OracleStage1, OracleStage2
+    from oracle.hqt_oracle import OracleStage1, OracleStage2, OracleStage2L3
     cores = os.cpu_count() or 1
+    three = s2.levels == 3
     w2 = synth.stage2_weights(s2, 0, 'bench')
     w1 = synth.stage1_weights(s1, 1, 'bench')
-    orc2, orc1 = OracleStage2(s2, w2), OracleStage1(s1, w1)
+    orc2, orc1 = (OracleStage2L3 if three else OracleStage2)(s2, w2), OracleStage1(s1, w1)
     n_pos = 2
-    noise = synth.exp_noise(0, n_pos, batch, s2.vocab_top)
     cond = synth.class_ids(0, batch, max(s2.n_classes, 1))
-    t0 = time.perf_counter()
-    ct, cb = orc2.sample(cond, batch, n_pos, noise)
-    t_ar = (time.perf_counter() - t0) / n_pos
     r = s1.z_res
     rng = np.random.default_rng(0)
-    code_t = rng.integers(0, s1.n_embed, (1, r // 2, r // 2))
-    code_b = rng.integers(0, s1.n_embed, (1, r, r))
+    if three:
+        noise = np.maximum(rng.standard_exponential((n_pos, 21, batch, s2.vocab_top), dtype=np.float32), np.float32(1e-30))
+    else:
+        noise = synth.exp_noise(0, n_pos, batch, s2.vocab_top)
     t0 = time.perf_counter()
-    orc1.decode_code(code_t, code_b)
+    orc2.sample(cond, batch, n_pos, noise)
+    t_ar = (time.perf_counter() - t0) / n_pos
+    code_b = rng.integers(0, s1.n_embed, (1, r, r))
+    code_m = rng.integers(0, s1.n_embed, (1, r // 2, r // 2))
+    t0 = time.perf_counter()
+    if three:
+        orc1.decode_codes3([rng.integers(0, s1.n_embed, (1, r // 4, r // 4)), code_m, code_b])
+    else:
+        orc1.decode_code(code_m, code_b)
     t_dec = time.perf_counter() - t0
-    n_positions = (r // 2) ** 2
+    n_positions = (r // (4 if three else 2)) ** 2
     per_image = t_ar * n_positions / batch + t_dec
     return {'value': round(1.0 / per_image, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n_pos} of {n_positions} AR positions at batch {batch} ({t_ar:.2f} s/position) + decode of 1 image '
@@ -122,7 +129,7 @@ def main():
     model = ImageGPT2(cfg, seed=0).to(dev).eval()
     s2, s1 = model.stage2.spec, model.stage1.spec
     B = args.batch
-    n_pos = (s1.z_res // 2) ** 2
+    n_pos = (s1.z_res // (4 if s2.levels == 3 else 2)) ** 2
     n_full = n_pos
     if args.positions:
         n_pos = min(n_pos, args.positions)
@@ -133,17 +140,29 @@ def main():
     if dist is not None and args.gather == 'pixels' and rank == 0:
         gathered = [torch.empty((B, s1.out_ch, H, H), dtype=torch.float32, device=dev) for _ in range(world)]
 
+    three = s2.levels == 3
+
+    def sample_codes(i, graph):
+        """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels)."""
+        if three:
+            c = sampling_hqtransformer(model.stage2, num_candidates=B, cond=int(classes[i]), top_k=[None] * 3, top_p=[None] * 3,
+                                       softmax_temperature=[1.0] * 3, use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i,
+                                       sample_offset=rank * B, use_graph=graph)
+            return c[0], c[1:]
+        return sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), top_k_top=None, top_p_top=None, top_k_bot=None,
+                               top_p_bot=None, softmax_temperature=[1.0, 1.0], use_fp16=fast, is_tqdm=False, max_seq_len=n_pos,
+                               model_stage1=None, seed=1 + i, sample_offset=rank * B, use_graph=graph)
+
     def decode(ct, cb, m=None):
+        if three:
+            return (m or model).stage1.decode_sequences([ct] + list(cb), precision=args.precision, clamp01=True)
         if n_pos < n_full:      # debug runs: pad the code grids so the decoder still sees full-size inputs
             ct = torch.cat([ct, ct.new_zeros(B, n_full - n_pos)], 1)
             cb = torch.cat([cb, cb.new_zeros(B, n_full - n_pos, 4)], 1)
         return (m or model).stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
 
     def step(i, graph=True):
-        ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), top_k_top=None, top_p_top=None,
-                                 top_k_bot=None, top_p_bot=None, softmax_temperature=[1.0, 1.0], use_fp16=fast,
-                                 is_tqdm=False, max_seq_len=n_pos, model_stage1=None, seed=1 + i,
-                                 sample_offset=rank * B, use_graph=graph and not args.no_graph)
+        ct, cb = sample_codes(i, graph and not args.no_graph)
         px = decode(ct, cb)
         if dist is not None and args.gather == 'pixels':
             dist.gather(px, gathered, dst=0)
@@ -206,9 +225,7 @@ def main():
         i = args.warmup + k
         with torch.cuda.stream(s_ar):
             ev[3 * k].record()
-            ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), softmax_temperature=[1.0, 1.0],
-                                     use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i, sample_offset=rank * B,
-                                     use_graph=not args.no_graph)
+            ct, cb = sample_codes(i, not args.no_graph)
             ev[3 * k + 1].record()
         with torch.cuda.stream(s_dec):
             s_dec.wait_event(ev[3 * k + 1])
@@ -240,7 +257,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if fast else 'f32', 'data': 'synthetic',
-            'config': {'workload': f'imagenet256-classcond hq-vae(8x8+16x16)+hq-transformer {s2.n_layers}L/{s2.embed_dim}d, '
+            'config': {'workload': f'imagenet256-classcond hq-vae({"8x8+16x16+32x32, three code levels" if three else "8x8+16x16"})+hq-transformer {s2.n_layers}L/{s2.embed_dim}d, '
                                    f'batch {B}/GPU, {n_pos} top positions, top_k=top_p=None, T=[1,1]',
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
                        'precision': 'FAST: bf16 weights+MFMA, fp32 accumulate' if fast else 'EXACT: fp32',

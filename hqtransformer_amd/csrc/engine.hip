@@ -260,6 +260,10 @@ static int alloc_workspace(hqt_handle* hp) {
     struct { hqt_handle* p; hqt_handle* get() const { return p; } hqt_handle* operator->() const { return p; } } h{hp};
     const hqt_config& c = h->cfg;
     const size_t B = (size_t)c.max_batch;
+    // source of padded rows / taps for the LDS-DMA kernels (stage-2 GEMMs with more than 256 rows use them too: the text
+    // prefill and the third code level)
+    CHK(dev_alloc(h.get(), &h->zero_page, 256, true));
+    HIPCHK(hipMemset(h->zero_page, 0, 256));
     if (c.has_stage2) {
         const size_t D = c.embed_dim;
         const int Tp = c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1;    // rows of the widest body pass
@@ -304,8 +308,6 @@ static int alloc_workspace(hqt_handle* hp) {
         h->act_elems = per_img * h->dec_chunk;
         for (int i = 0; i < 3; ++i) CHK(dev_alloc(h.get(), &h->act[i], h->act_elems * 4, true));
         CHK(dev_alloc(h.get(), &h->act[3], h->act_elems * 2, true));
-        CHK(dev_alloc(h.get(), &h->zero_page, 256, true));
-        HIPCHK(hipMemset(h->zero_page, 0, 256));
         {
             size_t pe = 0;
             for (auto& l : h->dec) pe = std::max(pe, gn_stats_fast_partial_elems(h->dec_chunk, l.res * l.res, l.cin, 32));

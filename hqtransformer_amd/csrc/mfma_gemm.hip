@@ -246,8 +246,9 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
 // NSTAGE = 4: four-slot LDS ring (128 KiB, 1 workgroup per CU) with two k-tiles of DMA in flight across the barrier:
 //   counted s_waitcnt vmcnt(8 * tiles_in_flight) + raw s_barrier per k-tile; the slot of tile kt-1 is refilled right
 //   after the barrier that every wave passes only once it has finished reading that tile.
-template <typename TC, bool NCHW, int NSTAGE, int ABL = 0>       // ABL: ablation switches of tools/micro/bench_conv
+template <typename TC, int MODE, int NSTAGE, int ABL = 0>        // MODE 0: plain rows, 1: NCHW (conv_out), 2: any store mode; ABL: tools/micro/bench_conv
 __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(GemmArgs g) {
+    constexpr bool NCHW = MODE == 1;
     constexpr int BM = 128, BN = 128, BKG = 64, ROWB = 128;            // ROWB: bytes per LDS row
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];     // [NSTAGE][A|B][BM * ROWB]
     auto LDS = [&](int stage, int op) -> char* { return lds_raw + (size_t)(stage * 2 + op) * (BM * ROWB); };
@@ -391,6 +392,8 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
                     if (g.clamp01) v = fminf(fmaxf(0.5f * v + 0.5f, 0.0f), 1.0f);
                     const int img = m / g.rows_per_image, pix = m - img * g.rows_per_image;
                     st1<TC>(Cb + ((long long)img * g.N + n) * g.rows_per_image + pix, v);
+                } else if (MODE == 2) {           // fused QKV / KV-cache row remap (stage-2 GEMMs with more than 256 rows);
+                    gemm_store<TC>(g, bz, m, n, acc[i][j][r]);     // own instantiation: inlined 64x it would bloat the plain kernels
                 } else {
                     const long long idx = (long long)m * g.ldc + n;
                     float v = apply_act(acc[i][j][r] * g.alpha + bn, g.act);
@@ -703,7 +706,8 @@ static bool halo_ok(const GemmArgs& g, int c_dt) {
 
 static bool glds_ok(const GemmArgs& g) {
     if (!g.zero_page || g.gn_stats || g.a_packed_mb) return false;
-    if (!((g.store == STORE_ROWS && g.rows_per_group == 0) || (g.store == STORE_NCHW && !g.resid && g.act == ACT_NONE))) return false;
+    if (!((g.store == STORE_ROWS && g.rows_per_group == 0) || (g.store == STORE_NCHW && !g.resid && g.act == ACT_NONE) ||
+          (g.store == STORE_QKV && !g.conv_taps))) return false;
     if (g.K % 64 != 0 || g.ldb % 8 != 0) return false;
     if (g.conv_taps) return g.Cin % 64 == 0;
     return g.lda % 8 == 0;
@@ -765,9 +769,11 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
             if (ring) conv_glds_kernel<TC, NCHW_, 4><<<grid, 256, smem, st>>>(g);                    \
             else conv_glds_kernel<TC, NCHW_, 2><<<grid, 256, smem, st>>>(g);
             if (g.store == STORE_NCHW) {
-                if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, true) } else { LAUNCH_GLDS(float, true) }
+                if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, 1) } else { LAUNCH_GLDS(float, 1) }
+            } else if (g.store == STORE_ROWS && g.rows_per_group == 0) {
+                if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, 0) } else { LAUNCH_GLDS(float, 0) }
             } else {
-                if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, false) } else { LAUNCH_GLDS(float, false) }
+                if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, 2) } else { LAUNCH_GLDS(float, 2) }
             }
 #undef LAUNCH_GLDS
             return hipGetLastError();
@@ -784,8 +790,9 @@ hipError_t mfma_gemm_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_glds_kernel<TC, NCHW_, NS>),                        \
                             hipFuncAttributeMaxDynamicSharedMemorySize, NS * 2 * 128 * 128);                        \
     if (e != hipSuccess) return e;
-    CFG(bf16_t, false, 2) CFG(bf16_t, false, 4) CFG(float, false, 2) CFG(float, false, 4)
-    CFG(bf16_t, true, 2) CFG(bf16_t, true, 4) CFG(float, true, 2) CFG(float, true, 4)
+    CFG(bf16_t, 0, 2) CFG(bf16_t, 0, 4) CFG(float, 0, 2) CFG(float, 0, 4)
+    CFG(bf16_t, 1, 2) CFG(bf16_t, 1, 4) CFG(float, 1, 2) CFG(float, 1, 4)
+    CFG(bf16_t, 2, 2) CFG(bf16_t, 2, 4) CFG(float, 2, 2) CFG(float, 2, 4)
 #undef CFG
 #define CFGH(TC, NCHW_)                                                                                             \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<TC, NCHW_, 8>),                          \

@@ -13,7 +13,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from .sampling import sampling_ihqgpt
+from .sampling import sampling_hqtransformer, sampling_ihqgpt
 
 
 class InflightSampler:
@@ -41,14 +41,20 @@ class InflightSampler:
         with torch.cuda.stream(st):
             if phase_events is not None:
                 phase_events[0].record(st)
-            ct, cb = sampling_ihqgpt(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
-                                     use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, **sample_kw)
+            three = getattr(self.model.stage2.spec, 'levels', 2) == 3
+            if three:                                # HQTransformer: (codes0, [codes1, codes2]) keeps the 4-tuple shape of the result
+                codes = sampling_hqtransformer(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
+                                               use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, **sample_kw)
+                ct, cb = codes[0], codes[1:]
+            else:
+                ct, cb = sampling_ihqgpt(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
+                                         use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, **sample_kw)
             if phase_events is not None:
                 phase_events[1].record(st)
             px = None
             if decode:
-                px = self.model.stage1.decode_sequences(ct, cb, precision=precision or ('fast' if use_fp16 else 'exact'),
-                                                        clamp01=clamp01, lane=lane)
+                px = self.model.stage1.decode_sequences([ct] + list(cb) if three else ct, None if three else cb,
+                                                        precision=precision or ('fast' if use_fp16 else 'exact'), clamp01=clamp01, lane=lane)
             if phase_events is not None:
                 phase_events[2].record(st)
             if after is not None:

@@ -298,9 +298,10 @@ def work_per_image(s2: Stage2Spec, s1: Stage1Spec, n_pos: int) -> Dict[str, floa
     (bf16) and decoder FLOPs per image."""
     D, V = s2.embed_dim, s2.vocab_top
     blk = 12 * D * D + 13 * D
-    ar_weight_bytes_per_pos = 2 * ((s2.n_layers + 2 * s2.n_layers_depth) * blk + 2 * D * V)
-    ar_flops = 2 * n_pos * (s2.n_layers * 12 * D * D + s2.n_layers_depth * 12 * D * D * 5 + 5 * D * V)
-    mac = s1.z_res ** 2 * 2 * s1.embed_dim * s1.z_channels
+    sub, toks = (3, 21) if s2.levels == 3 else (2, 5)          # depth sub-steps (each streams the depth weights once), depth tokens
+    ar_weight_bytes_per_pos = 2 * ((s2.n_layers + sub * s2.n_layers_depth) * blk + sub * D * V)
+    ar_flops = 2 * n_pos * (s2.n_layers * 12 * D * D + s2.n_layers_depth * 12 * D * D * toks + toks * D * V)
+    mac = s1.z_res ** 2 * (1 if s1.code_levels == 3 else 2) * s1.embed_dim * s1.z_channels
     for l in decoder_plan(s1):
         px = l.res * l.res
         if l.kind == 'conv3':

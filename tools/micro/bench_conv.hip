@@ -11,11 +11,11 @@ template <int ABL>
 static float run(const GemmArgs& g, hipStream_t st, int reps) {
     const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, 1);
     const size_t smem = 2 * 2 * 128 * 128;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_glds_kernel<bf16_t, false, 2, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    conv_glds_kernel<bf16_t, false, 2, ABL><<<grid, 256, smem, st>>>(g);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_glds_kernel<bf16_t, 0, 2, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    conv_glds_kernel<bf16_t, 0, 2, ABL><<<grid, 256, smem, st>>>(g);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     CK(hipEventRecord(a, st));
-    for (int r = 0; r < reps; ++r) conv_glds_kernel<bf16_t, false, 2, ABL><<<grid, 256, smem, st>>>(g);
+    for (int r = 0; r < reps; ++r) conv_glds_kernel<bf16_t, 0, 2, ABL><<<grid, 256, smem, st>>>(g);
     CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return 1000.f * ms / reps;
