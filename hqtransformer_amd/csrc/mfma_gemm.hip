@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
 // NSTAGE = 4: four-slot LDS ring (128 KiB, 1 workgroup per CU) with two k-tiles of DMA in flight across the barrier:
 //   counted s_waitcnt vmcnt(8 * tiles_in_flight) + raw s_barrier per k-tile; the slot of tile kt-1 is refilled right
 //   after the barrier that every wave passes only once it has finished reading that tile.
-template <typename TC, int MODE, int NSTAGE, int ABL = 0>        // MODE 0: plain rows, 1: NCHW (conv_out), 2: any store mode; ABL: tools/micro/bench_conv
+template <typename TC, int MODE, int NSTAGE, int ABL = 0>        // MODE 0: plain rows, 1: NCHW, 2: any store mode (element-wise), 3: fused QKV, 4 columns at a time; ABL: tools/micro/bench_conv
 __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(GemmArgs g) {
     constexpr bool NCHW = MODE == 1;
     constexpr int BM = 128, BN = 128, BKG = 64, ROWB = 128;            // ROWB: bytes per LDS row
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D rows = n, cols = m
         }
     };
     if constexpr (NSTAGE == 2) {
@@ -373,35 +373,66 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
         if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
         return;
     }
-    // epilogue: plain row-major store (template NCHW = false) or the fp32 NCHW store of conv_out
+    // epilogue.  The B operand (weights / second activation) is the MFMA A operand, so D col = lane & 31 -> row m of
+    // fragment i and D row = (r & 3) + 8 (r >> 2) + 4 fh -> column n: a lane owns 4 consecutive columns of one row per
+    // register quad and stores them with one 8-byte (bf16) / 16-byte (fp32) access; NCHW stores run along the lanes.
     TC* Cb = reinterpret_cast<TC*>(g.C) + (long long)bz * g.c_batch_stride;
     const TC* Rb = g.resid ? reinterpret_cast<const TC*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
+    const bool vec4 = (g.N & 3) == 0 && (g.ldc & 3) == 0;
+    const int qkv_dev = (MODE == 3 && g.row_offset_dev) ? *g.row_offset_dev : 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + fr;
+        if (m >= g.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + fr;
-            if (n >= g.N) continue;
-            const float bn = g.bias ? g.bias[n] : 0.0f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= g.M) continue;
-                if (NCHW) {                       // conv_out: fp32 NCHW (+clamp), n < out_ch only
-                    float v = acc[i][j][r] * g.alpha + bn;
-                    if (g.clamp01) v = fminf(fmaxf(0.5f * v + 0.5f, 0.0f), 1.0f);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int n4 = n0 + wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                if (n4 >= g.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q4 + e] * g.alpha + ((g.bias && n4 + e < g.N) ? g.bias[n4 + e] : 0.0f);
+                if (NCHW) {                       // fp32 / bf16 NCHW (+clamp): conv_out, V^T of the decoder attention
                     const int img = m / g.rows_per_image, pix = m - img * g.rows_per_image;
-                    st1<TC>(Cb + ((long long)img * g.N + n) * g.rows_per_image + pix, v);
-                } else if (MODE == 2) {           // fused QKV / KV-cache row remap (stage-2 GEMMs with more than 256 rows);
-                    gemm_store<TC>(g, bz, m, n, acc[i][j][r]);     // own instantiation: inlined 64x it would bloat the plain kernels
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n4 + e >= g.N) continue;
+                        float x = v[e];
+                        if (g.clamp01) x = fminf(fmaxf(0.5f * x + 0.5f, 0.0f), 1.0f);
+                        st1<TC>(Cb + ((long long)img * g.N + n4 + e) * g.rows_per_image + pix, x);
+                    }
+                } else if (MODE == 3) {           // dispatcher guarantees: STORE_QKV, N, ldc, qkv_D multiples of 4
+                    // fused [query; key; value] with the KV-cache row remap: the 4 columns lie in one part
+                    const int part = n4 / g.qkv_D, nn = n4 - part * g.qkv_D, which = part + g.qkv_first;
+                    long long row = m;
+                    if (which > 0) row = (m / g.rows_per_group) * g.group_stride + m % g.rows_per_group + g.row_offset + qkv_dev;
+                    TC* base = reinterpret_cast<TC*>(which == 0 ? g.C : (which == 1 ? g.C2 : g.C3));
+                    st4<TC>(base + row * g.ldc + nn, v);
+                } else if (MODE == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n4 + e < g.N) gemm_store<TC>(g, bz, m, n4 + e, acc[i][j][4 * q4 + e]);
                 } else {
-                    const long long idx = (long long)m * g.ldc + n;
-                    float v = apply_act(acc[i][j][r] * g.alpha + bn, g.act);
-                    if (Rb) v += ld1<TC>(Rb + idx);
-                    st1<TC>(Cb + idx, v);
+                    const long long idx = (long long)m * g.ldc + n4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
+                    if (vec4) {
+                        if (Rb) {
+                            float rv[4];
+                            ld4<TC>(Rb + idx, rv);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                        }
+                        st4<TC>(Cb + idx, v);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n4 + e < g.N) { float x = v[e]; if (Rb) x += ld1<TC>(Rb + idx + e); st1<TC>(Cb + idx + e, x); }
+                    }
                 }
             }
-        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -735,7 +766,7 @@ static bool big_tile_shape(const GemmArgs& g) {
     const long long tiles128 = (long long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.batch > 0 ? g.batch : 1);
     static const bool force128 = getenv("HQT_FORCE_TILE128") != nullptr;          // test hook: exercise the big-tile kernels on tiny shapes
     const bool narrow = g.N < 32 && g.M >= 4096 && glds_ok(g);       // conv_out (N = 3): one zero-padded 128-wide n-tile
-    return narrow || (g.N >= 128 && g.M >= 128 && (tiles128 >= 192 || force128));
+    return narrow || (g.N >= 128 && g.M >= 128 && (tiles128 >= 96 || force128));      // 96: the 1024-row x 1536-column GEMMs of the third code level
 }
 // true when launch_mfma_gemm will run the halo-tile kernel for g (the engine asks before requesting fused statistics)
 bool conv_halo_ok(const GemmArgs& g, int c_dt) {
@@ -772,6 +803,8 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
                 if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, 1) } else { LAUNCH_GLDS(float, 1) }
             } else if (g.store == STORE_ROWS && g.rows_per_group == 0) {
                 if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, 0) } else { LAUNCH_GLDS(float, 0) }
+            } else if (g.store == STORE_QKV && g.N % 4 == 0 && g.ldc % 4 == 0 && g.qkv_D % 4 == 0 && g.rows_per_group > 0) {
+                if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, 3) } else { LAUNCH_GLDS(float, 3) }
             } else {
                 if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, 2) } else { LAUNCH_GLDS(float, 2) }
             }
@@ -793,6 +826,7 @@ hipError_t mfma_gemm_configure() {
     CFG(bf16_t, 0, 2) CFG(bf16_t, 0, 4) CFG(float, 0, 2) CFG(float, 0, 4)
     CFG(bf16_t, 1, 2) CFG(bf16_t, 1, 4) CFG(float, 1, 2) CFG(float, 1, 4)
     CFG(bf16_t, 2, 2) CFG(bf16_t, 2, 4) CFG(float, 2, 2) CFG(float, 2, 4)
+    CFG(bf16_t, 3, 2) CFG(bf16_t, 3, 4) CFG(float, 3, 2) CFG(float, 3, 4)
 #undef CFG
 #define CFGH(TC, NCHW_)                                                                                             \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<TC, NCHW_, 8>),                          \
