@@ -9,7 +9,8 @@ what one iteration of the reference's `measure_throughput` loop times (measure_t
 Workload = BASELINE.json configs[1]: ImageNet-256 class-conditional HQ-VAE + 12-layer HQ-Transformer,
 batch 64 per GPU, synthetic (random-init weights, as the reference harness itself uses; random class per
 step; top_k = top_p = None, temperatures [1, 1]).  Weak scaling: every rank samples its own 64 images,
-weights replicated, the only collective is the gather of finished pixels to rank 0 (RCCL over xGMI).
+weights replicated, no collective inside the path (every image is an independent chain); `--gather pixels|codes`
+adds an optional RCCL gather of each step's result to rank 0.
 
 The JSON line also carries `roofline` (dominant kernel family, measured live with HIP events on the
 launch stream by libhqt's per-launch timers in a separate un-graphed pass) and `cpu_baseline` (the numpy
@@ -48,7 +49,8 @@ def parse():
     p.add_argument('--config', default=os.path.join(ROOT, 'configs', 'imagenet-12l.yaml'))
     p.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     p.add_argument('--precision', choices=['fast', 'exact'], default='fast')
-    p.add_argument('--gather', choices=['pixels', 'codes', 'none'], default='pixels')
+    p.add_argument('--gather', choices=['pixels', 'codes', 'none'], default='none',
+                   help='optional RCCL gather of every step\'s result to rank 0; the path itself has no exchange step, so the default is none')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-graph', action='store_true')
