@@ -216,6 +216,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_lanes = float(t.item())
     del kept
+    pipe.release(B, n_pos)            # lane 0 back to the latency-oriented kernels for the one-at-a-time reference pass
 
     # ---- reference pass: the same steps one at a time on one lane (the reference harness's order), with per-phase events
     n_serial = args.steps if inflight == 1 else min(args.steps, 3)
@@ -265,7 +266,7 @@ def main():
                        'precision': 'FAST: bf16 weights+MFMA, fp32 accumulate' if fast else 'EXACT: fp32',
                        'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph,
                        'pipeline': (f'{inflight} steps in flight per GPU (round-robin over {inflight} lanes: own HIP stream, KV cache and '
-                                    f'activations, shared weights); each step is one full batch-{B} pass') if inflight > 1 else 'serial'},
+                                    f'activations, shared weights, throughput-oriented GEMM tiles); each step is one full batch-{B} pass') if inflight > 1 else 'serial'},
             'serial': {'value': round(serial_value, 2), 'ms_per_step': round(serial_ms, 3), 'steps': n_serial,
                        'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
                        'note': 'the same steps one at a time on one lane (the reference harness order)'},

@@ -17,6 +17,7 @@ SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'mfma_gemm.hip']
 ABI_VERSION = 2
 
 PRECISION_EXACT, PRECISION_FAST = 0, 1
+POLICY_LATENCY, POLICY_THROUGHPUT = 0, 1
 
 
 class HqtLibraryError(RuntimeError):
@@ -78,6 +79,7 @@ SYMBOLS = {
     'hqt_set_weight': (C.c_int, [_VP, C.c_char_p, _VP, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     'hqt_finalize_weights': (C.c_int, [_VP]),
     'hqt_clone': (C.c_int, [_VP, C.POINTER(_VP)]),
+    'hqt_set_policy': (C.c_int, [_VP, C.c_int]),
     'hqt_sample': (C.c_int, [_VP, C.c_int, _I64P, C.POINTER(hqt_sample_opts), _F32P, _I64P, _I64P, _F32P, _I64P, _I64P, _VP]),
     'hqt_decode': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
     'hqt_decode_seq': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),

@@ -148,6 +148,7 @@ struct GemmArgs {
     //      a fixed-order finalize turns them into (mean, rstd).  NULL: not requested.
     float* gn_part_out;
     int gn_out_groups;
+    int tune;                // 0: latency-oriented tile choice, 1: throughput-oriented (hqt_set_policy)
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

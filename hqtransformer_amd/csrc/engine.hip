@@ -118,6 +118,7 @@ struct hqt_handle {
     // ---- lanes: a clone shares every weight buffer of its parent (non-owning) and owns only its workspace
     hqt_handle* parent = nullptr;
     int n_clones = 0;
+    int policy = 0;                           // HQT_POLICY_*: tile choice of the streaming GEMMs (part of the graph key)
     // ---- timing
     bool timing = false;
     std::vector<TimingSlot> slots;
@@ -603,6 +604,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     g.N = l.N; g.K = l.K; g.ldb = l.K;
     g.bias = l.b32;
     g.zero_page = h->zero_page;
+    g.tune = h->policy;
     if (g.alpha == 0.0f) g.alpha = 1.0f;
     if (g.lda == 0) g.lda = l.K;
     Timed t(h, tag, st);
@@ -1047,7 +1049,7 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
         std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)(cond != nullptr), (uint64_t)noise, (uint64_t)c.feed_top, (uint64_t)c.feed_bot,
                                      (uint64_t)logits_out, (uint64_t)opts->precision,
                                      (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot,
-                                     (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2]};
+                                     (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2], (uint64_t)h->policy};
         { uint32_t f3[2]; memcpy(f3, &c.top_p[2], 4); memcpy(f3 + 1, &c.temperature[2], 4); key.push_back(f3[0]); key.push_back(f3[1]); }
         uint32_t f[4];
         memcpy(f, &opts->top_p_top, 4); memcpy(f + 1, &opts->top_p_bot, 4);
@@ -1252,6 +1254,13 @@ extern "C" int hqt_decode_l3(hqt_handle* h, int B, const int64_t* code_t, const 
 extern "C" int hqt_decode_seq_l3(hqt_handle* h, int B, const int64_t* codes0, const int64_t* codes1, const int64_t* codes2, float* out,
                                  int clamp01, int precision, void* stream) {
     return decode_impl(h, B, codes0, codes1, codes2, 1, out, clamp01, precision, stream, 3);
+}
+
+extern "C" int hqt_set_policy(hqt_handle* h, int policy) {
+    if (!h) return fail(HQT_ERR_INVALID, "null handle");
+    if (policy != HQT_POLICY_LATENCY && policy != HQT_POLICY_THROUGHPUT) return fail(HQT_ERR_INVALID, "unknown policy %d", policy);
+    h->policy = policy;
+    return HQT_OK;
 }
 
 // ------------------------------------------------------------------------------------------ introspection

@@ -82,6 +82,11 @@ class Engine:
         self._clones.append(e)
         return e
 
+    def set_policy(self, policy: int) -> None:
+        """``hqt_set_policy``: 0 = latency-oriented kernel choice (one batch at a time), 1 = throughput-oriented (several
+        lanes in flight).  Part of the graph key: the next sample() re-captures if it changed."""
+        _lib.check(self.lib.hqt_set_policy(self.h, int(policy)))
+
     def close(self) -> None:
         for c in getattr(self, '_clones', []):       # clones go first: the parent owns the weights
             c.close()

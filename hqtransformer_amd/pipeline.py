@@ -13,6 +13,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
+from ._lib import POLICY_LATENCY, POLICY_THROUGHPUT
 from .sampling import sampling_hqtransformer, sampling_ihqgpt
 
 
@@ -25,6 +26,7 @@ class InflightSampler:
         self.device = device if device is not None else model.stage2._device
         self.streams: List[torch.cuda.Stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
         self.k = 0
+        self._policy_set = set()
 
     def submit(self, num_candidates: int, cond, *, seed: Optional[int] = None, max_seq_len: int = 64, use_fp16: bool = True,
                decode: bool = True, precision: Optional[str] = None, clamp01: bool = True, use_graph: bool = True,
@@ -38,6 +40,10 @@ class InflightSampler:
         # order the lane after whatever the caller's stream has queued (inputs; earlier direct use of lane 0's engine):
         # a lane's workspace must never be touched from two streams at once
         st.wait_stream(torch.cuda.current_stream(self.device))
+        if self.n > 1 and (lane, num_candidates, max_seq_len) not in self._policy_set:
+            # several batches in flight: kernels that cost the fewest CU-microseconds (hqt_set_policy)
+            self.model.stage2.engine(num_candidates, max_seq_len, lane).set_policy(POLICY_THROUGHPUT)
+            self._policy_set.add((lane, num_candidates, max_seq_len))
         with torch.cuda.stream(st):
             if phase_events is not None:
                 phase_events[0].record(st)
@@ -62,6 +68,13 @@ class InflightSampler:
             ev = torch.cuda.Event()
             ev.record(st)
         return ct, cb, px, ev
+
+    def release(self, batch: int, max_seq_len: int) -> None:
+        """Back to the latency-oriented kernels on lane 0 (the engine direct ``sampling_ihqgpt`` calls use)."""
+        self.drain()
+        if self.n > 1:
+            self.model.stage2.engine(batch, max_seq_len, 0).set_policy(POLICY_LATENCY)
+            self._policy_set.discard((0, batch, max_seq_len))
 
     def drain(self) -> None:
         """Wait for every lane; also orders the caller's stream after the lanes."""

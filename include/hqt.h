@@ -113,6 +113,14 @@ int hqt_finalize_weights(hqt_handle* h);
  * are bit-identical to the parent's.  Destroy clones before their parent (hqt_destroy(parent) fails otherwise). */
 int hqt_clone(hqt_handle* src, hqt_handle** out);
 
+/* hqt_set_policy -- kernel selection for the AR loop.  LATENCY (default): tile shapes that finish one batch soonest
+ * (every GEMM spread over as many CUs as possible).  THROUGHPUT: shapes that cost the fewest CU-microseconds (64-row
+ * weight tiles: half the activation re-reads per weight byte), for several lanes in flight (hqt_clone), where kernels
+ * of different batches share the chip: ~7 % more images/s with 3 lanes, ~15 % slower alone.  Results are unchanged up
+ * to fp32 summation order in FAST arithmetic (EXACT arithmetic does not use these kernels). */
+enum { HQT_POLICY_LATENCY = 0, HQT_POLICY_THROUGHPUT = 1 };
+int hqt_set_policy(hqt_handle* h, int policy);
+
 /* hqt_sample -- replaces sampling_ihqgpt + iHQGPT.sampling_step (hqvae/utils/sampling.py:164-237,
  * hierarchical_ar.py:428-480, 482-563, 667-789) for a batch of B independent images.
  *   cond        int64 [B] class ids (HQT_COND_CLASS), int64 [B, ctx_len_txt] token ids

@@ -232,6 +232,18 @@ def test_imagenet_head_geometry_vs_oracle(B):
                               return_logits=True, use_graph=graph)
         err = np.abs(np_(lf) - want[2]).max()
         assert err <= 0.1, f'FAST logits differ from the oracle by {err} (B={B}, graph={graph})'
+    # throughput-oriented tile shapes (hqt_set_policy; what several lanes in flight run): same bar
+    eng.set_policy(1)
+    try:
+        for graph in (False, True):
+            _, _, lt = eng.sample(B, torch.from_numpy(cond), n, precision=PRECISION_FAST, top_k=(None, 64), top_p=(None, 0.9),
+                                  temperature=(1.0, 0.9), noise=torch.from_numpy(noise), force_top=ft, force_bot=fb,
+                                  return_logits=True, use_graph=graph)
+            err = np.abs(np_(lt) - want[2]).max()
+            assert err <= 0.1, f'FAST (throughput policy) logits differ from the oracle by {err} (B={B}, graph={graph})'
+            assert np.abs(np_(lt) - np_(lf)).max() <= 0.05           # the two policies differ by fp32 summation order only
+    finally:
+        eng.set_policy(0)
 
 
 @pytest.mark.parametrize('opts', [((None, None), (None, None), (1.0, 1.0)), ((2048, 100), (1.0, 0.9), (0.95, 0.8))])

@@ -11,7 +11,7 @@ struct Chain {
 };
 
 int main(int argc, char** argv) {
-    const int L = 12, M = argc > 1 ? atoi(argv[1]) : 64, D = 1536, reps = 20, maxn = 4;
+    const int L = 12, M = argc > 1 ? atoi(argv[1]) : 64, D = 1536, reps = 20, maxn = argc > 3 ? atoi(argv[3]) : 4;
     const bool shared_w = argc > 2 ? atoi(argv[2]) != 0 : true;
     const int pk = packed_mb(M), Mpad = pk * 32;
     CK(stream_gemm_configure());
