@@ -455,7 +455,7 @@ constexpr int halo_pieces(int TY) { return (halo_rows(TY) + 7) / 8; }           
 constexpr int halo_patch_bytes(int TY) { return halo_pieces(TY) * 1024; }
 constexpr int halo_npatch(int TY) { return TY == 8 ? 2 : 1; }                           // 16-row tiles keep ONE patch buffer (LDS)
 constexpr int HALO_B_BYTES = 128 * 128;
-constexpr int halo_lds(int TY) { return halo_npatch(TY) * halo_patch_bytes(TY) + 2 * HALO_B_BYTES; }   // 79872 | 74752: two workgroups per CU
+constexpr int halo_lds(int TY, int BN = 128) { return halo_npatch(TY) * halo_patch_bytes(TY) + 2 * BN * 128; }   // 79872 | 74752: two workgroups per CU
 constexpr int HALO_CPITCH = 128 * 4 + 16;                                              // fp32 staging row (bytes)
 static_assert(128 * HALO_CPITCH <= halo_lds(8) && 128 * HALO_CPITCH <= halo_lds(16), "epilogue staging must fit in the operand buffers");
 
@@ -463,19 +463,23 @@ static_assert(128 * HALO_CPITCH <= halo_lds(8) && 128 * HALO_CPITCH <= halo_lds(
 // TY = 16: 16 x 16 pixel tile (256 pixels, each wave 128 x 64: twice the MFMAs per barrier and per DMA'd filter
 //          byte, 0.75 instead of 1 fragment read per MFMA); the 324-row patch is single-buffered and re-filled
 //          between channel chunks (the other workgroup of the CU covers that gap); the epilogue stages two halves.
-template <typename TC, bool NCHW, int TY, int ABL = 0>
+// BN = 128 output channels per workgroup (waves 2 x 2), or BN = 32 for conv_out (3 channels: 4 waves along the pixels, one
+// 32-channel fragment each -- 4x fewer MFMAs than padding 3 channels to 128; NCHW epilogue only).
+template <typename TC, bool NCHW, int TY, int ABL = 0, int BN = 128>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
+    static_assert(BN == 128 || (BN == 32 && NCHW), "the 32-channel variant exists for the NCHW conv_out store only");
+    constexpr int WMW = BN == 128 ? 2 : 4, FJ = BN / (BN == 128 ? 64 : 32), B_BYTES = BN * 128;
     constexpr int ROWS = halo_rows(TY), PIECES = halo_pieces(TY), NPATCH = halo_npatch(TY), PATCH_BYTES = halo_patch_bytes(TY);
-    constexpr int FI = TY / 4;                                      // 32-pixel fragments per wave (2 | 4)
+    constexpr int FI = (TY / 2) / WMW;                              // 32-pixel fragments per wave
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     auto PATCH = [&](int s) -> char* { return lds_raw + (size_t)s * PATCH_BYTES; };
-    auto BT = [&](int s) -> char* { return lds_raw + NPATCH * PATCH_BYTES + (size_t)s * HALO_B_BYTES; };
+    auto BT = [&](int s) -> char* { return lds_raw + NPATCH * PATCH_BYTES + (size_t)s * B_BYTES; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
     const int fr = lane & 31, fh = lane >> 5;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
-    const int n0 = tile_n * 128;
+    const int n0 = tile_n * BN;
     const int tiles_x = g.W / HALO_TX, tiles_y = g.H / TY;
     const int img = tile_m / (tiles_x * tiles_y);
     const int trem = tile_m - img * (tiles_x * tiles_y);
@@ -489,10 +493,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
     //      source chunk = slot ^ ((q >> 1) & 7) (the same involution the fragment reads apply).  The addresses are
     //      rebuilt per channel chunk (once per nine k-tiles) instead of being held in registers.
     constexpr int PPW = (PIECES + 3) / 4;                           // pieces per wave
-    const bf16_t* brow[4];
+    constexpr int BPW = BN / 32;                                    // filter DMA pieces per wave (4 | 1)
+    const bf16_t* brow[BPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < BPW; ++i) {
+        const int row = (wave * BPW + i) * 8 + (lane >> 3);
         const int ch = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
         brow[i] = (n0 + row < g.N) ? Bbase + (long long)(n0 + row) * g.ldb + ch : nullptr;
     }
@@ -515,29 +520,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
     };
     auto issue_b = [&](int k0, int s) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < BPW; ++i) {
             const bf16_t* src = brow[i] ? brow[i] + k0 : zero;
-            char* dst = BT(s) + (wave * 4 + i) * 1024;
+            char* dst = BT(s) + (wave * BPW + i) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
-    f32x16 acc[FI][2];                                              // [pixel block i][channel block j]
+    f32x16 acc[FI][FJ];                                             // [pixel block i][channel block j]
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // pixel of this lane in fragment i: tile row (wm TY/2 + 2 i + fr / 16, fr % 16); patch row of tap (0, 0)
     int qbase[FI];
 #pragma unroll
-    for (int i = 0; i < FI; ++i) qbase[i] = (wm * (TY / 2) + i * 2 + (fr >> 4)) * HALO_PITCH + (fr & 15);
-    int brd[2];                                                     // filter fragment rows
+    for (int i = 0; i < FI; ++i) qbase[i] = (wm * (2 * FI) + i * 2 + (fr >> 4)) * HALO_PITCH + (fr & 15);
+    int brd[FJ];                                                    // filter fragment rows
 #pragma unroll
-    for (int j = 0; j < 2; ++j) brd[j] = wn * 64 + j * 32 + fr;
+    for (int j = 0; j < FJ; ++j) brd[j] = wn * 64 + j * 32 + fr;
 
     auto compute = [&](int ps, int bs, int tapoff) {
         const char* Pb = PATCH(ps);
@@ -548,15 +553,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 2 + fh;
-            bf16x8 af[FI], bfr[2];
+            bf16x8 af[FI], bfr[FJ];
 #pragma unroll
             for (int i = 0; i < FI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Pb + qa[i] + ((c ^ sw[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + brd[j] * 128 + ((c ^ ((brd[j] >> 1) & 7)) << 4));
+            for (int j = 0; j < FJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + brd[j] * 128 + ((c ^ ((brd[j] >> 1) & 7)) << 4));
 #pragma unroll
             for (int i = 0; i < FI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < FI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < FJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
         if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
@@ -604,10 +609,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
         const long long hw = (long long)g.H * g.W;
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
-            const int py = wm * (TY / 2) + i * 2 + (fr >> 4);
+            const int py = wm * (2 * FI) + i * 2 + (fr >> 4);
             const long long pix = (long long)(ty0 + py) * g.W + tx0 + (fr & 15);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < FJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int n = n0 + wn * 64 + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
@@ -619,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
         }
         return;
     }
+    if constexpr (BN == 128) {
     // Staged store, 128 pixels (8 tile rows = the pixels of one wave row wm) at a time: fp32 tile through the dead operand
     // buffers, then full 256-B NHWC rows with 16-B stores per lane.
     char* stage = lds_raw;                              // [128 pixels][HALO_CPITCH] fp32; every operand read is behind the last barrier
@@ -705,6 +711,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(GemmArgs g) {
             }
         }
     }
+    }
 }
 
 // fused output statistics need whole groups inside a wave: channels per group a power of two <= 64
@@ -783,7 +790,11 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
 #define LAUNCH_HALO(TC, NCHW_)                                                                              \
             if (ty == 16) conv3x3_halo_kernel<TC, NCHW_, 16><<<grid, 256, halo_lds(16), st>>>(g);           \
             else conv3x3_halo_kernel<TC, NCHW_, 8><<<grid, 256, halo_lds(8), st>>>(g);
-            if (g.store == STORE_NCHW) {
+            const bool no_narrow = getenv("HQT_NO_NARROW_OUT") != nullptr;   // A/B switch (read per launch)
+            if (g.store == STORE_NCHW && g.N <= 32 && c_dt == DT_F32 && !no_narrow) {   // conv_out: 32-channel tiles instead of 3 padded to 128
+                if (ty == 16) conv3x3_halo_kernel<float, true, 16, 0, 32><<<grid, 256, halo_lds(16, 32), st>>>(g);
+                else conv3x3_halo_kernel<float, true, 8, 0, 32><<<grid, 256, halo_lds(8, 32), st>>>(g);
+            } else if (g.store == STORE_NCHW) {
                 if (c_dt == DT_BF16) { LAUNCH_HALO(bf16_t, true) } else { LAUNCH_HALO(float, true) }
             } else {
                 LAUNCH_HALO(bf16_t, false)
@@ -836,6 +847,10 @@ hipError_t mfma_gemm_configure() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(16));                                  \
     if (e != hipSuccess) return e;
     CFGH(bf16_t, false) CFGH(bf16_t, true) CFGH(float, true)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<float, true, 8, 0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(8, 32));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<float, true, 16, 0, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds(16, 32));
+    if (e != hipSuccess) return e;
 #undef CFGH
     return hipSuccess;
 }

@@ -346,12 +346,16 @@ def test_decode_fast_halo_conv_matches_generic_implicit_gemm():
         for ty in ('8', '16'):                      # 8 x 16 and 16 x 16 pixel tiles (the latter: single patch buffer, two-half epilogue)
             os.environ['HQT_HALO_TY'] = ty
             halo[ty] = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
+            os.environ['HQT_NO_NARROW_OUT'] = '1'   # conv_out through the 128-channel tiles instead of the 32-channel variant
+            wide_out = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
+            del os.environ['HQT_NO_NARROW_OUT']
+            assert np.array_equal(wide_out, halo[ty]), ty   # same products in the same order: bit-identical
         os.environ['HQT_NO_FUSED_GN'] = '1'         # statistics by the separate pass instead of the conv epilogue
         unfused = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
         os.environ['HQT_NO_HALO'] = '1'
         generic = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
     finally:
-        for k in ('HQT_NO_HALO', 'HQT_HALO_TY', 'HQT_NO_FUSED_GN', 'HQT_FORCE_TILE128'):
+        for k in ('HQT_NO_HALO', 'HQT_HALO_TY', 'HQT_NO_FUSED_GN', 'HQT_FORCE_TILE128', 'HQT_NO_NARROW_OUT'):
             os.environ.pop(k, None)
     want = O.OracleStage1(spec, weights).decode_code(ct, cb)
     eg = np.abs(generic - want)
