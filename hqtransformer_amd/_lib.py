@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'mfma_gemm.hip']
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 PRECISION_EXACT, PRECISION_FAST = 0, 1
 POLICY_LATENCY, POLICY_THROUGHPUT = 0, 1
@@ -70,6 +70,13 @@ class hqt_sample_opts_l3(C.Structure):
     ]
 
 
+class hqt_encode_out(C.Structure):
+    _fields_ = [
+        ('codes', C.c_void_p * 3), ('quant', C.c_void_p * 3), ('resid', C.c_void_p * 3),
+        ('recon', C.c_void_p), ('diff', C.c_void_p),
+    ]
+
+
 # every symbol include/hqt.h declares: name -> (restype, argtypes)
 _VP, _I64P, _F32P = C.c_void_p, C.c_void_p, C.c_void_p
 SYMBOLS = {
@@ -86,6 +93,8 @@ SYMBOLS = {
     'hqt_sample_l3': (C.c_int, [_VP, C.c_int, _I64P, C.POINTER(hqt_sample_opts_l3), _F32P, _I64P, _I64P, _I64P, _F32P, _I64P, _I64P, _I64P, _VP]),
     'hqt_decode_l3': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
     'hqt_decode_seq_l3': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
+    'hqt_encode': (C.c_int, [_VP, C.c_int, _F32P, C.c_int, C.POINTER(hqt_encode_out), _VP]),
+    'hqt_has_encoder': (C.c_int, [_VP]),
     'hqt_param_count': (C.c_int64, [_VP, C.c_int]),
     'hqt_workspace_bytes': (C.c_int64, [_VP]),
     'hqt_timing_enable': (C.c_int, [_VP, C.c_int]),

@@ -24,7 +24,16 @@ __device__ __host__ inline bf16_t f32_to_bf16(float f) {
 }
 
 enum { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_SIGMOID = 2 };
-enum { STORE_ROWS = 0, STORE_NCHW = 1, STORE_QKV = 2, STORE_PACKED = 3, STORE_RESID = 4 };
+enum { STORE_ROWS = 0, STORE_NCHW = 1, STORE_QKV = 2, STORE_PACKED = 3, STORE_RESID = 4, STORE_ARGMIN = 5 };
+
+// filter edge of an implicit-GEMM convolution from its tap count: 1x1, 3x3, 4x4 (the encoder's strided conv_in)
+__device__ __host__ inline int conv_ks(int taps) { return taps == 9 ? 3 : (taps == 16 ? 4 : 1); }
+// total order on floats as unsigned integers (smaller float <-> smaller key); NaN sorts last
+__device__ __host__ inline uint32_t float_order_key(float f) {
+    union { float f; uint32_t u; } c;
+    c.f = f;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
 
 // MFMA-fragment-packed activation layout of the AR loop's GEMM A operands (FAST precision):
 // element (row m, column k) of an [Mpad = 32*MB, K] matrix lives at packed_off(m, k, MB), i.e.
@@ -88,7 +97,9 @@ struct GemmArgs {
     int a_group_stride;
     int a_row_offset;
     int a_packed_mb;         // > 0: A is in the packed_off() layout with this many 32-row blocks
-    int conv_taps;           // 0 = plain, 1 = 1x1, 9 = 3x3
+    int conv_taps;           // 0 = plain, 1 = 1x1, 9 = 3x3, 16 = 4x4
+    int conv_stride2;        // 1: stride 2 (the input is 2H x 2W): Downsample / the encoder's conv_in
+    int conv_nopad;          // 1: no zero padding at the top / left (Downsample pads bottom / right only: layers.py:68-72)
     int H, W, Cin;           // output spatial size and input channels (conv)
     int upsample;            // 1: input is (H/2, W/2), nearest x2 before the conv
     const float* gn_stats;   // [batch_img][groups][2] mean, rstd  (NULL: no GroupNorm on load)
@@ -138,6 +149,11 @@ struct GemmArgs {
     //      through C3 in the same kernel.)
     bf16_t* resid_pk;
     float* resid_parts;
+    // ---- STORE_ARGMIN (nearest-code search, quantizer.py:99-103): d = (am_rownorm[m] + am_colnorm[n]) - 2 acc; the winner per row is
+    //      kept as atomicMin over (float_order_key(d) << 32 | n) in am_best[m] (ties -> lowest n, as torch.argmin on equal values)
+    const float* am_rownorm;
+    const float* am_colnorm;
+    unsigned long long* am_best;
     // ---- chained launches (AR loop on two alternating streams): consecutive kernels may be co-resident; a kernel issues
     //      the loads that do not depend on its predecessor (weights), then waits until chain_wait[0] >= chain_target
     //      (= the predecessor's workgroup count; every workgroup adds 1 to its chain_signal after its last store, behind

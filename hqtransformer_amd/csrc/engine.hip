@@ -59,7 +59,7 @@ struct BlockW {
 };
 
 struct DecLayer {
-    int kind;            // 0 conv3, 1 res, 2 attn, 3 upconv, 4 out
+    int kind;            // 0 conv3, 1 res, 2 attn, 3 upconv, 4 out; encoder: 5 Downsample, 6 conv_in, 7 out
     std::string name;
     int cin, cout, res;
     Lin conv1, conv2, nin, q, k, v, proj;      // conv3/upconv/out use conv1
@@ -102,7 +102,13 @@ struct hqt_handle {
     Lin head_l2;                              // head_levels.2 (three-level models; head_top / head_bot hold levels 0 / 1)
     // ---- stage 1
     std::vector<DecLayer> dec;
-    Lin post_quant;
+    std::vector<DecLayer> enc;               // Encoder.forward in execution order (kinds 6 conv_in, 1, 2, 5 Downsample, 7 norm_out + conv_out)
+    bool has_encoder = false;                 // the encoder tensors were set before finalize: hqt_encode is usable
+    Lin post_quant, quant_conv;
+    struct { bf16_t* w16 = nullptr; float* norm32 = nullptr; float* norm16 = nullptr; } cb[3];   // codebooks as distance-GEMM operands
+    float *vq_h = nullptr, *vq_recon = nullptr, *vq_zz = nullptr, *vq_err = nullptr;
+    void* vq_z = nullptr;
+    unsigned long long* vq_best = nullptr;
     void* act[4] = {nullptr, nullptr, nullptr, nullptr};   // 3 rotating activation buffers + the normalised/activated copy (FAST)
     double* gn_partial = nullptr;
     float* gn_tiles = nullptr;                // per-tile output statistics of the last halo conv ([image][tile][32][2])
@@ -221,6 +227,44 @@ static void build_decoder_plan(hqt_handle* h) {
     add(4, "decoder", block_in, c.s1_out_ch, res);
 }
 
+// Encoder.forward (stage1/modules/layers.py:270-297).  The reference tracks `curr_res` from `resolution` even when conv_in
+// already halves the image (layers.py:221), so with use_init_downsample the attention test runs on twice the real size.
+static void build_encoder_plan(hqt_handle* h) {
+    const hqt_config& c = h->cfg;
+    const int n = c.s1_n_mult;
+    auto is_attn_res = [&](int r) {
+        for (int i = 0; i < c.s1_n_attn_res; ++i) if (c.s1_attn_res[i] == r) return true;
+        return false;
+    };
+    auto add = [&](int kind, const std::string& name, int cin, int cout, int r) {
+        DecLayer l; l.kind = kind; l.name = name; l.cin = cin; l.cout = cout; l.res = r;
+        h->enc.push_back(l);
+    };
+    add(6, "encoder.conv_in", 3, c.s1_ch, c.s1_resolution);
+    int label = c.s1_resolution;
+    int res = c.s1_use_init_downsample ? c.s1_resolution / 2 : c.s1_resolution;
+    int block_in = c.s1_ch;
+    for (int lvl = 0; lvl < n; ++lvl) {
+        const int block_out = c.s1_ch * c.s1_ch_mult[lvl];
+        for (int b = 0; b < c.s1_num_res_blocks; ++b) {
+            add(1, "encoder.down." + std::to_string(lvl) + ".block." + std::to_string(b), block_in, block_out, res);
+            block_in = block_out;
+            if (is_attn_res(label) && c.s1_use_attn)
+                add(2, "encoder.down." + std::to_string(lvl) + ".attn." + std::to_string(b), block_in, block_in, res);
+        }
+        if (lvl != n - 1) {
+            add(5, "encoder.down." + std::to_string(lvl) + ".downsample.conv", block_in, block_in, res);
+            res /= 2; label /= 2;
+        }
+    }
+    if (c.s1_use_mid_block) {
+        add(1, "encoder.mid.block_1", block_in, block_in, res);
+        if (c.s1_use_attn) add(2, "encoder.mid.attn_1", block_in, block_in, res);
+        add(1, "encoder.mid.block_2", block_in, block_in, res);
+    }
+    add(7, "encoder", block_in, c.s1_z_channels, res);
+}
+
 // ------------------------------------------------------------------------------------------ create
 extern "C" int hqt_abi_version(void) { return HQT_ABI_VERSION; }
 extern "C" const char* hqt_last_error(void) { return g_err.c_str(); }
@@ -250,6 +294,7 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         if (c.s1_ch % 32) return fail(HQT_ERR_INVALID, "GroupNorm(32) needs ch %% 32 == 0");
         if (c.s1_z_channels % 16 || (2 * c.s1_embed_dim) % 16) return fail(HQT_ERR_INVALID, "z_channels and 2*embed_dim must be multiples of 16");
         build_decoder_plan(h.get());
+        build_encoder_plan(h.get());
     }
     CHK(alloc_workspace(h.get()));
     *out = h.release();
@@ -257,6 +302,20 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
 }
 
 // Everything a lane owns: activations, KV caches, step state, decoder buffers (the weights live in `w` / the Lin structs).
+// nearest-code search state of hqt_encode: allocated once the encoder tensors are known to be present (finalize), and for clones
+static int alloc_encode_workspace(hqt_handle* h) {
+    const hqt_config& c = h->cfg;
+    const int r = h->dec.front().res;
+    const size_t rows = (size_t)c.max_batch * r * r, elems = rows * c.s1_embed_dim;
+    CHK(dev_alloc(h, (void**)&h->vq_h, elems * 4, true));
+    CHK(dev_alloc(h, (void**)&h->vq_recon, elems * 4, true));
+    CHK(dev_alloc(h, &h->vq_z, elems * 4, true));
+    CHK(dev_alloc(h, (void**)&h->vq_zz, rows * 4, true));
+    CHK(dev_alloc(h, (void**)&h->vq_best, rows * 8, true));
+    CHK(dev_alloc(h, (void**)&h->vq_err, rows * 4 * 3, true));
+    return HQT_OK;
+}
+
 static int alloc_workspace(hqt_handle* hp) {
     struct { hqt_handle* p; hqt_handle* get() const { return p; } hqt_handle* operator->() const { return p; } } h{hp};
     const hqt_config& c = h->cfg;
@@ -298,9 +357,11 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), (void**)&h->partsd, (D / 32 + 1) * rows * 2 * 4, true));
     }
     if (c.has_stage1) {
+        std::vector<DecLayer> both(h->dec);                 // decoder and encoder share the activation / attention / statistics buffers
+        both.insert(both.end(), h->enc.begin(), h->enc.end());
         size_t per_img = 0;
-        for (auto& l : h->dec) {
-            const size_t in_e = (size_t)l.res * l.res * l.cin;
+        for (auto& l : both) {
+            const size_t in_e = (size_t)l.res * l.res * (l.kind == 6 ? 16 : l.cin);       // conv_in reads the image padded to <= 16 channels
             const size_t out_r = l.kind == 3 ? 2 * l.res : l.res;
             const size_t out_e = out_r * out_r * (size_t)(l.kind == 4 ? 0 : l.cout);
             per_img = std::max(per_img, std::max(in_e, out_e));
@@ -311,15 +372,16 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), &h->act[3], h->act_elems * 2, true));
         {
             size_t pe = 0;
-            for (auto& l : h->dec) pe = std::max(pe, gn_stats_fast_partial_elems(h->dec_chunk, l.res * l.res, l.cin, 32));
+            for (auto& l : both) if (l.kind != 6) pe = std::max(pe, gn_stats_fast_partial_elems(h->dec_chunk, l.res * l.res, l.cin, 32));
+            for (auto& l : both) if (l.kind == 1) pe = std::max(pe, gn_stats_fast_partial_elems(h->dec_chunk, l.res * l.res, l.cout, 32));
             CHK(dev_alloc(h.get(), (void**)&h->gn_partial, pe * sizeof(double), true));
             size_t te = 0;
-            for (auto& l : h->dec) { const int ro = l.kind == 3 ? 2 * l.res : l.res; te = std::max(te, (size_t)h->dec_chunk * (ro / 8 + 1) * (ro / 16 + 1) * 64); }
+            for (auto& l : both) { const int ro = l.kind == 3 ? 2 * l.res : l.res; te = std::max(te, (size_t)h->dec_chunk * (ro / 8 + 1) * (ro / 16 + 1) * 64); }
             CHK(dev_alloc(h.get(), (void**)&h->gn_tiles, te * sizeof(float), true));
         }
         const int r = h->dec.front().res;
         size_t attn_c = 0;
-        for (auto& l : h->dec) if (l.kind == 2) attn_c = std::max(attn_c, (size_t)l.cin * l.res * l.res);
+        for (auto& l : both) if (l.kind == 2) attn_c = std::max(attn_c, (size_t)l.cin * l.res * l.res);
         const size_t hw = (size_t)r * r;
         if (attn_c) {
             CHK(dev_alloc(h.get(), &h->aq, attn_c * h->dec_chunk * 4, true));
@@ -327,11 +389,12 @@ static int alloc_workspace(hqt_handle* hp) {
             CHK(dev_alloc(h.get(), &h->av, attn_c * h->dec_chunk * 4, true));
             CHK(dev_alloc(h.get(), &h->ao, attn_c * h->dec_chunk * 4, true));
             size_t smax = 0;
-            for (auto& l : h->dec) if (l.kind == 2) smax = std::max(smax, (size_t)l.res * l.res * l.res * l.res);
+            for (auto& l : both) if (l.kind == 2) smax = std::max(smax, (size_t)l.res * l.res * l.res * l.res);
             CHK(dev_alloc(h.get(), &h->as, smax * h->dec_chunk * 4, true));
         }
         CHK(dev_alloc(h.get(), &h->quant, hw * 2 * c.s1_embed_dim * h->dec_chunk * 4, true));
         CHK(dev_alloc(h.get(), (void**)&h->gn, (size_t)h->dec_chunk * 32 * 2 * 2 * 4, true));
+        if (h->has_encoder) CHK(alloc_encode_workspace(h.get()));            // clones of a handle with an encoder
     }
     return HQT_OK;
 }
@@ -485,6 +548,65 @@ static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int k
     return make_lin(h, l, wt, b, O, I * taps, false);
 }
 
+// the image enters conv_in as NHWC with its 3 channels zero-padded: 4 for the 4x4 stride-2 filter (K = 64), 16 for the 3x3 one (K = 144)
+static int conv_in_cpad(const hqt_config& c) { return c.s1_use_init_downsample ? 4 : 16; }
+
+// Encoder + quant_conv_b + the codebooks as distance-GEMM operands (hqt_encode).  All-or-nothing: called when
+// stage1.encoder.conv_in.weight was set; any other missing encoder tensor is an error.
+static int load_encoder(hqt_handle* h) {
+    const hqt_config& c = h->cfg;
+    for (auto& l : h->enc) {
+        if (l.kind == 6) {
+            const int ks = c.s1_use_init_downsample ? 4 : 3, taps = ks * ks, cp = conv_in_cpad(c);
+            const float *w, *b;
+            CHK(get_w(h, "stage1.encoder.conv_in.weight", {l.cout, 3, ks, ks}, &w));
+            CHK(get_w(h, "stage1.encoder.conv_in.bias", {l.cout}, &b));
+            float* wt;
+            CHK(dev_alloc(h, (void**)&wt, (size_t)l.cout * cp * taps * 4, false));
+            HIPCHK(launch_repack_conv(w, wt, l.cout, 3, taps, 0, cp));
+            CHK(make_lin(h, l.conv1, wt, b, l.cout, cp * taps, false));
+        } else if (l.kind == 5) {
+            CHK(load_conv(h, l.name, l.cout, l.cin, 3, l.conv1));
+        } else if (l.kind == 1) {
+            CHK(get_w(h, "stage1." + l.name + ".norm1.weight", {l.cin}, &l.n1_g));
+            CHK(get_w(h, "stage1." + l.name + ".norm1.bias", {l.cin}, &l.n1_b));
+            CHK(get_w(h, "stage1." + l.name + ".norm2.weight", {l.cout}, &l.n2_g));
+            CHK(get_w(h, "stage1." + l.name + ".norm2.bias", {l.cout}, &l.n2_b));
+            CHK(load_conv(h, l.name + ".conv1", l.cout, l.cin, 3, l.conv1));
+            CHK(load_conv(h, l.name + ".conv2", l.cout, l.cout, 3, l.conv2));
+            if (l.cin != l.cout) CHK(load_conv(h, l.name + ".nin_shortcut", l.cout, l.cin, 1, l.nin));
+        } else if (l.kind == 2) {
+            CHK(get_w(h, "stage1." + l.name + ".norm.weight", {l.cin}, &l.n1_g));
+            CHK(get_w(h, "stage1." + l.name + ".norm.bias", {l.cin}, &l.n1_b));
+            CHK(load_conv(h, l.name + ".q", l.cin, l.cin, 1, l.q));
+            CHK(load_conv(h, l.name + ".k", l.cin, l.cin, 1, l.k));
+            CHK(load_conv(h, l.name + ".v", l.cin, l.cin, 1, l.v));
+            CHK(load_conv(h, l.name + ".proj_out", l.cin, l.cin, 1, l.proj));
+        } else {
+            CHK(get_w(h, "stage1.encoder.norm_out.weight", {l.cin}, &l.n1_g));
+            CHK(get_w(h, "stage1.encoder.norm_out.bias", {l.cin}, &l.n1_b));
+            CHK(load_conv(h, "encoder.conv_out", l.cout, l.cin, 3, l.conv1));
+        }
+    }
+    const int E = c.s1_embed_dim, L = c.code_levels == 3 ? 3 : 2;
+    CHK(load_conv(h, "quant_conv_b", E, c.s1_z_channels, 1, h->quant_conv));
+    for (int l = 0; l < L; ++l) {
+        const int dim = E << (2 * (L - 1 - l));
+        const std::string name = L == 3 ? "stage1.quantizers." + std::to_string(l) + ".embedding"
+                                        : (l == 0 ? "stage1.quantize_t.embedding" : "stage1.quantize_b.embedding");
+        const float* e = h->w[name].d;
+        const size_t n = (size_t)c.s1_n_embed * dim;
+        CHK(dev_alloc(h, (void**)&h->cb[l].w16, n * 2, false));
+        CHK(dev_alloc(h, (void**)&h->cb[l].norm32, (size_t)c.s1_n_embed * 4, false));
+        CHK(dev_alloc(h, (void**)&h->cb[l].norm16, (size_t)c.s1_n_embed * 4, false));
+        HIPCHK(launch_f32_to_bf16(e, h->cb[l].w16, n, 0));
+        HIPCHK(launch_row_sumsq(e, DT_F32, h->cb[l].norm32, c.s1_n_embed, dim, 0));
+        HIPCHK(launch_row_sumsq(h->cb[l].w16, DT_BF16, h->cb[l].norm16, c.s1_n_embed, dim, 0));
+    }
+    h->has_encoder = true;
+    return alloc_encode_workspace(h);
+}
+
 static std::string key2(const hqt_handle* h, const char* name);
 
 extern "C" int hqt_finalize_weights(hqt_handle* h) {
@@ -584,6 +706,7 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
             }
         }
     }
+    if (c.has_stage1 && h->w.count("stage1.encoder.conv_in.weight")) CHK(load_encoder(h));
     HIPCHK(stream_gemm_configure());
     HIPCHK(mfma_gemm_configure());
     HIPCHK(hipDeviceSynchronize());
@@ -1097,14 +1220,124 @@ static void with_gn(GemmArgs& g, const float* stats, const float* gamma, const f
     g.gn_stats = stats; g.gn_gamma = gamma; g.gn_beta = beta; g.gn_groups = 32; g.gn_swish = swish;
 }
 
+// One chunk of images moving through the conv stack (decoder or encoder): the rotating activation buffers and the two
+// GroupNorm statistics slots.
+struct S1Ctx {
+    hqt_handle* h;
+    int n;
+    Mode md;
+    hipStream_t st;
+    int adt;
+    void *cur, *t1, *t2, *tn;
+    float *gn1, *gn2;
+};
+
+// GroupNorm(+swish) in front of a conv.  EXACT: statistics pass, then the normalisation is applied inside
+// the conv's operand loader.  FAST: statistics pass + one bandwidth-bound apply pass into `tn`, so the MFMA
+// conv reads a plain bf16 tensor.  Sets the tensor the conv must read / fills the loader's GN fields.
+static int s1_norm(S1Ctx& c, const void* src, int C, int hw, float* stats, const float* gamma, const float* beta, int swish, GemmArgs* g) {
+    hqt_handle* h = c.h;
+    hipStream_t st = c.st;
+    if (c.md.fast) {
+        if (h->gn_ready.tensor == src) {     // the producing conv already reduced its tiles: only the fixed-order finalize is left
+            Timed t(h, "gn_stats", st);
+            HIPCHK(launch_gn_finalize_tiles(h->gn_tiles, stats, c.n, h->gn_ready.tiles, hw, C, 32, 1e-6f, st));
+        } else {
+            Timed t(h, "gn_stats", st);
+            HIPCHK(launch_gn_stats_fast(src, stats, h->gn_partial, c.n, hw, C, 32, 1e-6f, st));
+        }
+        { Timed t(h, "gn_apply", st); HIPCHK(launch_gn_apply(src, c.tn, stats, gamma, beta, c.n, hw, C, 32, swish, st)); }
+        g->A = c.tn;
+    } else {
+        { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(src, c.adt, stats, c.n, hw, C, 32, 1e-6f, st)); }
+        with_gn(*g, stats, gamma, beta, swish);
+    }
+    return HQT_OK;
+}
+
+// kinds 0 conv3, 1 ResnetBlock, 2 AttnBlock, 3 upsample conv, 5 Downsample conv (shared by Decoder.forward and Encoder.forward)
+static int s1_layer(S1Ctx& c, const DecLayer& l) {
+    hqt_handle* h = c.h;
+    const Mode& md = c.md;
+    hipStream_t st = c.st;
+    const int adt = c.adt, n = c.n;
+    void *&cur = c.cur, *&t1 = c.t1, *&t2 = c.t2;
+    const int res = l.res, hw = res * res;
+    if (l.kind == 0 || l.kind == 3) {
+        const int ro = l.kind == 3 ? 2 * res : res;
+        GemmArgs g = conv_args(cur, n, ro, l.cin, 9, l.kind == 3, t1, l.cout);
+        CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
+        std::swap(cur, t1);
+    } else if (l.kind == 5) {               // Downsample (stage1/modules/layers.py:56-76): pad right / bottom by one, 3x3 stride 2
+        GemmArgs g = conv_args(cur, n, res / 2, l.cin, 9, 0, t1, l.cout);
+        g.conv_stride2 = 1; g.conv_nopad = 1;
+        CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv_down"));
+        std::swap(cur, t1);
+    } else if (l.kind == 1) {               // ResnetBlock (stage1/modules/layers.py:115-133)
+        GemmArgs g = conv_args(cur, n, res, l.cin, 9, 0, t1, l.cout);
+        CHK(s1_norm(c, cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g));
+        CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
+        const void* shortcut = cur;
+        void* outbuf = t2;
+        if (l.cin != l.cout) {
+            GemmArgs sc = conv_args(cur, n, res, l.cin, 1, 0, t2, l.cout);
+            CHK(run_linear(h, md, sc, l.nin, adt, adt, st, "conv1x1"));
+            shortcut = t2;
+            outbuf = cur;                   // x is dead once the shortcut is computed
+        }
+        g = conv_args(t1, n, res, l.cout, 9, 0, outbuf, l.cout);
+        CHK(s1_norm(c, t1, l.cout, hw, c.gn2, l.n2_g, l.n2_b, 1, &g));
+        g.resid = shortcut;
+        CHK(run_linear(h, md, g, l.conv2, adt, adt, st, "conv3x3"));
+        if (outbuf == t2) std::swap(cur, t2);
+    } else if (l.kind == 2) {               // AttnBlock (stage1/modules/layers.py:163-186)
+        const int C = l.cin;
+        GemmArgs g = conv_args(cur, n, res, C, 1, 0, h->aq, C);
+        CHK(s1_norm(c, cur, C, hw, c.gn1, l.n1_g, l.n1_b, 0, &g));
+        const GemmArgs normed = g;           // same normalised input for q, k, v
+        CHK(run_linear(h, md, g, l.q, adt, adt, st, "conv1x1"));
+        g = normed; g.C = h->ak;
+        CHK(run_linear(h, md, g, l.k, adt, adt, st, "conv1x1"));
+        g = normed; g.C = h->av;
+        g.store = STORE_NCHW; g.rows_per_image = hw;                 // V^T per image: [C][hw]
+        CHK(run_linear(h, md, g, l.v, adt, adt, st, "conv1x1"));
+        {   // S[i, j] = q_i . k_j * C^-0.5
+            Timed t(h, "attn_gemm", st);
+            GemmArgs sg{};
+            sg.A = h->aq; sg.lda = C; sg.a_batch_stride = (long long)hw * C;
+            sg.Bw = h->ak; sg.ldb = C; sg.b_batch_stride = (long long)hw * C;
+            sg.C = h->as; sg.ldc = hw; sg.c_batch_stride = (long long)hw * hw;
+            sg.M = hw; sg.N = hw; sg.K = C; sg.batch = n; sg.alpha = 1.0f / sqrtf((float)C); sg.store = STORE_ROWS;
+            if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
+            else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
+        }
+        { Timed t(h, "softmax", st); HIPCHK(launch_softmax_rows(h->as, adt, n * hw, hw, st)); }
+        {   // o[i, c] = sum_j w[i, j] v[c, j]
+            Timed t(h, "attn_gemm", st);
+            GemmArgs sg{};
+            sg.A = h->as; sg.lda = hw; sg.a_batch_stride = (long long)hw * hw;
+            sg.Bw = h->av; sg.ldb = hw; sg.b_batch_stride = (long long)hw * C;
+            sg.C = h->ao; sg.ldc = C; sg.c_batch_stride = (long long)hw * C;
+            sg.M = hw; sg.N = C; sg.K = hw; sg.batch = n; sg.alpha = 1.0f; sg.store = STORE_ROWS;
+            if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
+            else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
+        }
+        g = conv_args(h->ao, n, res, C, 1, 0, t1, C);
+        g.resid = cur;
+        CHK(run_linear(h, md, g, l.proj, adt, adt, st, "conv1x1"));
+        std::swap(cur, t1);
+    } else {
+        return fail(HQT_ERR_INVALID, "s1_layer: kind %d", l.kind);
+    }
+    return HQT_OK;
+}
+
 static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64_t* code_m, const int64_t* code_b, int seq_layout,
                         float* out, int clamp01, const Mode& md, hipStream_t st) {
     const hqt_config& cf = h->cfg;
     const int adt = md.act_dt();
     const int r = h->dec.front().res, E = cf.s1_embed_dim;
     h->gn_ready.tensor = nullptr;
-    float* gn1 = h->gn;
-    float* gn2 = h->gn + (size_t)h->dec_chunk * 64;
     const bool l3 = cf.code_levels == 3;
     {
         Timed t(h, "quant_gather", st);
@@ -1117,101 +1350,19 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
             HIPCHK(launch_quant_gather(q, st));
         }
     }
-    void* cur = h->act[0];
-    void* t1 = h->act[1];
-    void* t2 = h->act[2];
-    void* tn = h->act[3];
+    S1Ctx c{h, n, md, st, adt, h->act[0], h->act[1], h->act[2], h->act[3], h->gn, h->gn + (size_t)h->dec_chunk * 64};
     {
-        GemmArgs g = conv_args(h->quant, n, r, l3 ? E : 2 * E, 1, 0, cur, cf.s1_z_channels);
+        GemmArgs g = conv_args(h->quant, n, r, l3 ? E : 2 * E, 1, 0, c.cur, cf.s1_z_channels);
         CHK(run_linear(h, md, g, h->post_quant, adt, adt, st, "conv1x1"));
     }
-    // GroupNorm(+swish) in front of a conv.  EXACT: statistics pass, then the normalisation is applied inside
-    // the conv's operand loader.  FAST: statistics pass + one bandwidth-bound apply pass into `tn`, so the MFMA
-    // conv reads a plain bf16 tensor.  Returns the tensor the conv must read and fills the loader's GN fields.
-    auto norm = [&](const void* src, int C, int hw, float* stats, const float* gamma, const float* beta, int swish,
-                    GemmArgs* g) -> int {
-        if (md.fast) {
-            if (h->gn_ready.tensor == src) {     // the producing conv already reduced its tiles: only the fixed-order finalize is left
-                Timed t(h, "gn_stats", st);
-                HIPCHK(launch_gn_finalize_tiles(h->gn_tiles, stats, n, h->gn_ready.tiles, hw, C, 32, 1e-6f, st));
-            } else {
-                Timed t(h, "gn_stats", st);
-                HIPCHK(launch_gn_stats_fast(src, stats, h->gn_partial, n, hw, C, 32, 1e-6f, st));
-            }
-            { Timed t(h, "gn_apply", st); HIPCHK(launch_gn_apply(src, tn, stats, gamma, beta, n, hw, C, 32, swish, st)); }
-            g->A = tn;
-        } else {
-            { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(src, adt, stats, n, hw, C, 32, 1e-6f, st)); }
-            with_gn(*g, stats, gamma, beta, swish);
-        }
-        return HQT_OK;
-    };
     for (auto& l : h->dec) {
-        const int res = l.res, hw = res * res;
-        if (l.kind == 0 || l.kind == 3) {
-            const int ro = l.kind == 3 ? 2 * res : res;
-            GemmArgs g = conv_args(cur, n, ro, l.cin, 9, l.kind == 3, t1, l.cout);
-            CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
-            std::swap(cur, t1);
-        } else if (l.kind == 1) {               // ResnetBlock (stage1/modules/layers.py:115-133)
-            GemmArgs g = conv_args(cur, n, res, l.cin, 9, 0, t1, l.cout);
-            CHK(norm(cur, l.cin, hw, gn1, l.n1_g, l.n1_b, 1, &g));
-            CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
-            const void* shortcut = cur;
-            void* outbuf = t2;
-            if (l.cin != l.cout) {
-                GemmArgs sc = conv_args(cur, n, res, l.cin, 1, 0, t2, l.cout);
-                CHK(run_linear(h, md, sc, l.nin, adt, adt, st, "conv1x1"));
-                shortcut = t2;
-                outbuf = cur;                   // x is dead once the shortcut is computed
-            }
-            g = conv_args(t1, n, res, l.cout, 9, 0, outbuf, l.cout);
-            CHK(norm(t1, l.cout, hw, gn2, l.n2_g, l.n2_b, 1, &g));
-            g.resid = shortcut;
-            CHK(run_linear(h, md, g, l.conv2, adt, adt, st, "conv3x3"));
-            if (outbuf == t2) std::swap(cur, t2);
-        } else if (l.kind == 2) {               // AttnBlock (stage1/modules/layers.py:163-186)
-            const int C = l.cin;
-            GemmArgs g = conv_args(cur, n, res, C, 1, 0, h->aq, C);
-            CHK(norm(cur, C, hw, gn1, l.n1_g, l.n1_b, 0, &g));
-            const GemmArgs normed = g;           // same normalised input for q, k, v
-            CHK(run_linear(h, md, g, l.q, adt, adt, st, "conv1x1"));
-            g = normed; g.C = h->ak;
-            CHK(run_linear(h, md, g, l.k, adt, adt, st, "conv1x1"));
-            g = normed; g.C = h->av;
-            g.store = STORE_NCHW; g.rows_per_image = hw;                 // V^T per image: [C][hw]
-            CHK(run_linear(h, md, g, l.v, adt, adt, st, "conv1x1"));
-            {   // S[i, j] = q_i . k_j * C^-0.5
-                Timed t(h, "attn_gemm", st);
-                GemmArgs sg{};
-                sg.A = h->aq; sg.lda = C; sg.a_batch_stride = (long long)hw * C;
-                sg.Bw = h->ak; sg.ldb = C; sg.b_batch_stride = (long long)hw * C;
-                sg.C = h->as; sg.ldc = hw; sg.c_batch_stride = (long long)hw * hw;
-                sg.M = hw; sg.N = hw; sg.K = C; sg.batch = n; sg.alpha = 1.0f / sqrtf((float)C); sg.store = STORE_ROWS;
-                if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
-                else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
-            }
-            { Timed t(h, "softmax", st); HIPCHK(launch_softmax_rows(h->as, adt, n * hw, hw, st)); }
-            {   // o[i, c] = sum_j w[i, j] v[c, j]
-                Timed t(h, "attn_gemm", st);
-                GemmArgs sg{};
-                sg.A = h->as; sg.lda = hw; sg.a_batch_stride = (long long)hw * hw;
-                sg.Bw = h->av; sg.ldb = hw; sg.b_batch_stride = (long long)hw * C;
-                sg.C = h->ao; sg.ldc = C; sg.c_batch_stride = (long long)hw * C;
-                sg.M = hw; sg.N = C; sg.K = hw; sg.batch = n; sg.alpha = 1.0f; sg.store = STORE_ROWS;
-                if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
-                else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
-            }
-            g = conv_args(h->ao, n, res, C, 1, 0, t1, C);
-            g.resid = cur;
-            CHK(run_linear(h, md, g, l.proj, adt, adt, st, "conv1x1"));
-            std::swap(cur, t1);
-        } else {                                // norm_out -> swish -> conv_out, NCHW fp32 (+clamp)
-            GemmArgs g = conv_args(cur, n, res, l.cin, 9, 0, out, l.cout);
-            CHK(norm(cur, l.cin, hw, gn1, l.n1_g, l.n1_b, 1, &g));
-            g.store = STORE_NCHW; g.rows_per_image = hw; g.clamp01 = clamp01;
-            CHK(run_linear(h, md, g, l.conv1, adt, DT_F32, st, "conv_out"));
-        }
+        if (l.kind != 4) { CHK(s1_layer(c, l)); continue; }
+        // norm_out -> swish -> conv_out, NCHW fp32 (+clamp)
+        const int hw = l.res * l.res;
+        GemmArgs g = conv_args(c.cur, n, l.res, l.cin, 9, 0, out, l.cout);
+        CHK(s1_norm(c, c.cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g));
+        g.store = STORE_NCHW; g.rows_per_image = hw; g.clamp01 = clamp01;
+        CHK(run_linear(h, md, g, l.conv1, adt, DT_F32, st, "conv_out"));
     }
     return HQT_OK;
 }
@@ -1254,6 +1405,94 @@ extern "C" int hqt_decode_l3(hqt_handle* h, int B, const int64_t* code_t, const 
 extern "C" int hqt_decode_seq_l3(hqt_handle* h, int B, const int64_t* codes0, const int64_t* codes1, const int64_t* codes2, float* out,
                                  int clamp01, int precision, void* stream) {
     return decode_impl(h, B, codes0, codes1, codes2, 1, out, clamp01, precision, stream, 3);
+}
+
+// ------------------------------------------------------------------------------------------ stage 1, encode side
+// Encoder.forward + quant_conv_b for one chunk of images: h rows (fp32 NHWC [n, r, r, E]) into h_rows
+static int encode_chunk(hqt_handle* h, int n, const float* pixels, float* h_rows, const Mode& md, hipStream_t st) {
+    const hqt_config& cf = h->cfg;
+    const int adt = md.act_dt();
+    h->gn_ready.tensor = nullptr;
+    S1Ctx c{h, n, md, st, adt, h->act[0], h->act[1], h->act[2], h->act[3], h->gn, h->gn + (size_t)h->dec_chunk * 64};
+    for (auto& l : h->enc) {
+        if (l.kind == 6) {                  // conv_in (layers.py:212-216): 3x3 stride 1, or 4x4 stride 2 with use_init_downsample
+            const int cp = conv_in_cpad(cf), down = cf.s1_use_init_downsample ? 1 : 0;
+            { Timed t(h, "image_layout", st); HIPCHK(launch_image_to_nhwc(pixels, c.t2, adt, n, l.res, cp, st)); }
+            GemmArgs g = conv_args(c.t2, n, l.res >> down, cp, down ? 16 : 9, 0, c.t1, l.cout);
+            g.conv_stride2 = down;
+            CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv_in"));
+            std::swap(c.cur, c.t1);
+        } else if (l.kind == 7) {           // norm_out -> swish -> conv_out (layers.py:289-292), then quant_conv_b (generator.py:299) in fp32 rows
+            const int hw = l.res * l.res;
+            GemmArgs g = conv_args(c.cur, n, l.res, l.cin, 9, 0, c.t1, l.cout);
+            CHK(s1_norm(c, c.cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g));
+            CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
+            GemmArgs q = conv_args(c.t1, n, l.res, l.cout, 1, 0, h_rows, cf.s1_embed_dim);
+            CHK(run_linear(h, md, q, h->quant_conv, adt, DT_F32, st, "conv1x1"));
+        } else {
+            CHK(s1_layer(c, l));
+        }
+    }
+    return HQT_OK;
+}
+
+extern "C" int hqt_has_encoder(const hqt_handle* h) { return h ? (h->has_encoder ? 1 : 0) : -1; }
+
+extern "C" int hqt_encode(hqt_handle* h, int B, const float* pixels, int precision, const hqt_encode_out* out, void* stream) {
+    if (!h || !pixels || !out) return fail(HQT_ERR_INVALID, "null argument");
+    if (!h->finalized) return fail(HQT_ERR_STATE, "hqt_finalize_weights has not run");
+    if (!h->cfg.has_stage1) return fail(HQT_ERR_STATE, "handle was created without stage 1");
+    if (!h->has_encoder) return fail(HQT_ERR_STATE, "the encoder tensors (stage1.encoder.*, stage1.quant_conv_b.*) were not set before hqt_finalize_weights");
+    if (B < 1 || B > h->cfg.max_batch) return fail(HQT_ERR_INVALID, "B must be in [1, max_batch = %d]", h->cfg.max_batch);
+    const hqt_config& cf = h->cfg;
+    const int L = cf.code_levels == 3 ? 3 : 2;
+    for (int l = 0; l < L; ++l) if (!out->codes[l]) return fail(HQT_ERR_INVALID, "codes[%d] is NULL", l);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    Mode md;
+    md.fast = precision == HQT_PRECISION_FAST;
+    const int r = h->dec.front().res, E = cf.s1_embed_dim, R = cf.s1_resolution;
+    for (int b0 = 0; b0 < B; b0 += h->dec_chunk) {
+        const int n = std::min(h->dec_chunk, B - b0);
+        CHK(encode_chunk(h, n, pixels + (size_t)b0 * 3 * R * R, h->vq_h + (size_t)b0 * r * r * E, md, st));
+    }
+    // residual quantisation, coarse -> fine, over the whole batch (generator.py:300-309 / 541-560)
+    const size_t elems = (size_t)B * r * r * E;
+    for (int l = 0; l < L; ++l) {
+        const int k = L - 1 - l, rq = r >> k, dim = E << (2 * k), M = B * rq * rq;
+        const std::string name = L == 3 ? "quantizers." + std::to_string(l) + ".embedding" : (l == 0 ? "quantize_t.embedding" : "quantize_b.embedding");
+        VqArgs a{};
+        a.h = h->vq_h; a.recon = l == 0 ? nullptr : h->vq_recon;
+        a.B = B; a.r = r; a.E = E; a.k = k;
+        a.z = h->vq_z; a.z_dtype = md.act_dt(); a.zz = h->vq_zz; a.resid_nchw = out->resid[l];
+        a.best = h->vq_best; a.emb = W1(h, name); a.codes = out->codes[l]; a.quant_nchw = out->quant[l];
+        a.err_rows = h->vq_err + (size_t)l * cf.max_batch * r * r;
+        { Timed t(h, "vq_rows", st); HIPCHK(launch_vq_rows(a, st)); }
+        HIPCHK(hipMemsetAsync(h->vq_best, 0xff, (size_t)M * 8, st));
+        {
+            Timed t(h, "vq_distance", st);
+            GemmArgs g{};
+            g.A = h->vq_z; g.lda = dim; g.M = M; g.N = cf.s1_n_embed; g.K = dim; g.batch = 1; g.ldb = dim; g.alpha = 1.0f;
+            g.store = STORE_ARGMIN; g.am_rownorm = h->vq_zz; g.am_best = h->vq_best; g.zero_page = h->zero_page;
+            if (md.fast) {
+                g.Bw = h->cb[l].w16; g.am_colnorm = h->cb[l].norm16;
+                if (mfma_gemm_ok(g, DT_BF16, DT_BF16, DT_F32)) HIPCHK(launch_mfma_gemm(g, DT_BF16, DT_BF16, DT_F32, st));
+                else HIPCHK(launch_gemm_generic(g, DT_BF16, DT_BF16, DT_F32, st));
+            } else {
+                g.Bw = a.emb; g.am_colnorm = h->cb[l].norm32;
+                HIPCHK(launch_gemm_generic(g, DT_F32, DT_F32, DT_F32, st));
+            }
+        }
+        if (l == 0) {                       // the running reconstruction starts at zero; level 0 reads h alone (generator.py:300-301)
+            HIPCHK(hipMemsetAsync(h->vq_recon, 0, elems * 4, st));
+            a.recon = h->vq_recon;
+            // with recon == 0 the finish pass computes z = h - 0 and recon = q + 0: the same values as the reference's h_t / PS(quant_t)
+        }
+        { Timed t(h, "vq_finish", st); HIPCHK(launch_vq_finish(a, st)); }
+        if (out->diff) HIPCHK(launch_vq_diff(a.err_rows, M, 0.25f / ((float)M * (float)dim), out->diff + l, st));
+    }
+    if (out->recon) HIPCHK(launch_nhwc_to_nchw_f32(h->vq_recon, out->recon, B, r * r, E, st));
+    return HQT_OK;
 }
 
 extern "C" int hqt_set_policy(hqt_handle* h, int policy) {

@@ -6,7 +6,7 @@
 
 hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
 // [O][I][taps] -> [O][taps][I]
-hipError_t launch_repack_conv(const float* src, float* dst, int O, int I, int taps, hipStream_t st);
+hipError_t launch_repack_conv(const float* src, float* dst, int O, int I, int taps, hipStream_t st, int Ipad = 0);
 
 // ---- weight-streaming GEMM (AR loop, M = B or 4B rows): y[M,N] = x[M,K] W[N,K]^T, W pre-packed
 bool stream_gemm_supported(int N, int K);

@@ -20,19 +20,20 @@ hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream
     return hipGetLastError();
 }
 
-__global__ void repack_conv_kernel(const float* src, float* dst, int O, int I, int taps) {
-    const size_t n = (size_t)O * I * taps;
+__global__ void repack_conv_kernel(const float* src, float* dst, int O, int I, int taps, int Ipad) {
+    const size_t n = (size_t)O * Ipad * taps;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int ii = (int)(i % I);
-        const int t = (int)((i / I) % taps);
-        const size_t o = i / ((size_t)I * taps);
-        dst[i] = src[(o * I + ii) * taps + t];
+        const int ii = (int)(i % Ipad);
+        const int t = (int)((i / Ipad) % taps);
+        const size_t o = i / ((size_t)Ipad * taps);
+        dst[i] = ii < I ? src[(o * I + ii) * taps + t] : 0.0f;          // channels I..Ipad-1: zero filters for a zero-padded input
     }
 }
-hipError_t launch_repack_conv(const float* src, float* dst, int O, int I, int taps, hipStream_t st) {
-    const size_t n = (size_t)O * I * taps;
+hipError_t launch_repack_conv(const float* src, float* dst, int O, int I, int taps, hipStream_t st, int Ipad) {
+    if (Ipad < I) Ipad = I;
+    const size_t n = (size_t)O * Ipad * taps;
     const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-    repack_conv_kernel<<<grid, 256, 0, st>>>(src, dst, O, I, taps);
+    repack_conv_kernel<<<grid, 256, 0, st>>>(src, dst, O, I, taps, Ipad);
     return hipGetLastError();
 }
 

@@ -62,10 +62,13 @@ struct ALoader {
         if (!g.conv_taps) { ld4<TA>(row + k, v); return; }
         const int tap = k / g.Cin;
         const int c = k - tap * g.Cin;
-        int iy = y, ix = x;
-        if (g.conv_taps == 9) { iy += tap / 3 - 1; ix += tap % 3 - 1; }
-        if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) return;          // zero padding of the activated tensor
-        const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
+        const int ks = conv_ks(g.conv_taps), s = 1 + g.conv_stride2;
+        const int pad = (ks > 1 && !g.conv_nopad) ? 1 : 0;
+        const int t3 = tap / ks;
+        const int iy = y * s + t3 - pad, ix = x * s + (tap - t3 * ks) - pad;
+        const int Hv = g.H * s, Wv = g.W * s;                              // input size as the filter sees it (after the x2 upsample)
+        if (iy < 0 || iy >= Hv || ix < 0 || ix >= Wv) return;            // zero padding of the activated tensor
+        const int Hin = Hv >> g.upsample, Win = Wv >> g.upsample;
         const TA* p = base + (((long long)img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * g.Cin + c;
         ld4<TA>(p, v);
         if (g.gn_stats) {
@@ -161,6 +164,32 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
+    }
+    if (g.store == STORE_ARGMIN) {                   // nearest code: the tile's best (distance, index) per row, one atomic per row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ty * 4 + i;
+            unsigned long long best = ~0ull;
+            if (m < g.M) {
+                const float zz = g.am_rownorm[m];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + tx * 4 + j;
+                    if (n < g.N) {
+                        const float d = (zz + g.am_colnorm[n]) - 2.0f * acc[i][j];       // quantizer.py:99-101, same association
+                        const unsigned long long key = ((unsigned long long)float_order_key(d) << 32) | (unsigned)n;
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {      // the 16 lanes tx = 0..15 of one ty are consecutive lanes of a wave
+                const unsigned long long o = __shfl_xor(best, off);
+                best = o < best ? o : best;
+            }
+            if (tx == 0 && m < g.M) atomicMin(g.am_best + m, best);
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

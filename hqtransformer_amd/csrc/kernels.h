@@ -149,3 +149,36 @@ hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, in
 size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups);
 // statistics from the per-tile partials of a halo conv (fast_kernels.h: conv_halo_stats_ok)
 hipError_t launch_gn_finalize_tiles(const float* partial, float* stats, int B, int tiles, int HW, int C, int groups, float eps, hipStream_t st);
+
+// ---- HQ-VAE encode side (generator.py:298-310, 530-568; quantizer.py:91-133)
+// fp32 NCHW image [B, 3, R, R] -> NHWC [B, R, R, cpad] (channels >= 3 are zero) in the activation dtype
+hipError_t launch_image_to_nhwc(const float* img, void* out, int out_dtype, int B, int R, int cpad, hipStream_t st);
+// out[m] = sum_k rows[m][k]^2 (fp32, fixed order)
+hipError_t launch_row_sumsq(const void* rows, int dtype, float* out, int M, int K, hipStream_t st);
+
+// One residual-quantisation level.  Everything is kept in the bottom layout (NHWC fp32 [B, r, r, E]): h = quant_conv_b(encoder(x)),
+// recon = the pixel-shuffled sum of the coarser levels' quants (NULL at level 0).  Level rows: m = (b, y, x) at resolution
+// r >> k, column cq in [0, E * 4^k) <-> k nested pixel-unshuffles (cq = (...(c * 4 + 2 i1 + j1) * 4 + 2 i2 + j2)...).
+struct VqArgs {
+    const float* h;
+    float* recon;
+    int B, r, E, k;
+    // rows pass
+    void* z;                 // [M, dim] residual rows in `z_dtype` (the distance GEMM's A operand)
+    int z_dtype;
+    float* zz;               // [M] |z|^2 of the stored (rounded) rows
+    float* resid_nchw;       // optional [B, dim, rq, rq] fp32: the quantiser's input (reference `resids` / code[2])
+    // finish pass
+    const unsigned long long* best;
+    const float* emb;        // [n_embed, dim] fp32
+    int64_t* codes;          // [B, rq, rq]
+    float* quant_nchw;       // optional [B, dim, rq, rq]: z + (e - z)  (the straight-through value, quantizer.py:131)
+    float* err_rows;         // [M] sum_c (e - z)^2
+};
+hipError_t launch_vq_rows(const VqArgs& a, hipStream_t st);
+hipError_t launch_vq_finish(const VqArgs& a, hipStream_t st);
+// diff[0] = scale * sum(err_rows[0..M)) in a fixed order (one workgroup)
+hipError_t launch_vq_diff(const float* err_rows, int M, float scale, float* diff, hipStream_t st);
+// fp32 NHWC [B, r, r, E] -> fp32 NCHW
+hipError_t launch_nhwc_to_nchw_f32(const float* in, float* out, int B, int hw, int C, hipStream_t st);
+

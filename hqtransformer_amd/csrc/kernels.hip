@@ -986,6 +986,146 @@ hipError_t launch_softmax_rows(void* x, int dtype, int rows, int n, hipStream_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// HQ-VAE encode side: image layout, nearest-code search bookkeeping (the distance GEMM itself is STORE_ARGMIN)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void image_to_nhwc_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int R, int cpad) {
+    const long long npix = (long long)B * R * R;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        const long long b = p / ((long long)R * R), pix = p - b * R * R;
+        for (int c = 0; c < cpad; ++c) {
+            const float v = c < 3 ? img[(b * 3 + c) * R * R + pix] : 0.0f;
+            st1<T>(out + p * cpad + c, v);
+        }
+    }
+}
+hipError_t launch_image_to_nhwc(const float* img, void* out, int out_dtype, int B, int R, int cpad, hipStream_t st) {
+    const long long npix = (long long)B * R * R;
+    const int blocks = (int)std::min<long long>((npix + 255) / 256, 4096);
+    if (out_dtype == DT_BF16) image_to_nhwc_kernel<bf16_t><<<blocks, 256, 0, st>>>(img, (bf16_t*)out, B, R, cpad);
+    else image_to_nhwc_kernel<float><<<blocks, 256, 0, st>>>(img, (float*)out, B, R, cpad);
+    return hipGetLastError();
+}
+
+// fixed-order sum over the 256 threads of a workgroup (same result on every run)
+__device__ inline float block_sum_256(float v, float* sh) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[wave] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const T* __restrict__ rows, float* __restrict__ out, int M, int K) {
+    __shared__ float sh[4];
+    const int m = blockIdx.x;
+    float acc = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) { const float v = ld1<T>(rows + (long long)m * K + k); acc += v * v; }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) out[m] = acc;
+}
+hipError_t launch_row_sumsq(const void* rows, int dtype, float* out, int M, int K, hipStream_t st) {
+    if (dtype == DT_BF16) row_sumsq_kernel<bf16_t><<<M, 256, 0, st>>>((const bf16_t*)rows, out, M, K);
+    else row_sumsq_kernel<float><<<M, 256, 0, st>>>((const float*)rows, out, M, K);
+    return hipGetLastError();
+}
+
+// (level row m = (b, y, x), level column cq)  ->  offset into the bottom-layout NHWC [B, r, r, E] tensors
+__device__ __forceinline__ long long vq_bottom_off(int b, int y, int x, int cq, int k, int r, int E) {
+    int c = cq;
+    for (int t = 0; t < k; ++t) {           // PixelUnshuffle(2): channel c * 4 + 2 i + j of the coarse map = channel c at (2 y + i, 2 x + j)
+        const int j = c & 1, i = (c >> 1) & 1;
+        c >>= 2;
+        y = 2 * y + i; x = 2 * x + j;
+    }
+    return (((long long)b * r + y) * r + x) * E + c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vq_rows_kernel(VqArgs a) {
+    __shared__ float sh[4];
+    const int rq = a.r >> a.k, dim = a.E << (2 * a.k);
+    const int m = blockIdx.x;
+    const int b = m / (rq * rq), pix = m - b * rq * rq, y = pix / rq, x = pix - y * rq;
+    T* zrow = reinterpret_cast<T*>(a.z) + (long long)m * dim;
+    float acc = 0.0f;
+    for (int cq = threadIdx.x; cq < dim; cq += 256) {
+        const long long o = vq_bottom_off(b, y, x, cq, a.k, a.r, a.E);
+        float v = a.h[o];
+        if (a.recon) v = v - a.recon[o];                    // generator.py:303 / 544: h - upsampled coarser quant
+        if (a.resid_nchw) a.resid_nchw[((long long)b * dim + cq) * rq * rq + pix] = v;
+        st1<T>(zrow + cq, v);
+        const float vr = ld1<T>(zrow + cq);                  // the value the distance GEMM will read
+        acc += vr * vr;
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) a.zz[m] = acc;
+}
+hipError_t launch_vq_rows(const VqArgs& a, hipStream_t st) {
+    const int rq = a.r >> a.k, M = a.B * rq * rq;
+    if (a.z_dtype == DT_BF16) vq_rows_kernel<bf16_t><<<M, 256, 0, st>>>(a);
+    else vq_rows_kernel<float><<<M, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void vq_finish_kernel(VqArgs a) {
+    __shared__ float sh[4];
+    const int rq = a.r >> a.k, dim = a.E << (2 * a.k);
+    const int m = blockIdx.x;
+    const int b = m / (rq * rq), pix = m - b * rq * rq, y = pix / rq, x = pix - y * rq;
+    const long long code = (long long)(a.best[m] & 0xffffffffull);
+    if (threadIdx.x == 0) a.codes[m] = code;
+    const float* e = a.emb + code * dim;
+    float acc = 0.0f;
+    for (int cq = threadIdx.x; cq < dim; cq += 256) {
+        const long long o = vq_bottom_off(b, y, x, cq, a.k, a.r, a.E);
+        const float rec = a.recon ? a.recon[o] : 0.0f;
+        const float z = a.recon ? a.h[o] - rec : a.h[o];
+        const float d = e[cq] - z;
+        acc += d * d;                                        // quantizer.py:130 (before the straight-through form)
+        const float q = z + d;                               // quantizer.py:131: z + (z_q - z).detach()
+        if (a.quant_nchw) a.quant_nchw[((long long)b * dim + cq) * rq * rq + pix] = q;
+        if (a.recon) a.recon[o] = q + rec;                   // generator.py:552: _quant + recons[-1], then pixel-shuffled (= this layout)
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) a.err_rows[m] = acc;
+}
+hipError_t launch_vq_finish(const VqArgs& a, hipStream_t st) {
+    const int rq = a.r >> a.k, M = a.B * rq * rq;
+    vq_finish_kernel<<<M, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void vq_diff_kernel(const float* __restrict__ err_rows, int M, float scale, float* __restrict__ diff) {
+    __shared__ float sh[4];
+    float acc = 0.0f;
+    for (int m = threadIdx.x; m < M; m += 256) acc += err_rows[m];
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) diff[0] = acc * scale;
+}
+hipError_t launch_vq_diff(const float* err_rows, int M, float scale, float* diff, hipStream_t st) {
+    vq_diff_kernel<<<1, 256, 0, st>>>(err_rows, M, scale, diff);
+    return hipGetLastError();
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int hw, int C) {
+    const long long n = (long long)B * hw * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ((long long)hw * C), rem = i - b * hw * C;
+        const int c = (int)(rem / hw), p = (int)(rem - (long long)c * hw);          // i indexes the NCHW output
+        out[i] = in[(b * hw + p) * C + c];
+    }
+}
+hipError_t launch_nhwc_to_nchw_f32(const float* in, float* out, int B, int hw, int C, hipStream_t st) {
+    const long long n = (long long)B * hw * C;
+    nhwc_to_nchw_f32_kernel<<<(int)std::min<long long>((n + 255) / 256, 4096), 256, 0, st>>>(in, out, B, hw, C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic GEMM dispatch
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_gemm_generic(const GemmArgs& g, int ta, int tb, int tc, hipStream_t st) {

@@ -274,21 +274,22 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
         brow[i] = (n0 + row < g.N) ? Bbase + (long long)(n0 + row) * g.ldb : nullptr;
     }
     const int cpt = g.conv_taps ? g.Cin / BKG : 1;
-    const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
+    const int Hv = g.H << g.conv_stride2, Wv = g.W << g.conv_stride2;      // input size as the filter sees it (Downsample: stride 2)
+    const int Hin = Hv >> g.upsample, Win = Wv >> g.upsample;
     auto issue = [&](int kt, int buf) {
         const int k0 = kt * BKG;
         const int tap = g.conv_taps ? kt / cpt : 0;
         const int c0 = k0 - tap * g.Cin;
         int dy = 0, dx = 0;
-        if (g.conv_taps == 9) { const int t3 = tap / 3; dy = t3 - 1; dx = tap - 3 * t3 - 1; }
+        if (g.conv_taps == 9) { const int t3 = tap / 3; dy = t3 - 1 + g.conv_nopad; dx = tap - 3 * t3 - 1 + g.conv_nopad; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16_t* src = zero;
             if (arow[i].ok) {
                 if (!g.conv_taps) src = arow[i].row + k0 + chunk[i];
                 else {
-                    const int iy = arow[i].y + dy, ix = arow[i].x + dx;
-                    if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+                    const int iy = (arow[i].y << g.conv_stride2) + dy, ix = (arow[i].x << g.conv_stride2) + dx;
+                    if ((unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv)
                         src = Abase + (((long long)arow[i].img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * g.Cin + c0 + chunk[i];
                 }
             }
@@ -734,7 +735,7 @@ int conv_halo_tiles_per_image(const GemmArgs& g) { return (g.H / conv_halo_tile_
 // shapes the halo kernel takes: bf16 3x3 conv, whole 8 x 16 pixel tiles, 64-channel chunks, NHWC bf16 rows that
 // can be stored 16 B at a time (or the fp32 NCHW store of conv_out)
 static bool halo_ok(const GemmArgs& g, int c_dt) {
-    if (g.conv_taps != 9 || !g.zero_page || g.gn_stats || g.a_packed_mb || (g.batch > 1)) return false;
+    if (g.conv_taps != 9 || g.conv_stride2 || g.conv_nopad || !g.zero_page || g.gn_stats || g.a_packed_mb || (g.batch > 1)) return false;
     if (g.Cin % 64 != 0 || g.ldb % 8 != 0 || g.K != 9 * g.Cin) return false;
     if (g.H % 8 != 0 || g.W % HALO_TX != 0 || g.M % (g.H * g.W) != 0) return false;
     if (g.act != ACT_NONE) return false;               // swish lives in the GroupNorm pass; keeps the epilogue code small
@@ -747,13 +748,17 @@ static bool glds_ok(const GemmArgs& g) {
     if (!((g.store == STORE_ROWS && g.rows_per_group == 0) || (g.store == STORE_NCHW && !g.resid && g.act == ACT_NONE) ||
           (g.store == STORE_QKV && !g.conv_taps))) return false;
     if (g.K % 64 != 0 || g.ldb % 8 != 0) return false;
-    if (g.conv_taps) return g.Cin % 64 == 0;
+    if (g.conv_taps) return g.Cin % 64 == 0 && (g.conv_taps == 1 || g.conv_taps == 9) && !(g.conv_stride2 && g.upsample);
     return g.lda % 8 == 0;
 }
+
+static bool big_tile_shape(const GemmArgs& g);
 
 bool mfma_gemm_ok(const GemmArgs& g, int a_dt, int b_dt, int c_dt) {
     (void)c_dt;
     if (a_dt != DT_BF16 || b_dt != DT_BF16 || g.a_packed_mb) return false;
+    if (g.store == STORE_ARGMIN) return false;
+    if (g.conv_stride2 || g.conv_nopad || g.conv_taps == 16) return big_tile_shape(g) && glds_ok(g);   // only the LDS-DMA kernel knows strided taps
     if (g.K % BK != 0) return false;
     if (g.conv_taps && g.Cin % BK != 0) return false;
     if (!g.conv_taps && (g.lda % 8 != 0)) return false;

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import PRECISION_EXACT, PRECISION_FAST, hqt_config, hqt_sample_opts, hqt_sample_opts_l3
+from ._lib import PRECISION_EXACT, PRECISION_FAST, hqt_config, hqt_encode_out, hqt_sample_opts, hqt_sample_opts_l3
 from .spec import Stage1Spec, Stage2Spec
 
 
@@ -238,6 +238,52 @@ class Engine:
             _lib.check(fn(self.h, B, _ptr(cs[0]), _ptr(cs[1]), _ptr(cs[2]), _ptr(out), int(clamp01), int(precision), C.c_void_p(stream)))
         self._keep_dec = cs
         return out
+
+    # ------------------------------------------------------------------ stage 1, encode side
+    @property
+    def has_encoder(self) -> bool:
+        return self.lib.hqt_has_encoder(self.h) == 1
+
+    def encode(self, pixels: torch.Tensor, *, precision: int = PRECISION_EXACT, want_quant: bool = False,
+               want_resid: bool = False, want_recon: bool = False, want_diff: bool = False) -> Dict[str, object]:
+        """``SimRQGAN2Generator.encode`` / ``HQVAEGenerator.encode`` (generator.py:298-310, 530-568) through ``hqt_encode``:
+        fp32 [B, 3, R, R] -> ``codes`` (list, coarse -> fine, int64 [B, r_l, r_l]) and on request ``quant`` / ``resid``
+        (lists of fp32 [B, dim_l, r_l, r_l]), ``recon`` (fp32 [B, E, r, r]) and ``diff`` (fp32 [levels])."""
+        dev = self.device
+        s1 = self.s1
+        x = pixels.to(device=dev, dtype=torch.float32).contiguous()
+        B = int(x.shape[0])
+        if tuple(x.shape) != (B, 3, s1.resolution, s1.resolution):
+            raise ValueError(f'pixels: expected {(B, 3, s1.resolution, s1.resolution)}, got {tuple(x.shape)}')
+        L = 3 if s1.code_levels == 3 else 2
+        r, E = s1.z_res, s1.embed_dim
+        o = hqt_encode_out()
+        res: Dict[str, object] = {'codes': [], 'quant': [], 'resid': []}
+        for l in range(L):
+            k = L - 1 - l
+            rq, dim = r >> k, E * 4 ** k
+            c = torch.empty((B, rq, rq), dtype=torch.int64, device=dev)
+            res['codes'].append(c)
+            o.codes[l] = _ptr(c)
+            if want_quant:
+                q = torch.empty((B, dim, rq, rq), dtype=torch.float32, device=dev)
+                res['quant'].append(q)
+                o.quant[l] = _ptr(q)
+            if want_resid:
+                z = torch.empty((B, dim, rq, rq), dtype=torch.float32, device=dev)
+                res['resid'].append(z)
+                o.resid[l] = _ptr(z)
+        if want_recon:
+            res['recon'] = torch.empty((B, E, r, r), dtype=torch.float32, device=dev)
+            o.recon = _ptr(res['recon'])
+        if want_diff:
+            res['diff'] = torch.empty((L,), dtype=torch.float32, device=dev)
+            o.diff = _ptr(res['diff'])
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.hqt_encode(self.h, B, _ptr(x), int(precision), C.byref(o), C.c_void_p(stream)))
+        self._keep_enc = x
+        return res
 
     # ------------------------------------------------------------------ stage 1
     def decode(self, code_t: Optional[torch.Tensor], code_b: Optional[torch.Tensor], *, precision: int = PRECISION_EXACT,

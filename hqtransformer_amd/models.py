@@ -19,7 +19,7 @@ import torch
 from . import _lib, synth
 from ._lib import PRECISION_EXACT, PRECISION_FAST
 from .engine import Engine
-from .spec import (COND_CLS, COND_TXT, STAGE2_UNUSED, Stage1Spec, Stage2Spec, stage1_is_ignored, stage1_param_shapes,
+from .spec import (COND_CLS, COND_TXT, STAGE2_UNUSED, Stage1Spec, Stage2Spec, stage1_encoder_param_shapes, stage1_is_ignored, stage1_param_shapes,
                    stage1_spec_from_config, stage2_param_shapes, stage2_spec_from_config)
 
 
@@ -144,10 +144,14 @@ class HQTransformerStage2(_Stage):
 
 
 class HQVAEStage1(_Stage):
-    """Counterpart of ``SimRQGAN2Generator`` (``hqvae/models/stage1/generator.py:176-395``), decode side only."""
+    """Counterpart of ``SimRQGAN2Generator`` (``hqvae/models/stage1/generator.py:176-395``) and, with ``spec.code_levels == 3``,
+    of ``HQVAEGenerator`` (generator.py:398-615): ``decode_code`` / ``decode`` and the encode side (``encode``, ``get_codes``)."""
 
     def __init__(self, spec: Stage1Spec, seed: int = 0):
-        super().__init__(stage1_param_shapes(spec), synth.stage1_weights(spec, seed, 'bench'))
+        shapes = OrderedDict(stage1_encoder_param_shapes(spec))
+        shapes.update(stage1_param_shapes(spec))
+        w = synth.stage1_weights(spec, seed, 'bench', encoder=True)
+        super().__init__(shapes, OrderedDict((k, w[k]) for k in shapes))
         self.spec = spec
         self.precision = 'exact'      # the reference decodes outside autocast, i.e. in fp32 (measure_throughput:108-111)
         self.bottom_window = 2
@@ -180,6 +184,43 @@ class HQVAEStage1(_Stage):
         ref = code_t if code_t is not None else code_b
         prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
         return self.engine(int(ref.shape[0]), lane).decode(code_t, code_b, precision=prec, clamp01=clamp01)
+
+    # -- encode side (generator.py:298-310, 369-370; HQVAEGenerator.encode 530-568)
+    def _encode(self, x: torch.Tensor, precision: Optional[str], lane: int, **want):
+        prec = PRECISION_FAST if (precision or self.precision) == 'fast' else PRECISION_EXACT
+        return self.engine(int(x.shape[0]), lane).encode(x, precision=prec, **want)
+
+    def encode(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0):
+        """Two levels -- ``SimRQGAN2Generator.encode``: ``(quant_t, quant_b, diff_t, diff_b, (code_t, code_b, h_b))`` with the codes
+        flattened as the reference returns them ([B * r_l * r_l]) and ``h_b`` the bottom quantiser's input.
+        Three levels -- ``HQVAEGenerator.encode``: ``(quant, diffs, codes, resids[1:])`` with ``quant`` the summed reconstruction."""
+        three = self.spec.code_levels == 3
+        o = self._encode(x, precision, lane, want_quant=not three, want_resid=True, want_recon=three, want_diff=True)
+        codes = [c.reshape(-1) for c in o['codes']]
+        diffs = list(o['diff'].unbind(0))
+        if three:
+            return o['recon'], diffs, codes, o['resid'][1:]
+        return o['quant'][0], o['quant'][1], diffs[0], diffs[1], (codes[0], codes[1], o['resid'][1])
+
+    def get_codes(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0):
+        """``SimRQGAN2Generator.get_codes`` (generator.py:369-370): ``(code_t, code_b)``, flattened; three levels: the list of codes."""
+        o = self._encode(x, precision, lane)
+        codes = [c.reshape(-1) for c in o['codes']]
+        return codes if self.spec.code_levels == 3 else (codes[0], codes[1])
+
+    def code_grids(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0):
+        """The codes as grids [B, r_l, r_l], coarse -> fine: what ``decode_code`` takes back."""
+        return self._encode(x, precision, lane)['codes']
+
+    def forward(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0) -> torch.Tensor:
+        """Reconstruction ``decode(encode(x))`` (the ``dec`` of ``SimRQGAN2Generator.forward`` in eval mode, generator.py:262-280;
+        eval_stage1.py reads only this output)."""
+        grids = self.code_grids(x, precision, lane)
+        if self.spec.code_levels == 3:
+            return self.decode_code(list(grids), precision=precision, lane=lane)
+        return self.decode_code(grids[0], grids[1], precision=precision, lane=lane)
+
+    __call__ = forward
 
     def decode_sequences(self, codes_top, codes_bot: Optional[torch.Tensor] = None, precision: Optional[str] = None,
                          clamp01: bool = False, lane: int = 0) -> torch.Tensor:

@@ -287,10 +287,87 @@ def stage1_param_shapes(s: Stage1Spec) -> 'OrderedDict[str, Tuple[int, ...]]':
     return out
 
 
+def encoder_plan(s: Stage1Spec) -> List[DecoderLayer]:
+    """``Encoder.forward`` (stage1/modules/layers.py:270-297) in execution order; kinds 'in', 'res', 'attn', 'down', 'out'.
+    The reference starts its ``curr_res`` bookkeeping at ``resolution`` even when conv_in already halves the image
+    (layers.py:221), so with use_init_downsample the attention test sees twice the real feature-map size."""
+    n = len(s.ch_mult)
+    plan = [DecoderLayer('in', 'encoder.conv_in', 3, s.ch, s.resolution)]
+    label = s.resolution
+    res = s.resolution // 2 if s.use_init_downsample else s.resolution
+    block_in = s.ch
+    for lvl in range(n):
+        block_out = s.ch * s.ch_mult[lvl]
+        for b in range(s.num_res_blocks):
+            plan.append(DecoderLayer('res', f'encoder.down.{lvl}.block.{b}', block_in, block_out, res))
+            block_in = block_out
+            if label in s.attn_resolutions and s.use_attn:
+                plan.append(DecoderLayer('attn', f'encoder.down.{lvl}.attn.{b}', block_in, block_in, res))
+        if lvl != n - 1:
+            plan.append(DecoderLayer('down', f'encoder.down.{lvl}.downsample.conv', block_in, block_in, res))
+            res //= 2
+            label //= 2
+    if s.use_mid_block:
+        plan.append(DecoderLayer('res', 'encoder.mid.block_1', block_in, block_in, res))
+        if s.use_attn:
+            plan.append(DecoderLayer('attn', 'encoder.mid.attn_1', block_in, block_in, res))
+        plan.append(DecoderLayer('res', 'encoder.mid.block_2', block_in, block_in, res))
+    plan.append(DecoderLayer('out', 'encoder', block_in, s.z_channels, res))
+    return plan
+
+
+def _layer_shapes(l: DecoderLayer, out: 'OrderedDict[str, Tuple[int, ...]]') -> None:
+    if l.kind == 'res':
+        out[f'{l.name}.norm1.weight'] = (l.cin,)
+        out[f'{l.name}.norm1.bias'] = (l.cin,)
+        out[f'{l.name}.conv1.weight'] = (l.cout, l.cin, 3, 3)
+        out[f'{l.name}.conv1.bias'] = (l.cout,)
+        out[f'{l.name}.norm2.weight'] = (l.cout,)
+        out[f'{l.name}.norm2.bias'] = (l.cout,)
+        out[f'{l.name}.conv2.weight'] = (l.cout, l.cout, 3, 3)
+        out[f'{l.name}.conv2.bias'] = (l.cout,)
+        if l.cin != l.cout:
+            out[f'{l.name}.nin_shortcut.weight'] = (l.cout, l.cin, 1, 1)
+            out[f'{l.name}.nin_shortcut.bias'] = (l.cout,)
+    elif l.kind == 'attn':
+        out[f'{l.name}.norm.weight'] = (l.cin,)
+        out[f'{l.name}.norm.bias'] = (l.cin,)
+        for c in ('q', 'k', 'v', 'proj_out'):
+            out[f'{l.name}.{c}.weight'] = (l.cin, l.cin, 1, 1)
+            out[f'{l.name}.{c}.bias'] = (l.cin,)
+
+
+def stage1_encoder_param_shapes(s: Stage1Spec) -> 'OrderedDict[str, Tuple[int, ...]]':
+    """Tensors the encode side adds (generator.py:298-310): the Encoder and quant_conv_b (the codebooks are shared with
+    decode_code).  In a reference state_dict these keys precede the decoder's; order here is execution order."""
+    out: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
+    for l in encoder_plan(s):
+        if l.kind == 'in':
+            ks = 4 if s.use_init_downsample else 3           # layers.py:212-216
+            out['encoder.conv_in.weight'] = (l.cout, 3, ks, ks)
+            out['encoder.conv_in.bias'] = (l.cout,)
+        elif l.kind == 'down':
+            out[f'{l.name}.weight'] = (l.cout, l.cin, 3, 3)
+            out[f'{l.name}.bias'] = (l.cout,)
+        elif l.kind == 'out':
+            out['encoder.norm_out.weight'] = (l.cin,)
+            out['encoder.norm_out.bias'] = (l.cin,)
+            out['encoder.conv_out.weight'] = (l.cout, l.cin, 3, 3)
+            out['encoder.conv_out.bias'] = (l.cout,)
+        else:
+            _layer_shapes(l, out)
+    out['quant_conv_b.weight'] = (s.embed_dim, s.z_channels, 1, 1)
+    out['quant_conv_b.bias'] = (s.embed_dim,)
+    return out
+
+
+def stage1_is_encoder_key(key: str) -> bool:
+    return key.startswith('encoder.') or key.startswith('quant_conv_b.')
+
+
 def stage1_is_ignored(key: str) -> bool:
-    """Checkpoint keys of the encode/training side (not on the path) that ``load_state_dict`` tolerates."""
-    return (key.startswith('encoder.') or key.startswith('quant_conv_b.') or key.endswith('.cluster_size')
-            or key.endswith('.embedding_avg'))
+    """Checkpoint keys of the training side (EMA statistics of the quantisers) that ``load_state_dict`` tolerates."""
+    return key.endswith('.cluster_size') or key.endswith('.embedding_avg')
 
 
 def work_per_image(s2: Stage2Spec, s1: Stage1Spec, n_pos: int) -> Dict[str, float]:

@@ -14,7 +14,7 @@ from typing import Dict, Tuple
 
 import numpy as np
 
-from .spec import Stage1Spec, Stage2Spec, stage1_param_shapes, stage2_param_shapes
+from .spec import Stage1Spec, Stage2Spec, stage1_encoder_param_shapes, stage1_param_shapes, stage2_param_shapes
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:
@@ -66,8 +66,13 @@ def stage2_weights(spec: Stage2Spec, seed: int = 0, profile: str = 'bench') -> '
     return OrderedDict((n, _stage2_tensor(n, s, seed, profile)) for n, s in stage2_param_shapes(spec).items())
 
 
-def stage1_weights(spec: Stage1Spec, seed: int = 0, profile: str = 'bench') -> 'OrderedDict[str, np.ndarray]':
-    return OrderedDict((n, _stage1_tensor(n, s, seed, profile)) for n, s in stage1_param_shapes(spec).items())
+def stage1_weights(spec: Stage1Spec, seed: int = 0, profile: str = 'bench', encoder: bool = False) -> 'OrderedDict[str, np.ndarray]':
+    """Decode-side tensors; ``encoder=True`` adds the Encoder and quant_conv_b (tensors are keyed by name, so the decode-side
+    values do not depend on the flag)."""
+    shapes = OrderedDict(stage1_param_shapes(spec))
+    if encoder:
+        shapes.update(stage1_encoder_param_shapes(spec))
+    return OrderedDict((n, _stage1_tensor(n, s, seed, profile)) for n, s in shapes.items())
 
 
 def exp_noise(seed: int, n_steps: int, batch: int, vocab: int) -> np.ndarray:

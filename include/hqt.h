@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HQT_ABI_VERSION 2
+#define HQT_ABI_VERSION 3
 
 typedef enum {
     HQT_OK = 0,
@@ -162,6 +162,34 @@ int hqt_decode_l3(hqt_handle* h, int B, const int64_t* code_t, const int64_t* co
                   int clamp01, int precision, void* stream);
 int hqt_decode_seq_l3(hqt_handle* h, int B, const int64_t* codes0, const int64_t* codes1, const int64_t* codes2, float* out_pixels,
                       int clamp01, int precision, void* stream);
+
+/* hqt_encode -- replaces SimRQGAN2Generator.encode / get_codes (generator.py:298-310, 369-370) and, on a three-level
+ * handle, HQVAEGenerator.encode (generator.py:530-568): Encoder.forward (stage1/modules/layers.py:270-297), quant_conv_b,
+ * then per level coarse -> fine: PixelUnshuffle of (h - reconstruction so far), nearest code
+ * argmin(|z|^2 + |e|^2 - 2 z.e) (quantizer.py:91-103), reconstruction += PixelShuffle(z + (e - z)).
+ * Needs the encoder tensors (stage1.encoder.*, stage1.quant_conv_b.*) to have been set before hqt_finalize_weights;
+ * without them the call fails with HQT_ERR_STATE.
+ *   pixels   fp32 [B, 3, R, R] NCHW (device)
+ * Level index l runs coarse -> fine (two levels: 0 = top, 1 = bottom); r_l = r >> (levels - 1 - l),
+ * dim_l = embed_dim * 4^(levels - 1 - l).  Every pointer of hqt_encode_out except codes[] may be NULL.
+ *   codes[l]  int64 [B, r_l, r_l]                 (the reference returns them flattened)
+ *   quant[l]  fp32 [B, dim_l, r_l, r_l]           the straight-through quantised tensor of level l (quant_t / quant_b)
+ *   resid[l]  fp32 [B, dim_l, r_l, r_l]           the quantiser's input of level l (resid[1] of a two-level model is
+ *                                                 the reference's code[2] = h_b)
+ *   recon     fp32 [B, embed_dim, r, r]           sum of all levels in the bottom layout (HQVAEGenerator: recons[-1])
+ *   diff      fp32 [levels]                       0.25 * mean((e - z)^2) per level (quantizer.py:130)
+ * EXACT computes every convolution and the distance GEMM in fp32; FAST in bf16 MFMA with fp32 accumulation
+ * (near-tied codes may then differ from the fp32 choice). */
+typedef struct {
+    int64_t* codes[3];
+    float* quant[3];
+    float* resid[3];
+    float* recon;
+    float* diff;
+} hqt_encode_out;
+int hqt_encode(hqt_handle* h, int B, const float* pixels, int precision, const hqt_encode_out* out, void* stream);
+/* 1 when the handle holds the encoder tensors (hqt_encode is usable), else 0; -1 on a NULL handle */
+int hqt_has_encoder(const hqt_handle* h);
 
 /* hqt_decode -- replaces SimRQGAN2Generator.decode_code (generator.py:323-367: codebook lookup
  * quantizer.py:179-186, PixelShuffle, concat, post_quant_conv_b, Decoder.forward layers.py:385-410).

@@ -309,6 +309,42 @@ def conv2d(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
     return (y + b[None, :, None, None]).astype(F32)
 
 
+def conv2d_strided(x: np.ndarray, w: np.ndarray, b: np.ndarray, stride: int, pad: Tuple[int, int, int, int]) -> np.ndarray:
+    """nn.Conv2d with a stride and explicit zero padding (top, bottom, left, right): the encoder's conv_in (4x4, stride 2,
+    padding 1 -- stage1/modules/layers.py:212-216) and Downsample (pad right / bottom by one, 3x3, stride 2, padding 0 --
+    stage1/modules/layers.py:56-72)."""
+    B, C, H, W = x.shape
+    O, _, kh, kw = w.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (pad[0], pad[1]), (pad[2], pad[3])))
+    Ho = (xp.shape[2] - kh) // stride + 1
+    Wo = (xp.shape[3] - kw) // stride + 1
+    cols = np.empty((B, C, kh * kw, Ho, Wo), F32)
+    for dy in range(kh):
+        for dx in range(kw):
+            cols[:, :, dy * kw + dx] = xp[:, :, dy:dy + stride * Ho:stride, dx:dx + stride * Wo:stride]
+    y = (w.reshape(O, C * kh * kw) @ cols.reshape(B, C * kh * kw, Ho * Wo)).reshape(B, O, Ho, Wo)
+    return (y + b[None, :, None, None]).astype(F32)
+
+
+def pixel_unshuffle2(x: np.ndarray) -> np.ndarray:
+    """nn.PixelUnshuffle(2): out[4c + 2i + j, h, w] = in[c, 2h + i, 2w + j] (generator.py:228)."""
+    B, C, H, W = x.shape
+    return x.reshape(B, C, H // 2, 2, W // 2, 2).transpose(0, 1, 3, 5, 2, 4).reshape(B, C * 4, H // 2, W // 2)
+
+
+def nearest_code(z: np.ndarray, emb: np.ndarray):
+    """EMAVectorQuantizer.forward in eval mode (quantizer.py:91-133): z [B, C, H, W] -> (z + (e - z) [B, C, H, W], diff, codes [B*H*W]).
+    d = |z|^2 + |e|^2 - 2 z.e in fp32 with the reference's association; argmin takes the first minimum."""
+    B, C, H, W = z.shape
+    zf = np.ascontiguousarray(z.transpose(0, 2, 3, 1)).reshape(-1, C).astype(F32)
+    d = ((zf ** 2).sum(1, keepdims=True, dtype=F32) + (emb ** 2).sum(1, dtype=F32)[None, :]).astype(F32) - F32(2.0) * (zf @ emb.T).astype(F32)
+    codes = np.argmin(d, axis=1)
+    zq = emb[codes]
+    diff = F32(0.25) * np.mean((zq - zf) ** 2, dtype=F32)
+    st = (zf + (zq - zf)).astype(F32)                                       # quantizer.py:131
+    return np.ascontiguousarray(st.reshape(B, H, W, C).transpose(0, 3, 1, 2)), F32(diff), codes.astype(np.int64)
+
+
 def group_norm(x: np.ndarray, g: np.ndarray, b: np.ndarray, groups: int = 32, eps: float = 1e-6) -> np.ndarray:
     """GroupNorm(32, eps=1e-6, affine) -- stage1/modules/layers.py:17-21; stats per (sample, group)."""
     B, C, H, W = x.shape
@@ -387,6 +423,68 @@ class OracleStage1:
                 res *= 2
         h = swish(self._gn('decoder.norm_out', h))
         return self._conv('decoder.conv_out', h)
+
+    def encoder(self, x: np.ndarray) -> np.ndarray:
+        """Encoder.forward (stage1/modules/layers.py:270-297).  The attention test uses the reference's own `curr_res`, which
+        starts at `resolution` even when conv_in halves the image (layers.py:221)."""
+        s = self.s
+        n = len(s.ch_mult)
+        w = self.w
+        if s.use_init_downsample:
+            h = conv2d_strided(x, w['encoder.conv_in.weight'], w['encoder.conv_in.bias'], 2, (1, 1, 1, 1))
+        else:
+            h = self._conv('encoder.conv_in', x)
+        label = s.resolution
+        for lvl in range(n):
+            for blk in range(s.num_res_blocks):
+                h = self._resblock(f'encoder.down.{lvl}.block.{blk}', h)
+                if label in s.attn_resolutions and s.use_attn:
+                    h = self._attnblock(f'encoder.down.{lvl}.attn.{blk}', h)
+            if lvl != n - 1:
+                name = f'encoder.down.{lvl}.downsample.conv'
+                h = conv2d_strided(h, w[f'{name}.weight'], w[f'{name}.bias'], 2, (0, 1, 0, 1))
+                label //= 2
+        if s.use_mid_block:
+            h = self._resblock('encoder.mid.block_1', h)
+            if s.use_attn:
+                h = self._attnblock('encoder.mid.attn_1', h)
+            h = self._resblock('encoder.mid.block_2', h)
+        h = swish(self._gn('encoder.norm_out', h))
+        return self._conv('encoder.conv_out', h)
+
+    def encode(self, x: np.ndarray) -> Dict[str, object]:
+        """SimRQGAN2Generator.encode (generator.py:298-310) or, with three code levels, HQVAEGenerator.encode
+        (generator.py:530-568).  Returns codes / quant / resid / diff per level (coarse -> fine), `h` = quant_conv_b(encoder(x))
+        and `recon` = the summed reconstruction at the bottom resolution."""
+        w, s = self.w, self.s
+        h = self._conv('quant_conv_b', self.encoder(x))
+        out: Dict[str, object] = {'h': h, 'codes': [], 'quant': [], 'resid': [], 'diff': []}
+        if s.code_levels == 3:
+            h_map = [h]
+            for _ in range(2):
+                h_map.insert(0, pixel_unshuffle2(h_map[0]))
+            recon = None
+            for qi in range(3):
+                resid = h_map[qi] if recon is None else (h_map[qi] - recon).astype(F32)
+                q, diff, code = nearest_code(resid, w[f'quantizers.{qi}.embedding'])
+                recon = q if recon is None else (q + recon).astype(F32)
+                if qi < 2:
+                    recon = pixel_shuffle2(recon)
+                B, _, H, W = resid.shape
+                out['codes'].append(code.reshape(B, H, W)); out['quant'].append(q); out['resid'].append(resid); out['diff'].append(diff)
+            out['recon'] = recon
+            return out
+        h_t = pixel_unshuffle2(h)
+        q_t, diff_t, code_t = nearest_code(h_t, w['quantize_t.embedding'])
+        h_b = (h - pixel_shuffle2(q_t)).astype(F32)
+        q_b, diff_b, code_b = nearest_code(h_b, w['quantize_b.embedding'])
+        B = x.shape[0]
+        out['codes'] = [code_t.reshape(B, *h_t.shape[2:]), code_b.reshape(B, *h_b.shape[2:])]
+        out['quant'] = [q_t, q_b]
+        out['resid'] = [h_t, h_b]
+        out['diff'] = [diff_t, diff_b]
+        out['recon'] = (q_b + pixel_shuffle2(q_t)).astype(F32)
+        return out
 
     def decode_codes3(self, codes: Sequence[Optional[np.ndarray]]) -> np.ndarray:
         """HQVAEGenerator.decode_code (generator.py:577-599): codes = [top [B, r/4, r/4], mid [B, r/2, r/2], bottom [B, r, r]]

@@ -464,3 +464,120 @@ def test_l3_decode_vs_reference_fixture():
     fast = np_(eng.decode3([ct, cm, cb], precision=PRECISION_FAST))
     d = np.abs(fast - fx['pixels'])
     assert d.max() <= 0.1 and d.mean() <= 1e-2
+
+
+# --------------------------------------------------------------------------------------------- HQ-VAE encode side (hqt_encode)
+def _synth_images(seed, B, R):
+    r = np.random.default_rng([seed, 78])
+    yy, xx = np.meshgrid(np.linspace(0, 1, R, dtype=np.float32), np.linspace(0, 1, R, dtype=np.float32), indexing='ij')
+    img = np.zeros((B, 3, R, R), np.float32)
+    for b in range(B):
+        for c in range(3):
+            for _ in range(4):
+                fx_, fy_, ph = r.uniform(0.5, 6.0), r.uniform(0.5, 6.0), r.uniform(0, 2 * np.pi)
+                img[b, c] += r.uniform(0.1, 0.4) * np.sin(2 * np.pi * (fx_ * xx + fy_ * yy) + ph).astype(np.float32)
+    return np.clip(img + 0.05 * r.standard_normal(img.shape).astype(np.float32), -1.0, 1.0).astype(np.float32)
+
+
+def _excess_distance(resid, emb, codes):
+    """float64 d(z, e[code]) - min_n d(z, e[n]) per row: 0 where the code is the nearest one."""
+    z = np.ascontiguousarray(resid.transpose(0, 2, 3, 1)).reshape(-1, resid.shape[1]).astype(np.float64)
+    e = emb.astype(np.float64)
+    d = (z ** 2).sum(1, keepdims=True) + (e ** 2).sum(1)[None] - 2 * z @ e.T
+    return d[np.arange(len(z)), codes.reshape(-1)] - d.min(1)
+
+
+def _codebooks(spec, weights):
+    if spec.code_levels == 3:
+        return [weights[f'quantizers.{l}.embedding'] for l in range(3)]
+    return [weights['quantize_t.embedding'], weights['quantize_b.embedding']]
+
+
+@pytest.mark.parametrize('name', ['g9_encode_64.npz', 'g9_encode_64_noinit.npz', 'g9_encode_64_l3.npz'])
+def test_encode_exact_vs_reference_fixture(name):
+    """hqt_encode in EXACT precision against the reference's own encode (tools/gen_golden_enc.py): bit-identical codes at every
+    level (the fixtures sit >= 4e-4 from any argmin tie), quantiser inputs / straight-through outputs / reconstruction within
+    1e-4, commitment terms within 1e-4 relative.  Covers the 4x4 stride-2 and the 3x3 conv_in, Downsample's one-sided padding,
+    attention inside a `down` level, two and three code levels."""
+    fx = load(name)
+    spec = Stage1Spec(**json.loads(str(fx['spec'])))
+    weights = synth.stage1_weights(spec, int(fx['weight_seed']), 'fixture', encoder=True)
+    eng = engine_s1(spec, weights, int(fx['B']))
+    assert eng.has_encoder
+    L = 3 if spec.code_levels == 3 else 2
+    o = eng.encode(torch.from_numpy(fx['pixels']), precision=PRECISION_EXACT, want_quant=True, want_resid=True, want_recon=True, want_diff=True)
+    for l in range(L):
+        assert np.abs(np_(o['resid'][l]) - fx[f'resid_{l}']).max() <= PIXEL_TOL, l
+        assert np.array_equal(np_(o['codes'][l]).reshape(-1), fx[f'code_{l}'].reshape(-1)), l
+        assert abs(float(o['diff'][l]) - float(fx[f'diff_{l}'])) <= 1e-4 * float(fx[f'diff_{l}']), l
+        if f'quant_{l}' in fx:
+            assert np.abs(np_(o['quant'][l]) - fx[f'quant_{l}']).max() <= PIXEL_TOL, l
+    if 'recon' in fx:
+        assert np.abs(np_(o['recon']) - fx['recon']).max() <= PIXEL_TOL
+    # decode(encode(x)) = the reference's forward() in eval mode
+    if L == 3:
+        rec = eng.decode3(o['codes'], precision=PRECISION_EXACT)
+    else:
+        rec = eng.decode(o['codes'][0], o['codes'][1], precision=PRECISION_EXACT)
+    assert np.abs(np_(rec) - fx['reconstruction']).max() <= PIXEL_TOL
+    # a decode-only handle refuses to encode, loudly
+    dec_only = engine_s1(spec, synth.stage1_weights(spec, int(fx['weight_seed']), 'fixture'), 1)
+    assert not dec_only.has_encoder
+    with pytest.raises(Exception, match='encoder'):
+        dec_only.encode(torch.from_numpy(fx['pixels'][:1]))
+
+
+def test_encode_wide_config_exact_and_fast_vs_oracle():
+    """A config wide enough for the MFMA kernels (64..128 channels; HQT_FORCE_TILE128 makes the dispatcher pick the LDS-DMA kernel
+    with its stride-2 taps for Downsample).  EXACT: codes equal the oracle's except where the oracle's own float64 distance gap is
+    within 1e-4 (argmin ties under a different fp32 summation order), feature map within 1e-4.  FAST (bf16 convolutions and
+    distance GEMM): every chosen code is within 2 % of the best squared distance for the device's own quantiser input, the
+    feature map within 0.15 (2 % of its range) of the fp32 one, >= 60 % of the codes identical to the fp32 choice."""
+    import os
+    spec = Stage1Spec(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=64, z_channels=64,
+                      embed_dim=32, n_embed=256)
+    weights = synth.stage1_weights(spec, 81, 'fixture', encoder=True)
+    x = _synth_images(82, 5, 64)
+    want = O.OracleStage1(spec, weights).encode(x)
+    cbs = _codebooks(spec, weights)
+    os.environ['HQT_FORCE_TILE128'] = '1'
+    try:
+        eng = engine_s1(spec, weights, 5)
+        ex = eng.encode(torch.from_numpy(x), precision=PRECISION_EXACT, want_resid=True)
+        fa = eng.encode(torch.from_numpy(x), precision=PRECISION_FAST, want_resid=True)
+    finally:
+        del os.environ['HQT_FORCE_TILE128']
+    assert np.abs(np_(ex['resid'][0]) - want['resid'][0]).max() <= PIXEL_TOL
+    for l in range(2):
+        got = np_(ex['codes'][l])
+        bad = got != want['codes'][l]
+        if bad.any():                           # only allowed at ties of the oracle's own distances
+            assert l == 0 and _excess_distance(want['resid'][l], cbs[l], got)[bad.reshape(-1)].max() <= 1e-4
+    for l in range(2):
+        resid, codes = np_(fa['resid'][l]), np_(fa['codes'][l])
+        exc = _excess_distance(resid, cbs[l], codes)
+        z = resid.transpose(0, 2, 3, 1).reshape(-1, resid.shape[1]).astype(np.float64)
+        best = ((z[:, None, :] - cbs[l][None].astype(np.float64)) ** 2).sum(-1).min(1) if len(z) * len(cbs[l]) * z.shape[1] < 5e7 else None
+        if best is not None:
+            assert (exc <= 0.02 * best + 1e-3).all(), (l, float((exc / best).max()))
+    assert np.abs(np_(fa['resid'][0]) - want['resid'][0]).max() <= 0.15
+    agree = np.mean(np_(fa['codes'][0]) == want['codes'][0])
+    assert agree >= 0.6, agree
+
+
+def test_encode_batch_chunking_is_batch_invariant():
+    """More images than one conv-stack chunk (64): codes of image i do not depend on its position in the batch, EXACT and FAST."""
+    fx = load('g9_encode_64.npz')
+    spec = Stage1Spec(**json.loads(str(fx['spec'])))
+    weights = synth.stage1_weights(spec, int(fx['weight_seed']), 'fixture', encoder=True)
+    x = np.concatenate([_synth_images(91, 67, 64), fx['pixels']])
+    eng = engine_s1(spec, weights, 70)
+    small = engine_s1(spec, weights, 3)
+    for prec in (PRECISION_EXACT, PRECISION_FAST):
+        big = eng.encode(torch.from_numpy(x), precision=prec)
+        ref = small.encode(torch.from_numpy(x[67:]), precision=prec)
+        for l in range(2):
+            assert np.array_equal(np_(big['codes'][l])[67:], np_(ref['codes'][l])), (prec, l)
+    assert np.array_equal(np_(big['codes'][0])[67:].reshape(-1), np_(ref['codes'][0]).reshape(-1))
+    exact = eng.encode(torch.from_numpy(x), precision=PRECISION_EXACT)
+    assert np.array_equal(np_(exact['codes'][1])[67:].reshape(-1), fx['code_1'].reshape(-1))

@@ -86,7 +86,7 @@ def test_model_surface_and_state_dict_contract():
     assert all(k.startswith(('stage1.', 'stage2.')) for k in sd)
     model.load_state_dict(sd, strict=True)
     extra = dict(sd)
-    extra['stage1.encoder.conv_in.weight'] = torch.zeros(1)                  # encode-side tensors are tolerated
+    assert 'stage1.encoder.conv_in.weight' in sd and 'stage1.quant_conv_b.weight' in sd   # the encode side is part of the model
     extra['stage1.quantize_t.cluster_size'] = torch.zeros(1)
     model.load_state_dict(extra, strict=True)
     bad = dict(sd)

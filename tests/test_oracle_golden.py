@@ -187,3 +187,38 @@ def test_l3_decode_pixels():
     assert np.abs(orc.decode_codes3([fx['code_t'], fx['code_m'], fx['code_b']]) - fx['pixels']).max() <= 1e-4
     assert np.abs(orc.decode_codes3([fx['code_t'][:1], None, None]) - fx['pixels_top_only']).max() <= 1e-4
     assert np.abs(orc.decode_codes3([None, None, fx['code_b'][:1]]) - fx['pixels_bot_only']).max() <= 1e-4
+
+
+ENCODE_FIXTURES = ('g9_encode_64.npz', 'g9_encode_64_noinit.npz', 'g9_encode_64_l3.npz')
+
+
+@pytest.mark.parametrize('name', ENCODE_FIXTURES)
+def test_encode_side_vs_reference(name):
+    """G9: SimRQGAN2Generator.encode / HQVAEGenerator.encode run by the reference itself (tools/gen_golden_enc.py): the encoder's
+    feature map within 1e-4, then -- the fixtures sit >= 4e-4 away from any argmin tie -- bit-identical codes at every level,
+    quantiser inputs and straight-through outputs within 1e-4, the commitment terms within 1e-5 relative."""
+    from hqtransformer_amd.spec import Stage1Spec, stage1_encoder_param_shapes
+    from oracle.hqt_oracle import OracleStage1
+    fx = load(name)
+    spec = Stage1Spec(**json.loads(str(fx['spec'])))
+    want_shapes = dict(stage1_encoder_param_shapes(spec))
+    want_shapes.update(stage1_param_shapes(spec))
+    assert {k: tuple(v) for k, v in json.loads(str(fx['param_shapes'])).items()} == want_shapes
+    orc = OracleStage1(spec, synth.stage1_weights(spec, int(fx['weight_seed']), 'fixture', encoder=True))
+    x = fx['pixels']
+    assert np.abs(orc.encoder(x[:1])[0] - fx['encoder_out'][0]).max() <= 1e-4
+    out = orc.encode(x)
+    assert np.abs(out['h'] - fx['h']).max() <= 1e-4
+    L = 3 if spec.code_levels == 3 else 2
+    assert float(fx['margins'].min()) > 1e-4
+    for l in range(L):
+        assert np.array_equal(out['codes'][l].reshape(-1), fx[f'code_{l}'].reshape(-1)), l
+        assert np.abs(out['resid'][l] - fx[f'resid_{l}']).max() <= 1e-4
+        assert abs(float(out['diff'][l]) - float(fx[f'diff_{l}'])) <= 1e-5 * abs(float(fx[f'diff_{l}'])) + 1e-7
+        if f'quant_{l}' in fx:
+            assert np.abs(out['quant'][l] - fx[f'quant_{l}']).max() <= 1e-4
+    if 'recon' in fx:
+        assert np.abs(out['recon'] - fx['recon']).max() <= 1e-4
+    # decode(encode(x)) closes the loop through the decode-side oracle
+    rec = orc.decode_codes3(out['codes']) if L == 3 else orc.decode_code(out['codes'][0], out['codes'][1])
+    assert np.abs(rec - fx['reconstruction']).max() <= 1e-4

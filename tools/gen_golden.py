@@ -42,7 +42,12 @@ from hqvae.models.stage1.generator import SimRQGAN2Generator  # noqa: E402
 from hqvae.utils import sampling as ref_sampling  # noqa: E402
 
 from hqtransformer_amd import synth  # noqa: E402
-from hqtransformer_amd.spec import (Stage1Spec, Stage2Spec, stage1_is_ignored)  # noqa: E402
+from hqtransformer_amd.spec import (Stage1Spec, Stage2Spec, stage1_is_ignored as _s1_ign, stage1_is_encoder_key)  # noqa: E402
+
+
+def stage1_is_ignored(k):          # decode-side fixtures: the encoder tensors keep the reference's own initialisation
+    return _s1_ign(k) or stage1_is_encoder_key(k)
+
 
 torch.Tensor.cuda = lambda self, *a, **k: self
 torch.set_grad_enabled(False)
