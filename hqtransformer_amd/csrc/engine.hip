@@ -105,7 +105,7 @@ struct hqt_handle {
     std::vector<DecLayer> enc;               // Encoder.forward in execution order (kinds 6 conv_in, 1, 2, 5 Downsample, 7 norm_out + conv_out)
     bool has_encoder = false;                 // the encoder tensors were set before finalize: hqt_encode is usable
     Lin post_quant, quant_conv;
-    struct { bf16_t* w16 = nullptr; float* norm32 = nullptr; float* norm16 = nullptr; } cb[3];   // codebooks as distance-GEMM operands
+    float* cb_norm[3] = {nullptr, nullptr, nullptr};   // |e_n|^2 of each codebook (distance GEMM epilogue)
     float *vq_h = nullptr, *vq_recon = nullptr, *vq_zz = nullptr, *vq_err = nullptr;
     void* vq_z = nullptr;
     unsigned long long* vq_best = nullptr;
@@ -595,13 +595,8 @@ static int load_encoder(hqt_handle* h) {
         const std::string name = L == 3 ? "stage1.quantizers." + std::to_string(l) + ".embedding"
                                         : (l == 0 ? "stage1.quantize_t.embedding" : "stage1.quantize_b.embedding");
         const float* e = h->w[name].d;
-        const size_t n = (size_t)c.s1_n_embed * dim;
-        CHK(dev_alloc(h, (void**)&h->cb[l].w16, n * 2, false));
-        CHK(dev_alloc(h, (void**)&h->cb[l].norm32, (size_t)c.s1_n_embed * 4, false));
-        CHK(dev_alloc(h, (void**)&h->cb[l].norm16, (size_t)c.s1_n_embed * 4, false));
-        HIPCHK(launch_f32_to_bf16(e, h->cb[l].w16, n, 0));
-        HIPCHK(launch_row_sumsq(e, DT_F32, h->cb[l].norm32, c.s1_n_embed, dim, 0));
-        HIPCHK(launch_row_sumsq(h->cb[l].w16, DT_BF16, h->cb[l].norm16, c.s1_n_embed, dim, 0));
+        CHK(dev_alloc(h, (void**)&h->cb_norm[l], (size_t)c.s1_n_embed * 4, false));
+        HIPCHK(launch_row_sumsq(e, DT_F32, h->cb_norm[l], c.s1_n_embed, dim, 0));
     }
     h->has_encoder = true;
     return alloc_encode_workspace(h);
@@ -1464,7 +1459,7 @@ extern "C" int hqt_encode(hqt_handle* h, int B, const float* pixels, int precisi
         VqArgs a{};
         a.h = h->vq_h; a.recon = l == 0 ? nullptr : h->vq_recon;
         a.B = B; a.r = r; a.E = E; a.k = k;
-        a.z = h->vq_z; a.z_dtype = md.act_dt(); a.zz = h->vq_zz; a.resid_nchw = out->resid[l];
+        a.z = h->vq_z; a.z_dtype = DT_F32; a.zz = h->vq_zz; a.resid_nchw = out->resid[l];
         a.best = h->vq_best; a.emb = W1(h, name); a.codes = out->codes[l]; a.quant_nchw = out->quant[l];
         a.err_rows = h->vq_err + (size_t)l * cf.max_batch * r * r;
         { Timed t(h, "vq_rows", st); HIPCHK(launch_vq_rows(a, st)); }
@@ -1474,14 +1469,11 @@ extern "C" int hqt_encode(hqt_handle* h, int B, const float* pixels, int precisi
             GemmArgs g{};
             g.A = h->vq_z; g.lda = dim; g.M = M; g.N = cf.s1_n_embed; g.K = dim; g.batch = 1; g.ldb = dim; g.alpha = 1.0f;
             g.store = STORE_ARGMIN; g.am_rownorm = h->vq_zz; g.am_best = h->vq_best; g.zero_page = h->zero_page;
-            if (md.fast) {
-                g.Bw = h->cb[l].w16; g.am_colnorm = h->cb[l].norm16;
-                if (mfma_gemm_ok(g, DT_BF16, DT_BF16, DT_F32)) HIPCHK(launch_mfma_gemm(g, DT_BF16, DT_BF16, DT_F32, st));
-                else HIPCHK(launch_gemm_generic(g, DT_BF16, DT_BF16, DT_F32, st));
-            } else {
-                g.Bw = a.emb; g.am_colnorm = h->cb[l].norm32;
-                HIPCHK(launch_gemm_generic(g, DT_F32, DT_F32, DT_F32, st));
-            }
+            // fp32 in both precisions: h leaves quant_conv_b in fp32 either way, the fp32 vector-ALU GEMM runs these two shapes at
+            // ~70 TFLOP/s (1.8 ms of a 8 ms FAST encode at batch 64), and the codes then are the exact nearest ones of the
+            // device's own feature map instead of a bf16 approximation of them
+            g.Bw = a.emb; g.am_colnorm = h->cb_norm[l];
+            HIPCHK(launch_gemm_generic(g, DT_F32, DT_F32, DT_F32, st));
         }
         if (l == 0) {                       // the running reconstruction starts at zero; level 0 reads h alone (generator.py:300-301)
             HIPCHK(hipMemsetAsync(h->vq_recon, 0, elems * 4, st));

@@ -178,8 +178,9 @@ int hqt_decode_seq_l3(hqt_handle* h, int B, const int64_t* codes0, const int64_t
  *                                                 the reference's code[2] = h_b)
  *   recon     fp32 [B, embed_dim, r, r]           sum of all levels in the bottom layout (HQVAEGenerator: recons[-1])
  *   diff      fp32 [levels]                       0.25 * mean((e - z)^2) per level (quantizer.py:130)
- * EXACT computes every convolution and the distance GEMM in fp32; FAST in bf16 MFMA with fp32 accumulation
- * (near-tied codes may then differ from the fp32 choice). */
+ * EXACT computes every convolution in fp32; FAST runs the convolutions in bf16 MFMA with fp32 accumulation.  The distance
+ * GEMM and the argmin are fp32 in both, so the codes are always the exact nearest ones of the feature map the handle
+ * computed (under FAST that map, and hence some codes, differ slightly from the fp32 one). */
 typedef struct {
     int64_t* codes[3];
     float* quant[3];

@@ -530,8 +530,8 @@ def test_encode_exact_vs_reference_fixture(name):
 def test_encode_wide_config_exact_and_fast_vs_oracle():
     """A config wide enough for the MFMA kernels (64..128 channels; HQT_FORCE_TILE128 makes the dispatcher pick the LDS-DMA kernel
     with its stride-2 taps for Downsample).  EXACT: codes equal the oracle's except where the oracle's own float64 distance gap is
-    within 1e-4 (argmin ties under a different fp32 summation order), feature map within 1e-4.  FAST (bf16 convolutions and
-    distance GEMM): every chosen code is within 2 % of the best squared distance for the device's own quantiser input, the
+    within 1e-4 (argmin ties under a different fp32 summation order), feature map within 1e-4.  FAST (bf16 convolutions,
+    fp32 distance GEMM): every chosen code is the nearest one for the device's own quantiser input (up to 1e-4 ties), the
     feature map within 0.15 (2 % of its range) of the fp32 one, >= 60 % of the codes identical to the fp32 choice."""
     import os
     spec = Stage1Spec(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=64, z_channels=64,
@@ -555,11 +555,7 @@ def test_encode_wide_config_exact_and_fast_vs_oracle():
             assert l == 0 and _excess_distance(want['resid'][l], cbs[l], got)[bad.reshape(-1)].max() <= 1e-4
     for l in range(2):
         resid, codes = np_(fa['resid'][l]), np_(fa['codes'][l])
-        exc = _excess_distance(resid, cbs[l], codes)
-        z = resid.transpose(0, 2, 3, 1).reshape(-1, resid.shape[1]).astype(np.float64)
-        best = ((z[:, None, :] - cbs[l][None].astype(np.float64)) ** 2).sum(-1).min(1) if len(z) * len(cbs[l]) * z.shape[1] < 5e7 else None
-        if best is not None:
-            assert (exc <= 0.02 * best + 1e-3).all(), (l, float((exc / best).max()))
+        assert _excess_distance(resid, cbs[l], codes).max() <= 1e-4, l
     assert np.abs(np_(fa['resid'][0]) - want['resid'][0]).max() <= 0.15
     agree = np.mean(np_(fa['codes'][0]) == want['codes'][0])
     assert agree >= 0.6, agree

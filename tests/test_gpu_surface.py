@@ -168,3 +168,40 @@ def test_three_level_surface_matches_the_oracle(tmp_path, capsys):
              '--top-k', '100', '--top-resolution', '4'])
     pxs = pickle.load(open(tmp_path / 'samples_(1_0).pkl', 'rb'))
     assert pxs.dtype == np.float32 and pxs.shape == (2, 3, 64, 64) and pxs.min() >= 0 and pxs.max() <= 1
+
+
+def test_encode_surface_matches_the_oracle(model):
+    """``stage1.encode`` / ``get_codes`` / ``forward`` with the reference's return shapes (generator.py:298-310, 369-370, 262-280),
+    against the CPU oracle built from the same state dict.  tiny-cls uses 'bench'-profile weights, so a code may sit on an fp32
+    argmin tie: mismatches are accepted only where the oracle's own float64 distance gap is below 1e-4."""
+    s1 = model.stage1.spec
+    w1 = {k: v.numpy() for k, v in model.stage1.state_dict().items()}
+    r = np.random.default_rng(3)
+    x = np.clip(0.5 * r.standard_normal((2, 3, s1.resolution, s1.resolution)), -1, 1).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    quant_t, quant_b, diff_t, diff_b, (code_t, code_b, h_b) = model.stage1.encode(xt)
+    rz = s1.z_res
+    assert tuple(quant_t.shape) == (2, 4 * s1.embed_dim, rz // 2, rz // 2) and tuple(quant_b.shape) == (2, s1.embed_dim, rz, rz)
+    assert tuple(code_t.shape) == (2 * (rz // 2) ** 2,) and tuple(code_b.shape) == (2 * rz * rz,) and code_t.dtype == torch.int64
+    assert tuple(h_b.shape) == (2, s1.embed_dim, rz, rz) and diff_t.ndim == 0
+    want = O.OracleStage1(s1, w1).encode(x)
+    assert np.abs(h_b.cpu().numpy() - want['resid'][1]).max() <= 1e-4 or not np.array_equal(code_t.cpu().numpy(), want['codes'][0].reshape(-1))
+    for got, l in ((code_t, 0), (code_b, 1)):
+        g = got.cpu().numpy()
+        bad = g != want['codes'][l].reshape(-1)
+        if l == 0 and bad.any():
+            z = want['resid'][0].transpose(0, 2, 3, 1).reshape(-1, want['resid'][0].shape[1]).astype(np.float64)
+            e = w1['quantize_t.embedding'].astype(np.float64)
+            d = (z ** 2).sum(1, keepdims=True) + (e ** 2).sum(1)[None] - 2 * z @ e.T
+            assert (d[np.arange(len(z)), g] - d.min(1))[bad].max() <= 1e-4
+        elif l == 1 and np.array_equal(code_t.cpu().numpy(), want['codes'][0].reshape(-1)):
+            assert bad.mean() <= 0.01
+    assert abs(float(diff_t) - float(want['diff'][0])) <= 1e-3 * float(want['diff'][0])
+    ct, cb = model.stage1.get_codes(xt)
+    assert torch.equal(ct, code_t) and torch.equal(cb, code_b)
+    rec = model.stage1(xt)                                     # decode(encode(x))
+    grids = model.stage1.code_grids(xt)
+    assert torch.equal(rec, model.stage1.decode_code(grids[0], grids[1]))
+    assert tuple(rec.shape) == (2, 3, s1.resolution, s1.resolution)
+    fast = model.stage1.get_codes(xt, precision='fast')
+    assert (fast[0] == ct).float().mean() >= 0.5
