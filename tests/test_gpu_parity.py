@@ -577,3 +577,36 @@ def test_encode_batch_chunking_is_batch_invariant():
     assert np.array_equal(np_(big['codes'][0])[67:].reshape(-1), np_(ref['codes'][0]).reshape(-1))
     exact = eng.encode(torch.from_numpy(x), precision=PRECISION_EXACT)
     assert np.array_equal(np_(exact['codes'][1])[67:].reshape(-1), fx['code_1'].reshape(-1))
+
+
+def test_encode_imagenet_geometry_vs_oracle():
+    """The released ImageNet stage-1 shape (256 x 256, ch 128, ch_mult [1, 2, 4, 4], 4x4 stride-2 conv_in, 8192 codes of 1024 / 256
+    dims) on 2 images: EXACT feature map within 2e-4 of the oracle and codes equal up to fp32 argmin ties (oracle's own float64
+    gap <= 1e-4); FAST (the halo / LDS-DMA MFMA kernels incl. the stride-2 Downsample taps on their real shapes): feature map
+    within 3 % of its range, codes the exact nearest ones for the device's own feature map, decode(encode(x)) finite."""
+    import os
+    from hqtransformer_amd.config import load_config
+    from hqtransformer_amd.spec import stage1_spec_from_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = stage1_spec_from_config(load_config(os.path.join(root, 'configs', 'imagenet-12l.yaml')))
+    assert spec.resolution == 256 and spec.n_embed == 8192
+    weights = synth.stage1_weights(spec, 95, 'fixture', encoder=True)
+    x = _synth_images(96, 2, 256)
+    want = O.OracleStage1(spec, weights).encode(x)
+    cbs = _codebooks(spec, weights)
+    eng = engine_s1(spec, weights, 2)
+    ex = eng.encode(torch.from_numpy(x), precision=PRECISION_EXACT, want_resid=True)
+    assert np.abs(np_(ex['resid'][0]) - want['resid'][0]).max() <= 2e-4
+    top_same = np.array_equal(np_(ex['codes'][0]), want['codes'][0])
+    for l in range(2):
+        got = np_(ex['codes'][l])
+        bad = (got != want['codes'][l]).reshape(-1)
+        if bad.any() and (l == 0 or top_same):
+            assert _excess_distance(want['resid'][l], cbs[l], got)[bad].max() <= 1e-4, l
+    fa = eng.encode(torch.from_numpy(x), precision=PRECISION_FAST, want_resid=True)
+    rng = float(np.abs(want['resid'][0]).max())
+    assert np.abs(np_(fa['resid'][0]) - want['resid'][0]).max() <= 0.03 * rng, (np.abs(np_(fa['resid'][0]) - want['resid'][0]).max(), rng)
+    for l in range(2):
+        assert _excess_distance(np_(fa['resid'][l]), cbs[l], np_(fa['codes'][l])).max() <= 1e-3, l
+    rec = eng.decode(fa['codes'][0], fa['codes'][1], precision=PRECISION_FAST)
+    assert bool(torch.isfinite(rec).all())
