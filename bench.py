@@ -207,7 +207,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kept = [pipe.submit(B, int(classes[args.warmup + k]), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
-                        sample_offset=rank * B, use_graph=not args.no_graph, after=after) for k in range(args.steps)]
+                        sample_offset=rank * B, use_graph=not args.no_graph, after=after,
+                        order_after_current=not os.environ.get('HQT_BENCH_NO_ORDER')) for k in range(args.steps)]
     pipe.drain()
     barrier()
     elapsed_lanes = time.perf_counter() - t0

@@ -165,6 +165,10 @@ struct GemmArgs {
     float* gn_part_out;
     int gn_out_groups;
     int tune;                // 0: latency-oriented tile choice, 1: throughput-oriented (hqt_set_policy)
+    // ---- in-kernel split-K of the streaming GEMM (gridDim.z = S > 1 with xs_ctr set): every workgroup publishes its fp32
+    //      partial tile to slab z with agent-scope stores, then bumps xs_ctr[tile]; the last arriver of a tile sums the S
+    //      partials in z order (deterministic), resets the counter and runs the fused epilogue.  No workgroup waits.
+    unsigned* xs_ctr;        // [gridDim.x * gridDim.y] zeros between launches
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

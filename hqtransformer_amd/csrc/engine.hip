@@ -94,6 +94,7 @@ struct hqt_handle {
     int nparts = 0, npartsd = 0;
     float* fold_tmp = nullptr;
     float* splitk = nullptr;                  // split-K partial slabs of the streaming GEMM
+    unsigned* xs_ctr = nullptr;               // arrival counters of the in-kernel split-K (zero between launches)
     size_t splitk_elems = 0;
     struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
     StepState* state = nullptr;
@@ -346,6 +347,8 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), &h->dv, dkv, true));
         h->splitk_elems = (size_t)16 * rows * (size_t)std::max<size_t>(4 * D, (size_t)c.vocab_top);
         CHK(dev_alloc(h.get(), (void**)&h->splitk, h->splitk_elems * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->xs_ctr, 4096 * 4, true));
+        HIPCHK(hipMemset(h->xs_ctr, 0, 4096 * 4));
         CHK(dev_alloc(h.get(), (void**)&h->state, sizeof(StepState), true));
         CHK(dev_alloc(h.get(), (void**)&h->cond_buf, B * (size_t)std::max(1, c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1) * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->codes_top, B * (size_t)c.max_steps * 8, true));
@@ -736,8 +739,12 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         if (l.wpk && !g.conv_taps && stream_gemm_ok(g, a_dt, c_dt)) {
             int S = (defer_residual && g.store != STORE_RESID) ? stream_gemm_splitk(g) : 1;
             if ((size_t)S * 32 * g.a_packed_mb * g.N > h->splitk_elems) S = 1;
+            if (S == 1 && h->xs_ctr) {                // residual producers at M = 64: split K inside the kernel (last arriver finishes the tile)
+                const int xs = stream_gemm_xs_S(g);
+                if (xs > 1 && (size_t)xs * 32 * g.a_packed_mb * g.N <= h->splitk_elems && (g.N / 32) * g.a_packed_mb <= 4096) { S = xs; g.xs_ctr = h->xs_ctr; }
+            }
             HIPCHK(launch_stream_gemm(g, l.wpk, a_dt, c_dt, S, h->splitk, st));
-            if (S > 1) { h->pend.slabs = h->splitk; h->pend.S = S; h->pend.rows = 32 * g.a_packed_mb; h->pend.bias = l.b32; }
+            if (S > 1 && !g.xs_ctr) { h->pend.slabs = h->splitk; h->pend.S = S; h->pend.rows = 32 * g.a_packed_mb; h->pend.bias = l.b32; }
             return HQT_OK;
         }
         g.Bw = l.w16;

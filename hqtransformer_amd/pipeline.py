@@ -30,7 +30,7 @@ class InflightSampler:
 
     def submit(self, num_candidates: int, cond, *, seed: Optional[int] = None, max_seq_len: int = 64, use_fp16: bool = True,
                decode: bool = True, precision: Optional[str] = None, clamp01: bool = True, use_graph: bool = True,
-               after=None, phase_events=None, **sample_kw) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.cuda.Event]:
+               after=None, phase_events=None, order_after_current: bool = True, **sample_kw) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.cuda.Event]:
         """Queue one batch on the next lane; returns (codes_top, codes_bot, pixels or None, done_event) immediately.
         The tensors are valid once ``done_event`` has completed (or after ``drain()``).  ``phase_events``: three timing
         events recorded on the lane's stream at AR start / AR end / decode end (lane time: phases of different lanes overlap)."""
@@ -39,7 +39,8 @@ class InflightSampler:
         st = self.streams[lane]
         # order the lane after whatever the caller's stream has queued (inputs; earlier direct use of lane 0's engine):
         # a lane's workspace must never be touched from two streams at once
-        st.wait_stream(torch.cuda.current_stream(self.device))
+        if order_after_current:                      # False: the caller has nothing queued that this batch depends on (keeps the null stream's queue idle)
+            st.wait_stream(torch.cuda.current_stream(self.device))
         if self.n > 1 and (lane, num_candidates, max_seq_len) not in self._policy_set:
             # several batches in flight: kernels that cost the fewest CU-microseconds (hqt_set_policy)
             self.model.stage2.engine(num_candidates, max_seq_len, lane).set_policy(POLICY_THROUGHPUT)
