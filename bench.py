@@ -74,7 +74,7 @@ def cpu_baseline(cfg, s2, s1, batch):
     w1 = synth.stage1_weights(s1, 1, 'bench')
     orc2, orc1 = (OracleStage2L3 if three else OracleStage2)(s2, w2), OracleStage1(s1, w1)
     n_pos = 2
-    cond = synth.class_ids(0, batch, max(s2.n_classes, 1))
+    cond = synth.text_ids(0, batch, s2.ctx_len_txt, s2.vocab_txt) if s2.cond == 2 else synth.class_ids(0, batch, max(s2.n_classes, 1))
     r = s1.z_res
     rng = np.random.default_rng(0)
     if three:
@@ -84,6 +84,13 @@ def cpu_baseline(cfg, s2, s1, batch):
     t0 = time.perf_counter()
     orc2.sample(cond, batch, n_pos, noise)
     t_ar = (time.perf_counter() - t0) / n_pos
+    t_prefill = 0.0
+    if s2.cond == 2:                        # the prompt prefill runs once per batch: separate it from the per-position cost
+        t0 = time.perf_counter()
+        orc2.sample(cond, batch, 1, noise[:1])
+        t1 = time.perf_counter() - t0
+        per_pos = max(t_ar * n_pos - t1, 1e-9) / (n_pos - 1)
+        t_prefill, t_ar = max(t1 - per_pos, 0.0), per_pos
     code_b = rng.integers(0, s1.n_embed, (1, r, r))
     code_m = rng.integers(0, s1.n_embed, (1, r // 2, r // 2))
     t0 = time.perf_counter()
@@ -93,9 +100,9 @@ def cpu_baseline(cfg, s2, s1, batch):
         orc1.decode_code(code_m, code_b)
     t_dec = time.perf_counter() - t0
     n_positions = (r // (4 if three else 2)) ** 2
-    per_image = t_ar * n_positions / batch + t_dec
+    per_image = (t_prefill + t_ar * n_positions) / batch + t_dec
     return {'value': round(1.0 / per_image, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_pos} of {n_positions} AR positions at batch {batch} ({t_ar:.2f} s/position) + decode of 1 image '
+            'sample': f'{n_pos} of {n_positions} AR positions at batch {batch} ({t_ar:.2f} s/position' + (f', prompt prefill {t_prefill:.2f} s' if s2.cond == 2 else '') + ') + decode of 1 image '
                       f'({t_dec:.2f} s), fp32 numpy/OpenBLAS oracle, extrapolated per image'}
 
 
@@ -137,6 +144,12 @@ def main():
         n_pos = min(n_pos, args.positions)
     fast = args.precision == 'fast'
     classes = synth.class_ids(1000 + rank, args.steps + args.warmup + 4, max(s2.n_classes, 1))
+    txt_cond = s2.cond == 2                 # text-conditional configs (BASELINE configs[4]): synthetic prompt ids, resident in HBM
+    prompts = [torch.from_numpy(synth.text_ids(2000 + 131 * rank + i, B, s2.ctx_len_txt, s2.vocab_txt)).to(dev)
+               for i in range(args.steps + args.warmup + 4)] if txt_cond else None
+
+    def cond_of(i):
+        return prompts[i % len(prompts)] if txt_cond else int(classes[i % len(classes)])
     H = s1.resolution
     gathered = None
     if dist is not None and args.gather == 'pixels' and rank == 0:
@@ -147,11 +160,11 @@ def main():
     def sample_codes(i, graph):
         """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels)."""
         if three:
-            c = sampling_hqtransformer(model.stage2, num_candidates=B, cond=int(classes[i]), top_k=[None] * 3, top_p=[None] * 3,
+            c = sampling_hqtransformer(model.stage2, num_candidates=B, cond=cond_of(i), top_k=[None] * 3, top_p=[None] * 3,
                                        softmax_temperature=[1.0] * 3, use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i,
                                        sample_offset=rank * B, use_graph=graph)
             return c[0], c[1:]
-        return sampling_ihqgpt(model.stage2, num_candidates=B, cond=int(classes[i]), top_k_top=None, top_p_top=None, top_k_bot=None,
+        return sampling_ihqgpt(model.stage2, num_candidates=B, cond=cond_of(i), top_k_top=None, top_p_top=None, top_k_bot=None,
                                top_p_bot=None, softmax_temperature=[1.0, 1.0], use_fp16=fast, is_tqdm=False, max_seq_len=n_pos,
                                model_stage1=None, seed=1 + i, sample_offset=rank * B, use_graph=graph)
 
@@ -201,12 +214,12 @@ def main():
             dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
 
     for li in range(max(inflight, args.warmup)):                        # every lane at least once: workspace, graph capture
-        pipe.submit(B, int(classes[li % len(classes)]), seed=1000 + li, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
+        pipe.submit(B, cond_of(li), seed=1000 + li, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
                     use_graph=not args.no_graph, after=after)
     pipe.drain()
     barrier()
     t0 = time.perf_counter()
-    kept = [pipe.submit(B, int(classes[args.warmup + k]), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
+    kept = [pipe.submit(B, cond_of(args.warmup + k), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
                         sample_offset=rank * B, use_graph=not args.no_graph, after=after,
                         order_after_current=not os.environ.get('HQT_BENCH_NO_ORDER')) for k in range(args.steps)]
     pipe.drain()
@@ -257,11 +270,11 @@ def main():
         work = work_per_image(s2, s1, n_pos)
         value = world * B * args.steps / elapsed
         out = {
-            'metric': 'images/sec (256x256 class-cond sampling)', 'value': round(value, 2), 'unit': 'images/s',
+            'metric': 'images/sec (256x256 text-cond sampling)' if txt_cond else 'images/sec (256x256 class-cond sampling)', 'value': round(value, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if fast else 'f32', 'data': 'synthetic',
-            'config': {'workload': f'imagenet256-classcond hq-vae({"8x8+16x16+32x32, three code levels" if three else "8x8+16x16"})+hq-transformer {s2.n_layers}L/{s2.embed_dim}d, '
+            'config': {'workload': (f'text-to-image ({s2.ctx_len_txt}-token synthetic prompts, prefill + ' if txt_cond else 'imagenet256-classcond (') + f'hq-vae({"8x8+16x16+32x32, three code levels" if three else "8x8+16x16"})+hq-transformer {s2.n_layers}L/{s2.embed_dim}d), '
                                    f'batch {B}/GPU, {n_pos} top positions, top_k=top_p=None, T=[1,1]',
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
                        'precision': 'FAST: bf16 weights+MFMA, fp32 accumulate' if fast else 'EXACT: fp32',

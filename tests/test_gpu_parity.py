@@ -610,3 +610,24 @@ def test_encode_imagenet_geometry_vs_oracle():
         assert _excess_distance(np_(fa['resid'][l]), cbs[l], np_(fa['codes'][l])).max() <= 1e-3, l
     rec = eng.decode(fa['codes'][0], fa['codes'][1], precision=PRECISION_FAST)
     assert bool(torch.isfinite(rec).all())
+
+
+def test_decode_five_level_geometry_vs_oracle():
+    """BASELINE configs[3] geometry (the reference's 5-level pattern ch_mult [1, 2, 4, 4, 4], attention at 32 x 32 = 1024 tokens,
+    bottom grid 16 x 16 here instead of 32 x 32, 32 base channels so the CPU oracle finishes in seconds): EXACT pixels within
+    1e-4 of the oracle, FAST within the bf16 budget of test_decode_fast_tolerance.  tools/bench_decoder.py runs the full
+    1024 x 1024 / 128-channel size (oracle-free: determinism + finiteness + throughput)."""
+    spec = Stage1Spec(ch=32, ch_mult=[1, 2, 4, 4, 4], num_res_blocks=1, attn_resolutions=[32], resolution=512, z_channels=64,
+                      embed_dim=32, n_embed=256)
+    assert spec.z_res == 16
+    weights = synth.stage1_weights(spec, 101, 'fixture')
+    r = np.random.default_rng(102)
+    ct, cb = r.integers(0, 256, (1, 8, 8)), r.integers(0, 256, (1, 16, 16))
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    eng = engine_s1(spec, weights, 1)
+    exact = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_EXACT))
+    assert exact.shape == (1, 3, 512, 512)
+    assert np.abs(exact - want).max() <= PIXEL_TOL, np.abs(exact - want).max()
+    fast = np_(eng.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_FAST))
+    d = np.abs(fast - want)
+    assert d.max() <= 0.1 * max(1.0, float(np.abs(want).max()) / 5.0) and d.mean() <= 1e-2, (d.max(), d.mean())
