@@ -213,13 +213,15 @@ def main():
         elif dist is not None and args.gather == 'codes':
             dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
 
-    for li in range(max(inflight, args.warmup)):                        # every lane at least once: workspace, graph capture
+    debug_short = n_pos < n_full            # --positions (counter collection): the padded decode of step(), one lane, no pipeline
+    for li in range(0 if debug_short else max(inflight, args.warmup)):  # every lane at least once: workspace, graph capture
         pipe.submit(B, cond_of(li), seed=1000 + li, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
                     use_graph=not args.no_graph, after=after)
     pipe.drain()
     barrier()
     t0 = time.perf_counter()
-    kept = [pipe.submit(B, cond_of(args.warmup + k), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
+    kept = [step(args.warmup + k) for k in range(args.steps)] if debug_short else \
+           [pipe.submit(B, cond_of(args.warmup + k), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
                         sample_offset=rank * B, use_graph=not args.no_graph, after=after,
                         order_after_current=not os.environ.get('HQT_BENCH_NO_ORDER')) for k in range(args.steps)]
     pipe.drain()

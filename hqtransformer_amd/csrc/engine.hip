@@ -1310,6 +1310,7 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
             sg.Bw = h->ak; sg.ldb = C; sg.b_batch_stride = (long long)hw * C;
             sg.C = h->as; sg.ldc = hw; sg.c_batch_stride = (long long)hw * hw;
             sg.M = hw; sg.N = hw; sg.K = C; sg.batch = n; sg.alpha = 1.0f / sqrtf((float)C); sg.store = STORE_ROWS;
+            sg.zero_page = h->zero_page;          // lets the LDS-DMA kernel take the batched product
             if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
             else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
         }
@@ -1321,6 +1322,7 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
             sg.Bw = h->av; sg.ldb = hw; sg.b_batch_stride = (long long)hw * C;
             sg.C = h->ao; sg.ldc = C; sg.c_batch_stride = (long long)hw * C;
             sg.M = hw; sg.N = C; sg.K = hw; sg.batch = n; sg.alpha = 1.0f; sg.store = STORE_ROWS;
+            sg.zero_page = h->zero_page;
             if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
             else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
         }
