@@ -246,14 +246,18 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(GemmArgs g) {
 // NSTAGE = 4: four-slot LDS ring (128 KiB, 1 workgroup per CU) with two k-tiles of DMA in flight across the barrier:
 //   counted s_waitcnt vmcnt(8 * tiles_in_flight) + raw s_barrier per k-tile; the slot of tile kt-1 is refilled right
 //   after the barrier that every wave passes only once it has finished reading that tile.
-template <typename TC, int MODE, int NSTAGE, int ABL = 0>        // MODE 0: plain rows, 1: NCHW, 2: any store mode (element-wise), 3: fused QKV, 4 columns at a time; ABL: tools/micro/bench_conv
+// BM_ = 64: 64 x 128 tiles (4 waves side by side, 64 x 32 each) for GEMMs whose 128 x 128 grid would leave most CUs idle
+// (the 1024-row narrow GEMMs of the third code level: 96 -> 192 workgroups); two LDS buffers only.
+template <typename TC, int MODE, int NSTAGE, int ABL = 0, int BM_ = 128>   // MODE 0: plain rows, 1: NCHW, 2: any store mode (element-wise), 3: fused QKV, 4 columns at a time; ABL: tools/micro/bench_conv
 __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(GemmArgs g) {
     constexpr bool NCHW = MODE == 1;
-    constexpr int BM = 128, BN = 128, BKG = 64, ROWB = 128;            // ROWB: bytes per LDS row
+    static_assert(BM_ == 128 || (BM_ == 64 && NSTAGE == 2), "64-row tiles run with two LDS buffers");
+    constexpr int BM = BM_, BN = 128, BKG = 64, ROWB = 128;            // ROWB: bytes per LDS row
+    constexpr int WNW = BM == 128 ? 64 : 32, FJ = WNW / 32, APW = BM / 32;   // columns per wave, 32-column fragments per wave, A DMA pieces per wave
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];     // [NSTAGE][A|B][BM * ROWB]
-    auto LDS = [&](int stage, int op) -> char* { return lds_raw + (size_t)(stage * 2 + op) * (BM * ROWB); };
+    auto LDS = [&](int stage, int op) -> char* { return lds_raw + (size_t)stage * ((BM + BN) * ROWB) + (op ? BM * ROWB : 0); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BM == 128 ? wave >> 1 : 0, wn = BM == 128 ? wave & 1 : wave;
     const int bz = blockIdx.z;
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
@@ -263,15 +267,20 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g.zero_page);
 
     // DMA instruction i (0..3) of this wave fills rows (wave * 4 + i) * 8 .. + 7; lane -> (row, slot)
-    RowCtx arow[4];
+    RowCtx arow[APW];
     const bf16_t* brow[4];
-    int chunk[4];                                                     // source chunk of this lane (elements: * 8)
+    int chunk[4], achunk[APW];                                        // source chunk of this lane (elements: * 8)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         chunk[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
-        arow[i] = make_row(g, Abase, m0 + row);
         brow[i] = (n0 + row < g.N) ? Bbase + (long long)(n0 + row) * g.ldb : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int row = (wave * APW + i) * 8 + (lane >> 3);
+        achunk[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        arow[i] = make_row(g, Abase, m0 + row);
     }
     const int cpt = g.conv_taps ? g.Cin / BKG : 1;
     const int Hv = g.H << g.conv_stride2, Wv = g.W << g.conv_stride2;      // input size as the filter sees it (Downsample: stride 2)
@@ -283,17 +292,17 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
         int dy = 0, dx = 0;
         if (g.conv_taps == 9) { const int t3 = tap / 3; dy = t3 - 1 + g.conv_nopad; dx = tap - 3 * t3 - 1 + g.conv_nopad; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < APW; ++i) {
             const bf16_t* src = zero;
             if (arow[i].ok) {
-                if (!g.conv_taps) src = arow[i].row + k0 + chunk[i];
+                if (!g.conv_taps) src = arow[i].row + k0 + achunk[i];
                 else {
                     const int iy = (arow[i].y << g.conv_stride2) + dy, ix = (arow[i].x << g.conv_stride2) + dx;
                     if ((unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv)
-                        src = Abase + (((long long)arow[i].img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * g.Cin + c0 + chunk[i];
+                        src = Abase + (((long long)arow[i].img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * g.Cin + c0 + achunk[i];
                 }
             }
-            char* dst = LDS(buf, 0) + (wave * 4 + i) * 8 * ROWB;            // wave-uniform base; HW adds 16 * lane
+            char* dst = LDS(buf, 0) + (wave * APW + i) * 8 * ROWB;          // wave-uniform base; HW adds 16 * lane
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -306,11 +315,11 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][FJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -322,21 +331,21 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 2 + fh;
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[2], bfr[FJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = wm * 64 + i * 32 + fr;
                 af[i] = *reinterpret_cast<const bf16x8*>(Ab + r * ROWB + ((c ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = wn * 64 + j * 32 + fr;
+            for (int j = 0; j < FJ; ++j) {
+                const int r = wn * WNW + j * 32 + fr;
                 bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + r * ROWB + ((c ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D rows = n, cols = m
+                for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D rows = n, cols = m
         }
     };
     if constexpr (NSTAGE == 2) {
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < FJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
         if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
@@ -386,10 +395,10 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void conv_glds_kernel(Gem
         const int m = m0 + wm * 64 + i * 32 + fr;
         if (m >= g.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                const int n4 = n0 + wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                const int n4 = n0 + wn * WNW + j * 32 + 8 * q4 + 4 * fh;
                 if (n4 >= g.N) continue;
                 float v[4];
 #pragma unroll
@@ -812,6 +821,22 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
             static const int nstage = getenv("HQT_CONV_STAGES") ? atoi(getenv("HQT_CONV_STAGES")) : 2;   // A/B switch: the 4-slot ring (1 WG/CU) measured 1.5x slower than 2 buffers x 2 WGs/CU
             const bool ring = nstage == 4 && g.K / 64 >= 4;
             const size_t smem = (size_t)(ring ? 4 : 2) * 2 * 128 * 128;
+            // few 128 x 128 tiles and rows to spare (third code level: [1024, 1536] GEMMs = 96 tiles): 64-row tiles fill the chip
+            const long long t128 = (long long)grid.x * grid.y * grid.z;
+            // (latency policy only: with several steps in flight the 128 x 128 tiles cost fewer CU-microseconds -- level-3 config,
+            // 3 lanes: 594 vs 576 images/s; one lane: AR 158.7 vs 169.1 ms)
+            if (t128 < 192 && g.M >= 256 && !g.conv_taps && g.store == STORE_ROWS && g.tune == 0 && !getenv("HQT_NO_TILE64")) {
+                const dim3 grid64((g.N + 127) / 128, (g.M + 63) / 64, grid.z);
+                const size_t smem64 = (size_t)2 * (64 + 128) * 128;
+                if (g.rows_per_group == 0) {
+                    if (c_dt == DT_BF16) conv_glds_kernel<bf16_t, 0, 2, 0, 64><<<grid64, 256, smem64, st>>>(g);
+                    else conv_glds_kernel<float, 0, 2, 0, 64><<<grid64, 256, smem64, st>>>(g);
+                } else {
+                    if (c_dt == DT_BF16) conv_glds_kernel<bf16_t, 2, 2, 0, 64><<<grid64, 256, smem64, st>>>(g);
+                    else conv_glds_kernel<float, 2, 2, 0, 64><<<grid64, 256, smem64, st>>>(g);
+                }
+                return hipGetLastError();
+            }
 #define LAUNCH_GLDS(TC, NCHW_)                                                                      \
             if (ring) conv_glds_kernel<TC, NCHW_, 4><<<grid, 256, smem, st>>>(g);                    \
             else conv_glds_kernel<TC, NCHW_, 2><<<grid, 256, smem, st>>>(g);
