@@ -169,6 +169,7 @@ struct GemmArgs {
     //      partial tile to slab z with agent-scope stores, then bumps xs_ctr[tile]; the last arriver of a tile sums the S
     //      partials in z order (deterministic), resets the counter and runs the fused epilogue.  No workgroup waits.
     unsigned* xs_ctr;        // [gridDim.x * gridDim.y] zeros between launches
+    int w_nt;                // streaming GEMM: 1 = fetch the weights with the non-temporal hint (read once), 0 = ordinary loads (re-read soon)
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

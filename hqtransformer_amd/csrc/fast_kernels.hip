@@ -1,5 +1,6 @@
 // FAST-precision kernels (bf16 operands, fp32 accumulation on the gfx950 matrix cores).
 #include "fast_kernels.h"
+#include <type_traits>
 #include "gemm_generic.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -156,11 +157,20 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     int ks = 0;
     bool first = true;
     const unsigned polled = chain_poll(g.chain);
+    // Two copies of the run loop: weights fetched with the non-temporal hint (streamed once: the body's 340 MB per position) or as
+    // ordinary loads (re-read soon: the depth blocks run twice per position, and steps in flight on other lanes re-read what
+    // this one just pulled through the 256 MB Infinity Cache).  GemmArgs.w_nt picks; a runtime select per load would put the
+    // loads in branches.
+    auto run_main = [&](auto nt_tag) {
+    constexpr bool WNT = decltype(nt_tag)::value;
     for (; ks + U <= cnt; ks += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wbuf[u][t] = __builtin_nontemporal_load(wp + ((size_t)t * KS + (ABL == 2 ? 0 : ks + u)) * 64);
+            for (int t = 0; t < NT; ++t) {
+                const u32x4* wsrc = wp + ((size_t)t * KS + (ABL == 2 ? 0 : ks + u)) * 64;
+                wbuf[u][t] = WNT ? __builtin_nontemporal_load(wsrc) : *wsrc;
+            }
         if (first) {                                  // weights are in flight; everything below depends on the predecessor
             __builtin_amdgcn_sched_barrier(0);
             chain_wait(g.chain, polled);
@@ -189,6 +199,8 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
                     acc[t][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, xbuf[u][mb]), acc[t][mb], 0, 0, 0);
             }
     }
+    };
+    if (g.w_nt) run_main(std::true_type{}); else run_main(std::false_type{});
     if (first) {                                      // K too short for a full run: nothing was prefetched
         chain_wait(g.chain, polled);
     }
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
         for (int u = 0; u < U; ++u) {
             const int kk = ks + min(u, rem - 1);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wbuf[u][t] = __builtin_nontemporal_load(wp + ((size_t)t * KS + kk) * 64);
+            for (int t = 0; t < NT; ++t) wbuf[u][t] = wp[((size_t)t * KS + kk) * 64];
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) xbuf[u][mb] = xp[((size_t)kk * MB + mb) * 64];
         }
