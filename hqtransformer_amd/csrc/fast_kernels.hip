@@ -604,11 +604,13 @@ static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, f
         }
     }
     if (S == 1 && g.tune == 1) {
-        // throughput policy (several batches in flight): fewest CU-microseconds per GEMM.  64-row weight tiles halve the
-        // activation re-reads per weight byte; measured with 3 lanes: 1036 -> 1111 images/s (alone: 694 -> 598).
-        if (g.a_packed_mb == 2 && g.N >= 3072 && (g.N / 32) % 2 == 0) return launch_stream_t<2, 2, 8, 6, TC>(g, wpk, 1, nullptr, st);
+        // throughput policy (several batches in flight): fewest CU-microseconds per GEMM.  Re-swept with cacheable weight loads
+        // (tools/sweep_gemm_policy.sh, 3 lanes): 64-row tiles over 6-step runs for the 64-row GEMMs, 64-row WEIGHT tiles for the
+        // narrow 256-row ones (proj / fc2 of depth sub-step 1): 1180 -> 1220 images/s; alone these choices cost 4-5 ms of AR.
+        if (g.a_packed_mb == 2 && g.N >= 3072) return launch_stream_t<2, 1, 8, 6, TC>(g, wpk, 1, nullptr, st);
         if (g.a_packed_mb == 2) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);
         if (g.a_packed_mb == 8 && g.N >= 3072 && (g.N / 32) % 2 == 0) return launch_stream_t<4, 2, 4, 3, TC>(g, wpk, 1, nullptr, st);
+        if (g.a_packed_mb == 8 && (g.N / 32) % 2 == 0) return launch_stream_t<2, 2, 8, 6, TC>(g, wpk, 1, nullptr, st);
     }
     const int wgs2 = (g.N / 32) * (g.a_packed_mb / 2);
     if (S == 1 && g.a_packed_mb == 2 && wgs2 >= 128) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);
