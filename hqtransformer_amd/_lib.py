@@ -129,6 +129,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it carries its own HIP runtime, and libhqt.so must bind to THAT copy.  Loaded the other way round (libhqt.so
+    # pulling in /opt/rocm's libamdhip64 before torch is imported) the process ends up with the system runtime under torch and
+    # torch.cuda reports 'No HIP GPUs are available'.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise HqtLibraryError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                               '(hqtransformer_amd has no CPU fallback)')
