@@ -966,15 +966,24 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
         Timed t(h, "sampler", c.st);
         SamplerArgs s{h->logits, B, V, 1, B, c.o.temperature_top, c.o.top_k_top, c.o.top_p_top, c.noise, 0,
                       h->state, c.o.n_steps, c.out_top, c.logits_out};
+        // the draw and the embedding lookup of the drawn code in one kernel: the sampler's workgroup of sample b also writes the
+        // four input rows of depth sub-step 1 (HQT_NO_FUSED_EMBED=1: separate depth_embed_kernel, for A/B runs)
+        static const bool fuse = !getenv("HQT_NO_FUSED_EMBED");
+        if (fuse) {
+            s.emb_tok = W(h, "tok_emb_top_depth.weight"); s.emb_pos = W(h, "pos_emb_depth.weight");
+            s.emb_feed = c.feed_top != c.out_top ? c.feed_top : nullptr;
+            s.emb_x = h->xd; s.emb_D = D;
+            s.emb_xpk = dln4 ? h->xdpk : nullptr; s.emb_pk_mb = dln4 ? packed_mb(4 * B) : 0; s.emb_parts = h->partsd;
+        }
         HIPCHK(launch_sampler(s, c.st));
-    }
-    // ---- depth sub-step 1: four bottom codes in one pass
-    {
-        Timed t(h, "embed", c.st);
-        HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
-                                  h->xd, B, D, dln4 ? h->xdpk : nullptr, dln4 ? packed_mb(4 * B) : 0, h->partsd, c.st));
+        if (!fuse) {
+            Timed t2(h, "embed", c.st);
+            HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
+                                      h->xd, B, D, dln4 ? h->xdpk : nullptr, dln4 ? packed_mb(4 * B) : 0, h->partsd, c.st));
+        }
         h->npartsd = 1;
     }
+    // ---- depth sub-step 1: four bottom codes in one pass
     for (int l = 0; l < cf.n_layers_depth; ++l) {
         void* kc = (char*)h->dk + l * dkv_layer;
         void* vc = (char*)h->dv + l * dkv_layer;

@@ -92,6 +92,17 @@ struct SamplerArgs {
     int64_t* out;                // top: [B, n_steps]; bottom: [B, n_steps, 4]
     float* logits_out;           // optional [n_steps, draws, B, V]
     int draws;                   // draws per top position: 5 (two levels; 0 means 5) or 21 (three levels) -- noise / logits_out stride
+    // ---- fused embedding lookup of the code just drawn (top draw, slots == 1): the four input rows of depth sub-step 1,
+    //      x[(b * 4 + s)] = emb_tok[code] + emb_pos[s] (hierarchical_ar.py:705-712), plus the packed bf16 copy and row statistics
+    //      the deferred-LayerNorm GEMMs read.  emb_tok == NULL: no fusion (depth_embed_kernel does it).
+    const float* emb_tok;        // [V, D]
+    const float* emb_pos;        // [>= 4, D]
+    const int64_t* emb_feed;     // code to embed instead of the drawn one (teacher forcing), same indexing as `out`; NULL: the drawn code
+    float* emb_x;                // [4 B, D]
+    int emb_D;
+    bf16_t* emb_xpk;             // optional packed copy (packed_off layout with emb_pk_mb row blocks)
+    int emb_pk_mb;
+    float* emb_parts;            // [4 B][2]
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
 // depth sub-step 2 of the three-level model (hqtransformer.py:537-551): token i (raster (H1 H2 W1 W2)) =

@@ -599,6 +599,39 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
         for (int w = 1; w < NT / 64; ++w)
             if (redf[w] > best || (redf[w] == best && redi[w] < besti)) { best = redf[w]; besti = redi[w]; }
         a.out[((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
+        if (a.emb_tok) sel[0] = a.emb_feed ? (int)a.emb_feed[((long long)b * a.n_steps + step) * a.slots + slot] : besti;
+    }
+    if (!a.emb_tok) return;                              // workgroup-uniform
+    // ---- fused embedding lookup: this workgroup drew the top code of sample b, so it also writes the four depth-token rows
+    __syncthreads();
+    const long long code = sel[0];
+    const int D = a.emb_D;
+#pragma unroll 1
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int row = b * 4 + s4;
+        float rs = 0.0f, rq = 0.0f;
+        for (int d = tid; d < D; d += NT) {
+            const float v = a.emb_tok[code * D + d] + a.emb_pos[(long long)s4 * D + d];
+            a.emb_x[(long long)row * D + d] = v;
+            if (a.emb_xpk) {
+                const bf16_t hb = f32_to_bf16(v);
+                a.emb_xpk[packed_off(row, d, a.emb_pk_mb)] = hb;
+                const float r = bf16_to_f32(hb);
+                rs += r; rq += r * r;
+            }
+        }
+        if (a.emb_xpk) {                                 // fixed-order reduction: waves, then wave 0 .. NT/64-1
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { rs += __shfl_xor(rs, off, 64); rq += __shfl_xor(rq, off, 64); }
+            __syncthreads();
+            if ((tid & 63) == 0) { redf[tid >> 6] = rs; dsum[tid >> 6] = (double)rq; }
+            __syncthreads();
+            if (tid == 0) {
+                float ts = 0.0f, tq = 0.0f;
+                for (int w = 0; w < NT / 64; ++w) { ts += redf[w]; tq += (float)dsum[w]; }
+                a.emb_parts[2 * row] = ts; a.emb_parts[2 * row + 1] = tq;
+            }
+        }
     }
 }
 
