@@ -205,3 +205,29 @@ def test_encode_surface_matches_the_oracle(model):
     assert tuple(rec.shape) == (2, 3, s1.resolution, s1.resolution)
     fast = model.stage1.get_codes(xt, precision='fast')
     assert (fast[0] == ct).float().mean() >= 0.5
+
+
+def test_three_level_encode_surface(tmp_path):
+    """``HQVAEGenerator.encode`` through the model mirror (generator.py:530-568): ``(quant, diffs, codes, resids[1:])`` with the
+    reference's shapes; the summed reconstruction equals what ``decode_code`` rebuilds from the codes (checked through the
+    pixels), and the round trip ``stage1(x)`` equals ``decode_code(code_grids(x))``."""
+    l3 = os.path.join(ROOT, 'configs', 'tiny-l3.yaml')
+    m = ImageGPT2(load_config(l3), seed=9).to('cuda').eval()
+    s1 = m.stage1.spec
+    w1 = {k: v.numpy() for k, v in m.stage1.state_dict().items()}
+    r = np.random.default_rng(4)
+    x = np.clip(0.5 * r.standard_normal((2, 3, s1.resolution, s1.resolution)), -1, 1).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    quant, diffs, codes, resids = m.stage1.encode(xt)
+    rz, E = s1.z_res, s1.embed_dim
+    assert tuple(quant.shape) == (2, E, rz, rz) and len(diffs) == 3 and len(codes) == 3 and len(resids) == 2
+    assert [tuple(c.shape) for c in codes] == [(2 * (rz // 4) ** 2,), (2 * (rz // 2) ** 2,), (2 * rz * rz,)]
+    assert [tuple(z.shape) for z in resids] == [(2, 4 * E, rz // 2, rz // 2), (2, E, rz, rz)]
+    want = O.OracleStage1(s1, w1).encode(x)
+    assert np.abs(resids[0].cpu().numpy() - want['resid'][1]).max() <= 1e-4 or not np.array_equal(codes[0].cpu().numpy(), want['codes'][0].reshape(-1))
+    if all(np.array_equal(c.cpu().numpy(), w.reshape(-1)) for c, w in zip(codes, want['codes'])):
+        assert np.abs(quant.cpu().numpy() - want['recon']).max() <= 1e-4
+        assert all(abs(float(d) - float(wd)) <= 1e-3 * float(wd) for d, wd in zip(diffs, want['diff']))
+    grids = m.stage1.code_grids(xt)
+    assert torch.equal(m.stage1(xt), m.stage1.decode_code(list(grids)))
+    assert [c.reshape(-1).tolist() for c in grids] == [c.tolist() for c in m.stage1.get_codes(xt)]
