@@ -129,8 +129,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # test hook for boxes with fewer GPUs than ranks (exercises the N > 1 control flow only; the numbers mean nothing):
+        # HQT_BENCH_SHARE_GPU=1 maps the ranks onto the visible devices round-robin and rendezvous runs over gloo
+        share = bool(os.environ.get('HQT_BENCH_SHARE_GPU'))
+        if share:
+            local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if share:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
