@@ -608,7 +608,7 @@ static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, f
         // (tools/sweep_gemm_policy.sh, 3 lanes): 64-row tiles over 6-step runs for the 64-row GEMMs, 64-row WEIGHT tiles for the
         // narrow 256-row ones (proj / fc2 of depth sub-step 1): 1180 -> 1220 images/s; alone these choices cost 4-5 ms of AR.
         if (g.a_packed_mb == 2 && g.N >= 3072) return launch_stream_t<2, 1, 8, 6, TC>(g, wpk, 1, nullptr, st);
-        if (g.a_packed_mb == 2) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);
+        if (g.a_packed_mb == 2) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);   // (16-wave variants <1,1,16,6> etc.: no difference beyond the +-2 % run-to-run noise)
         if (g.a_packed_mb == 8 && g.N >= 3072 && (g.N / 32) % 2 == 0) return launch_stream_t<4, 2, 4, 3, TC>(g, wpk, 1, nullptr, st);
         if (g.a_packed_mb == 8 && (g.N / 32) % 2 == 0) return launch_stream_t<2, 2, 8, 6, TC>(g, wpk, 1, nullptr, st);
     }
