@@ -241,6 +241,7 @@ def main():
         elapsed_lanes = float(t.item())
     del kept
     pipe.release(B, n_pos)            # lane 0 back to the latency-oriented kernels for the one-at-a-time reference pass
+    sample_codes(0, not args.no_graph)  # untimed: the policy change re-captures lane 0's graph; keep that out of the pass below
 
     # ---- reference pass: the same steps one at a time on one lane (the reference harness's order), with per-phase events
     n_serial = args.steps if inflight == 1 else min(args.steps, 3)

@@ -1194,7 +1194,12 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
     const int remaining = opts->n_steps - first;
     if (remaining <= 0) return HQT_OK;
     if (opts->use_graph && !h->timing) {
-        std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)(cond != nullptr), (uint64_t)noise, (uint64_t)c.feed_top, (uint64_t)c.feed_bot,
+        // positions per captured graph: the largest divisor of the remaining positions up to HQT_GRAPH_POSITIONS (default 16):
+        // one graph launch then covers G positions (fewer host launches and graph-to-graph hand-overs on the device)
+        static const int gmax = getenv("HQT_GRAPH_POSITIONS") ? std::max(1, atoi(getenv("HQT_GRAPH_POSITIONS"))) : 16;
+        int G = 1;
+        for (int d = std::min(gmax, remaining); d >= 1; --d) if (remaining % d == 0) { G = d; break; }
+        std::vector<uint64_t> key = {(uint64_t)G, (uint64_t)B, (uint64_t)(cond != nullptr), (uint64_t)noise, (uint64_t)c.feed_top, (uint64_t)c.feed_bot,
                                      (uint64_t)logits_out, (uint64_t)opts->precision,
                                      (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot,
                                      (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2], (uint64_t)h->policy};
@@ -1214,7 +1219,8 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
             SampleCtx cc = c;
             cc.st = cs;
             HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-            int rc = run_decode_step(h, cc);
+            int rc = HQT_OK;
+            for (int gi = 0; gi < G && rc == HQT_OK; ++gi) rc = run_decode_step(h, cc);
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamEndCapture(cs, &graph);
             hipStreamDestroy(cs);
@@ -1224,7 +1230,7 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
             hipGraphDestroy(graph);
             h->graph_key = key;
         }
-        for (int s = 0; s < remaining; ++s) HIPCHK(hipGraphLaunch(h->graph_exec, c.st));
+        for (int s = 0; s < remaining / G; ++s) HIPCHK(hipGraphLaunch(h->graph_exec, c.st));
         return HQT_OK;
     }
     for (int s = 0; s < remaining; ++s) CHK(run_decode_step(h, c));
