@@ -13,10 +13,11 @@ from typing import List, Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'mfma_gemm.hip']
+SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'mfma_gemm.hip', 'split_conv.hip']
 ABI_VERSION = 3
 
-PRECISION_EXACT, PRECISION_FAST = 0, 1
+PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT = 0, 1, 2
+PRECISIONS = {'exact': PRECISION_EXACT, 'fast': PRECISION_FAST, 'split': PRECISION_SPLIT}
 POLICY_LATENCY, POLICY_THROUGHPUT = 0, 1
 
 
@@ -108,20 +109,39 @@ _lib: Optional[C.CDLL] = None
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile libhqt.so for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
-        [os.path.join(os.path.dirname(HERE), 'include', 'hqt.h')]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """Compile libhqt.so for gfx950 in-tree with hipcc (cross-compiles without a GPU): one object per source, the stale
+    ones in parallel, then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(os.path.dirname(HERE), 'include', 'hqt.h')]
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
-           '-Wno-unused-result', '-o', LIB_PATH] + srcs
-    if verbose:
-        print(' '.join(cmd))
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if proc.returncode != 0:
-        raise HqtLibraryError('hipcc failed:\n' + proc.stdout)
+    flags = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+    objdir = os.path.join(CSRC, 'build')
+    os.makedirs(objdir, exist_ok=True)
+
+    def stale(out, deps):
+        return force or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps)
+
+    def compile_one(name):
+        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name.replace('.hip', '.o'))
+        if not stale(obj, [src] + hdrs):
+            return obj
+        cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode != 0:
+            raise HqtLibraryError(f'hipcc failed on {name}:\n' + proc.stdout)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1))) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    if stale(LIB_PATH, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode != 0:
+            raise HqtLibraryError('link failed:\n' + proc.stdout)
     return LIB_PATH
 
 

@@ -170,6 +170,10 @@ struct GemmArgs {
     //      partials in z order (deterministic), resets the counter and runs the fused epilogue.  No workgroup waits.
     unsigned* xs_ctr;        // [gridDim.x * gridDim.y] zeros between launches
     int w_nt;                // streaming GEMM: 1 = fetch the weights with the non-temporal hint (read once), 0 = ordinary loads (re-read soon)
+    // ---- SPLIT precision (split_kernels.h): A holds fp16 [row][hi K | lo K] planes, Bw the hi filters, Bw_lo the lo filters;
+    //      C / resid are fp32.  gn_part_out_d: per-tile GroupNorm partials of the fp32 output as doubles (layout of gn_part_out).
+    const void* Bw_lo;
+    double* gn_part_out_d;
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

@@ -3,6 +3,7 @@
 #include "../../include/hqt.h"
 #include "kernels.h"
 #include "fast_kernels.h"
+#include "split_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -46,6 +47,8 @@ struct Lin {            // one nn.Linear / conv filter bank in every layout the 
     const float* w32 = nullptr;   // [N, K] fp32 (conv: tap-major [O][tap][I])
     const float* b32 = nullptr;   // [N] or null
     bf16_t* w16 = nullptr;        // [N, K] bf16 row-major (FAST generic + conv MFMA)
+    half_t* w16h = nullptr;       // [N, K] fp16 hi / lo planes of w32 (SPLIT convolutions: split_kernels.h)
+    half_t* w16l = nullptr;
     bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)
     bf16_t* wpk_ln = nullptr;     // same packing of gamma o W (deferred LayerNorm), with its column sums and folded bias
     float* colsum = nullptr;
@@ -115,7 +118,7 @@ struct hqt_handle {
     void* act[4] = {nullptr, nullptr, nullptr, nullptr};   // 3 rotating activation buffers + the normalised/activated copy (FAST)
     double* gn_partial = nullptr;
     float* gn_tiles = nullptr;                // per-tile output statistics of the last halo conv ([image][tile][32][2])
-    struct { const void* tensor; int tiles; } gn_ready = {nullptr, 0};
+    struct { const void* tensor; int tiles; bool dbl; } gn_ready = {nullptr, 0, false};   // dbl: double partials (SPLIT conv)
     void* zero_page = nullptr;
     size_t act_elems = 0;
     int dec_chunk = 0;
@@ -140,7 +143,7 @@ static int dev_alloc(hqt_handle* h, void** p, size_t bytes, bool workspace) {
     HIPCHK(hipMalloc(p, bytes ? bytes : 16));
     // test hook: HQT_POISON_WORKSPACE=1 fills every workspace buffer with 0xFF (NaN as fp32 / bf16, -1 as int64) so that
     // a read of something no kernel wrote shows up instead of passing on freshly zeroed memory
-    static const bool poison = getenv("HQT_POISON_WORKSPACE") != nullptr;
+    const bool poison = getenv("HQT_POISON_WORKSPACE") != nullptr;       // read per allocation: tests switch it on around one engine
     if (poison && workspace && bytes) HIPCHK(hipMemset(*p, 0xFF, bytes));
     h->owned.push_back(*p);
     if (workspace) h->workspace_bytes += bytes;
@@ -356,10 +359,13 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), (void**)&h->codes_top, B * (size_t)c.max_steps * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->codes_bot, B * (size_t)c.max_steps * 4 * 8, true));
         if (c.code_levels == 3) CHK(dev_alloc(h.get(), (void**)&h->codes_l2, B * (size_t)c.max_steps * 16 * 8, true));
-        CHK(dev_alloc(h.get(), (void**)&h->xpk, rows * D * 2, true));
-        CHK(dev_alloc(h.get(), (void**)&h->xdpk, rows * D * 2, true));
-        CHK(dev_alloc(h.get(), (void**)&h->parts, (D / 32 + 1) * rows * 2 * 4, true));
-        CHK(dev_alloc(h.get(), (void**)&h->partsd, (D / 32 + 1) * rows * 2 * 4, true));
+        // packed_off() buffers are addressed with a row stride of 32 * packed_mb(M) (32 / 64 / 128 / 256 rows), which can
+        // exceed round32(M): size them for the widest padded block any M <= 256 pass can use
+        const size_t rows_pk = std::max<size_t>(rows, 256);
+        CHK(dev_alloc(h.get(), (void**)&h->xpk, rows_pk * D * 2, true));
+        CHK(dev_alloc(h.get(), (void**)&h->xdpk, rows_pk * D * 2, true));
+        CHK(dev_alloc(h.get(), (void**)&h->parts, (D / 32 + 1) * rows_pk * 2 * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->partsd, (D / 32 + 1) * rows_pk * 2 * 4, true));
     }
     if (c.has_stage1) {
         std::vector<DecLayer> both(h->dec);                 // decoder and encoder share the activation / attention / statistics buffers
@@ -374,7 +380,7 @@ static int alloc_workspace(hqt_handle* hp) {
         h->dec_chunk = std::min<int>(c.max_batch, 64);
         h->act_elems = per_img * h->dec_chunk;
         for (int i = 0; i < 3; ++i) CHK(dev_alloc(h.get(), &h->act[i], h->act_elems * 4, true));
-        CHK(dev_alloc(h.get(), &h->act[3], h->act_elems * 2, true));
+        CHK(dev_alloc(h.get(), &h->act[3], h->act_elems * 4, true));     // bf16 copy (FAST) or fp16 hi / lo planes (SPLIT)
         {
             size_t pe = 0;
             for (auto& l : both) if (l.kind != 6) pe = std::max(pe, gn_stats_fast_partial_elems(h->dec_chunk, l.res * l.res, l.cin, 32));
@@ -382,7 +388,7 @@ static int alloc_workspace(hqt_handle* hp) {
             CHK(dev_alloc(h.get(), (void**)&h->gn_partial, pe * sizeof(double), true));
             size_t te = 0;
             for (auto& l : both) { const int ro = l.kind == 3 ? 2 * l.res : l.res; te = std::max(te, (size_t)h->dec_chunk * (ro / 8 + 1) * (ro / 16 + 1) * 64); }
-            CHK(dev_alloc(h.get(), (void**)&h->gn_tiles, te * sizeof(float), true));
+            CHK(dev_alloc(h.get(), (void**)&h->gn_tiles, te * sizeof(double), true));     // floats (FAST) or doubles (SPLIT)
         }
         const int r = h->dec.front().res;
         size_t attn_c = 0;
@@ -482,10 +488,15 @@ static int get_w(hqt_handle* h, const std::string& name, std::vector<int64_t> sh
     return HQT_OK;
 }
 
-static int make_lin(hqt_handle* h, Lin& l, const float* w32, const float* b32, int N, int K, bool stream_pack) {
+static int make_lin(hqt_handle* h, Lin& l, const float* w32, const float* b32, int N, int K, bool stream_pack, bool split_planes = false) {
     l.w32 = w32; l.b32 = b32; l.N = N; l.K = K;
     CHK(dev_alloc(h, (void**)&l.w16, (size_t)N * K * 2, false));
     HIPCHK(launch_f32_to_bf16(w32, l.w16, (size_t)N * K, 0));
+    if (split_planes) {
+        CHK(dev_alloc(h, (void**)&l.w16h, (size_t)N * K * 2, false));
+        CHK(dev_alloc(h, (void**)&l.w16l, (size_t)N * K * 2, false));
+        HIPCHK(launch_split_f32(w32, l.w16h, l.w16l, (size_t)N * K, 0));
+    }
     if (stream_pack && stream_gemm_supported(N, K)) {
         CHK(dev_alloc(h, (void**)&l.wpk, (size_t)N * K * 2, false));
         HIPCHK(launch_pack_stream_weights(w32, l.wpk, N, K, 0));
@@ -550,7 +561,7 @@ static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int k
         CHK(dev_alloc(h, (void**)&wt, (size_t)O * I * taps * 4, false));
         HIPCHK(launch_repack_conv(w, wt, O, I, taps, 0));
     }
-    return make_lin(h, l, wt, b, O, I * taps, false);
+    return make_lin(h, l, wt, b, O, I * taps, false, true);
 }
 
 // the image enters conv_in as NHWC with its 3 channels zero-padded: 4 for the 4x4 stride-2 filter (K = 64), 16 for the 3x3 one (K = 144)
@@ -709,6 +720,7 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
     if (c.has_stage1 && h->w.count("stage1.encoder.conv_in.weight")) CHK(load_encoder(h));
     HIPCHK(stream_gemm_configure());
     HIPCHK(mfma_gemm_configure());
+    HIPCHK(split_kernels_configure());
     HIPCHK(hipDeviceSynchronize());
     h->finalized = true;
     return HQT_OK;
@@ -716,10 +728,19 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
 
 // ------------------------------------------------------------------------------------------ GEMM dispatch
 struct Mode {
-    bool fast;
+    bool fast = false;
+    bool split = false;     // stage 1 only: fp32 tensors, convolutions on the matrix cores with fp16 hi / lo operands (split_kernels.h)
     int act_dt() const { return fast ? DT_BF16 : DT_F32; }
     size_t act_sz() const { return fast ? 2 : 4; }
 };
+static int mode_of(int precision, bool stage1, Mode* md) {
+    if (precision == HQT_PRECISION_FAST) md->fast = true;
+    else if (precision == HQT_PRECISION_SPLIT && stage1) md->split = true;
+    else if (precision != HQT_PRECISION_EXACT)
+        return fail(HQT_ERR_INVALID, precision == HQT_PRECISION_SPLIT ? "HQT_PRECISION_SPLIT applies to the stage-1 entry points (decode / encode) only"
+                                                                       : "unknown precision %d", precision);
+    return HQT_OK;
+}
 
 // y = x W^T (+b)(act)(+resid): picks the MFMA kernels in FAST mode when the shape allows
 static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, int a_dt, int c_dt, hipStream_t st,
@@ -732,6 +753,20 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     if (g.alpha == 0.0f) g.alpha = 1.0f;
     if (g.lda == 0) g.lda = l.K;
     Timed t(h, tag, st);
+    if (g.Bw_lo) {                              // SPLIT: the caller packed the operand planes (s1_operand) after checking the shape
+        g.Bw = l.w16h; g.Bw_lo = l.w16l;
+        if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
+        if (g.conv_taps == 9) {
+            if (g.store == STORE_ROWS && h->gn_tiles && conv_halo_stats_ok(g.N, 32)) {   // every such output is normalised next
+                g.gn_part_out_d = reinterpret_cast<double*>(h->gn_tiles); g.gn_out_groups = 32;
+                h->gn_ready.tensor = g.C; h->gn_ready.tiles = split_conv3_tiles_per_image(g); h->gn_ready.dbl = true;
+            }
+            HIPCHK(launch_split_conv3(g, st));
+        } else {
+            HIPCHK(launch_split_gemm(g, st));
+        }
+        return HQT_OK;
+    }
     if (md.fast) {
         if (g.ln_parts) {                       // deferred LayerNorm: gamma-folded weights, folded bias; stream kernel only
             if (!l.wpk_ln || !stream_gemm_ok(g, a_dt, c_dt)) return fail(HQT_ERR_STATE, "deferred-LayerNorm GEMM without folded weights (%s)", tag);
@@ -756,7 +791,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
             if (g.conv_taps == 9 && g.store == STORE_ROWS && h->gn_tiles && conv_halo_ok(g, c_dt) && conv_halo_stats_ok(g.N, 32) &&
                 !getenv("HQT_NO_FUSED_GN")) {
                 g.gn_part_out = h->gn_tiles; g.gn_out_groups = 32;
-                h->gn_ready.tensor = g.C; h->gn_ready.tiles = conv_halo_tiles_per_image(g);
+                h->gn_ready.tensor = g.C; h->gn_ready.tiles = conv_halo_tiles_per_image(g); h->gn_ready.dbl = false;
             } else if (h->gn_ready.tensor == g.C) {
                 h->gn_ready.tensor = nullptr;                           // the tensor is being overwritten by something else
             }
@@ -768,6 +803,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         return HQT_OK;
     }
     g.Bw = l.w32;
+    if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
     HIPCHK(launch_gemm_generic(g, DT_F32, DT_F32, DT_F32, st));
     return HQT_OK;
 }
@@ -1123,7 +1159,7 @@ extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_s
     c.feed_bot = force_bot ? force_bot : h->codes_bot;
     c.logits_out = logits_out; c.out_top = h->codes_top; c.out_bot = h->codes_bot;
     c.st = (hipStream_t)stream;
-    c.md.fast = opts->precision == HQT_PRECISION_FAST;
+    CHK(mode_of(opts->precision, false, &c.md));
     if (cond) HIPCHK(hipMemcpyAsync(h->cond_buf, cond, (size_t)B * (cf.cond_type == HQT_COND_TEXT ? cf.ctx_len_txt : 1) * 8, hipMemcpyDefault, c.st));
     const int rc_run = sample_run(h, c);
     if (rc_run != HQT_OK) return rc_run;
@@ -1163,7 +1199,7 @@ extern "C" int hqt_sample_l3(hqt_handle* h, int B, const int64_t* cond, const hq
     c.feed_l2 = force2 ? force2 : h->codes_l2;
     c.logits_out = logits_out; c.out_top = h->codes_top; c.out_bot = h->codes_bot; c.out_l2 = h->codes_l2;
     c.st = (hipStream_t)stream;
-    c.md.fast = opts->precision == HQT_PRECISION_FAST;
+    CHK(mode_of(opts->precision, false, &c.md));
     if (cond) HIPCHK(hipMemcpyAsync(h->cond_buf, cond, (size_t)B * (cf.cond_type == HQT_COND_TEXT ? cf.ctx_len_txt : 1) * 8, hipMemcpyDefault, c.st));
     const int rc_run = sample_run(h, c);
     if (rc_run != HQT_OK) return rc_run;
@@ -1263,14 +1299,40 @@ struct S1Ctx {
     float *gn1, *gn2;
 };
 
+// SPLIT: can conv / GEMM `g` (A = an fp32 NHWC tensor) with filters `l` run on the matrix cores?  Shapes the split kernels do
+// not take (strided taps, channel counts that are not multiples of 64, ...) fall back to the fp32 vector-ALU kernel.
+static bool split_shape_ok(const hqt_handle* h, const GemmArgs& g, const Lin& l) {
+    if (!l.w16h) return false;
+    GemmArgs t = g;
+    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l;
+    if (t.lda == 0) t.lda = l.K;
+    return t.conv_taps == 9 ? split_conv3_ok(t) : split_gemm_ok(t);
+}
+// SPLIT operand pass: fp16 hi / lo planes of (GroupNorm + swish of) the fp32 tensor g->A into `tn`; the conv then reads `tn`.
+static int s1_split_pack(S1Ctx& c, GemmArgs* g, const float* stats, const float* gamma, const float* beta, int swish) {
+    hqt_handle* h = c.h;
+    const int hw_in = g->conv_taps ? ((g->H << g->conv_stride2) >> g->upsample) * ((g->W << g->conv_stride2) >> g->upsample) : 0;
+    const int C = g->conv_taps ? g->Cin : g->lda;
+    const int rows = g->conv_taps ? c.n : 1, per = g->conv_taps ? hw_in : g->M;
+    Timed t(h, "split_pack", c.st);
+    HIPCHK(launch_split_pack(reinterpret_cast<const float*>(g->A), reinterpret_cast<half_t*>(c.tn), stats, gamma, beta, rows, per, C, 32, swish, c.st));
+    g->A = c.tn;
+    g->Bw_lo = c.tn;                         // non-NULL marks the operand as split planes; run_linear substitutes the filter planes
+    if (!g->conv_taps) g->lda = 2 * C;
+    return HQT_OK;
+}
+
 // GroupNorm(+swish) in front of a conv.  EXACT: statistics pass, then the normalisation is applied inside
 // the conv's operand loader.  FAST: statistics pass + one bandwidth-bound apply pass into `tn`, so the MFMA
-// conv reads a plain bf16 tensor.  Sets the tensor the conv must read / fills the loader's GN fields.
-static int s1_norm(S1Ctx& c, const void* src, int C, int hw, float* stats, const float* gamma, const float* beta, int swish, GemmArgs* g) {
+// conv reads a plain bf16 tensor.  SPLIT: statistics (from the producing conv's epilogue when it left them), then the
+// operand pass writes the normalised tensor as fp16 hi / lo planes into `tn`; shapes the split kernels do not take run
+// the EXACT way.  Sets the tensor the conv must read / fills the loader's GN fields.
+static int s1_norm(S1Ctx& c, const void* src, int C, int hw, float* stats, const float* gamma, const float* beta, int swish, GemmArgs* g,
+                   const Lin* l = nullptr) {
     hqt_handle* h = c.h;
     hipStream_t st = c.st;
     if (c.md.fast) {
-        if (h->gn_ready.tensor == src) {     // the producing conv already reduced its tiles: only the fixed-order finalize is left
+        if (h->gn_ready.tensor == src && !h->gn_ready.dbl) {     // the producing conv already reduced its tiles: only the fixed-order finalize is left
             Timed t(h, "gn_stats", st);
             HIPCHK(launch_gn_finalize_tiles(h->gn_tiles, stats, c.n, h->gn_ready.tiles, hw, C, 32, 1e-6f, st));
         } else {
@@ -1279,10 +1341,25 @@ static int s1_norm(S1Ctx& c, const void* src, int C, int hw, float* stats, const
         }
         { Timed t(h, "gn_apply", st); HIPCHK(launch_gn_apply(src, c.tn, stats, gamma, beta, c.n, hw, C, 32, swish, st)); }
         g->A = c.tn;
+    } else if (c.md.split && l && split_shape_ok(h, *g, *l)) {
+        {
+            Timed t(h, "gn_stats", st);
+            if (h->gn_ready.tensor == src && h->gn_ready.dbl)
+                HIPCHK(launch_gn_finalize_tiles_d(reinterpret_cast<const double*>(h->gn_tiles), stats, c.n, h->gn_ready.tiles, hw, C, 32, 1e-6f, st));
+            else
+                HIPCHK(launch_gn_stats_fast(src, stats, h->gn_partial, c.n, hw, C, 32, 1e-6f, st, DT_F32));
+        }
+        CHK(s1_split_pack(c, g, stats, gamma, beta, swish));
     } else {
         { Timed t(h, "gn_stats", st); HIPCHK(launch_gn_stats(src, c.adt, stats, c.n, hw, C, 32, 1e-6f, st)); }
         with_gn(*g, stats, gamma, beta, swish);
     }
+    return HQT_OK;
+}
+// a conv without GroupNorm in front (conv_in, upsample conv, nin_shortcut, proj_out, the 1x1 convs around the quantiser): SPLIT
+// needs the operand planes, the other modes read the tensor as it is
+static int s1_plain(S1Ctx& c, GemmArgs* g, const Lin& l) {
+    if (c.md.split && split_shape_ok(c.h, *g, l)) CHK(s1_split_pack(c, g, nullptr, nullptr, nullptr, 0));
     return HQT_OK;
 }
 
@@ -1297,6 +1374,7 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
     if (l.kind == 0 || l.kind == 3) {
         const int ro = l.kind == 3 ? 2 * res : res;
         GemmArgs g = conv_args(cur, n, ro, l.cin, 9, l.kind == 3, t1, l.cout);
+        CHK(s1_plain(c, &g, l.conv1));
         CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
         std::swap(cur, t1);
     } else if (l.kind == 5) {               // Downsample (stage1/modules/layers.py:56-76): pad right / bottom by one, 3x3 stride 2
@@ -1306,25 +1384,26 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
         std::swap(cur, t1);
     } else if (l.kind == 1) {               // ResnetBlock (stage1/modules/layers.py:115-133)
         GemmArgs g = conv_args(cur, n, res, l.cin, 9, 0, t1, l.cout);
-        CHK(s1_norm(c, cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g));
+        CHK(s1_norm(c, cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g, &l.conv1));
         CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
         const void* shortcut = cur;
         void* outbuf = t2;
         if (l.cin != l.cout) {
             GemmArgs sc = conv_args(cur, n, res, l.cin, 1, 0, t2, l.cout);
+            CHK(s1_plain(c, &sc, l.nin));
             CHK(run_linear(h, md, sc, l.nin, adt, adt, st, "conv1x1"));
             shortcut = t2;
             outbuf = cur;                   // x is dead once the shortcut is computed
         }
         g = conv_args(t1, n, res, l.cout, 9, 0, outbuf, l.cout);
-        CHK(s1_norm(c, t1, l.cout, hw, c.gn2, l.n2_g, l.n2_b, 1, &g));
         g.resid = shortcut;
+        CHK(s1_norm(c, t1, l.cout, hw, c.gn2, l.n2_g, l.n2_b, 1, &g, &l.conv2));
         CHK(run_linear(h, md, g, l.conv2, adt, adt, st, "conv3x3"));
         if (outbuf == t2) std::swap(cur, t2);
     } else if (l.kind == 2) {               // AttnBlock (stage1/modules/layers.py:163-186)
         const int C = l.cin;
         GemmArgs g = conv_args(cur, n, res, C, 1, 0, h->aq, C);
-        CHK(s1_norm(c, cur, C, hw, c.gn1, l.n1_g, l.n1_b, 0, &g));
+        CHK(s1_norm(c, cur, C, hw, c.gn1, l.n1_g, l.n1_b, 0, &g, &l.q));
         const GemmArgs normed = g;           // same normalised input for q, k, v
         CHK(run_linear(h, md, g, l.q, adt, adt, st, "conv1x1"));
         g = normed; g.C = h->ak;
@@ -1357,6 +1436,7 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
         }
         g = conv_args(h->ao, n, res, C, 1, 0, t1, C);
         g.resid = cur;
+        CHK(s1_plain(c, &g, l.proj));
         CHK(run_linear(h, md, g, l.proj, adt, adt, st, "conv1x1"));
         std::swap(cur, t1);
     } else {
@@ -1386,6 +1466,7 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
     S1Ctx c{h, n, md, st, adt, h->act[0], h->act[1], h->act[2], h->act[3], h->gn, h->gn + (size_t)h->dec_chunk * 64};
     {
         GemmArgs g = conv_args(h->quant, n, r, l3 ? E : 2 * E, 1, 0, c.cur, cf.s1_z_channels);
+        CHK(s1_plain(c, &g, h->post_quant));
         CHK(run_linear(h, md, g, h->post_quant, adt, adt, st, "conv1x1"));
     }
     for (auto& l : h->dec) {
@@ -1393,8 +1474,8 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
         // norm_out -> swish -> conv_out, NCHW fp32 (+clamp)
         const int hw = l.res * l.res;
         GemmArgs g = conv_args(c.cur, n, l.res, l.cin, 9, 0, out, l.cout);
-        CHK(s1_norm(c, c.cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g));
         g.store = STORE_NCHW; g.rows_per_image = hw; g.clamp01 = clamp01;
+        CHK(s1_norm(c, c.cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g, &l.conv1));
         CHK(run_linear(h, md, g, l.conv1, adt, DT_F32, st, "conv_out"));
     }
     return HQT_OK;
@@ -1410,7 +1491,7 @@ static int decode_impl(hqt_handle* h, int B, const int64_t* code_t, const int64_
     if (B < 1) return fail(HQT_ERR_INVALID, "B must be >= 1");
     HIPCHK(hipSetDevice(h->device));
     Mode md;
-    md.fast = precision == HQT_PRECISION_FAST;
+    CHK(mode_of(precision, true, &md));
     const int r = h->dec.front().res;
     const int rt = levels == 3 ? r / 4 : r / 2, rm = r / 2;
     const size_t out_per = (size_t)h->cfg.s1_out_ch * h->dec.back().res * h->dec.back().res;
@@ -1458,9 +1539,10 @@ static int encode_chunk(hqt_handle* h, int n, const float* pixels, float* h_rows
         } else if (l.kind == 7) {           // norm_out -> swish -> conv_out (layers.py:289-292), then quant_conv_b (generator.py:299) in fp32 rows
             const int hw = l.res * l.res;
             GemmArgs g = conv_args(c.cur, n, l.res, l.cin, 9, 0, c.t1, l.cout);
-            CHK(s1_norm(c, c.cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g));
+            CHK(s1_norm(c, c.cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g, &l.conv1));
             CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
             GemmArgs q = conv_args(c.t1, n, l.res, l.cout, 1, 0, h_rows, cf.s1_embed_dim);
+            CHK(s1_plain(c, &q, h->quant_conv));
             CHK(run_linear(h, md, q, h->quant_conv, adt, DT_F32, st, "conv1x1"));
         } else {
             CHK(s1_layer(c, l));
@@ -1483,7 +1565,7 @@ extern "C" int hqt_encode(hqt_handle* h, int B, const float* pixels, int precisi
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     Mode md;
-    md.fast = precision == HQT_PRECISION_FAST;
+    CHK(mode_of(precision, true, &md));
     const int r = h->dec.front().res, E = cf.s1_embed_dim, R = cf.s1_resolution;
     for (int b0 = 0; b0 < B; b0 += h->dec_chunk) {
         const int n = std::min(h->dec_chunk, B - b0);

@@ -156,10 +156,12 @@ hipError_t launch_gn_apply(const void* x, void* y, const float* stats, const flo
                            int C, int groups, int swish, hipStream_t st);
 // FAST decoder GroupNorm statistics: coalesced partial sums per (image, pixel chunk), then a finalize pass
 hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, int B, int HW, int C, int groups, float eps,
-                                hipStream_t st);
+                                hipStream_t st, int dtype = DT_BF16);
 size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups);
 // statistics from the per-tile partials of a halo conv (fast_kernels.h: conv_halo_stats_ok)
 hipError_t launch_gn_finalize_tiles(const float* partial, float* stats, int B, int tiles, int HW, int C, int groups, float eps, hipStream_t st);
+// the same from the double partials a SPLIT conv leaves (split_kernels.h)
+hipError_t launch_gn_finalize_tiles_d(const double* partial, float* stats, int B, int tiles, int HW, int C, int groups, float eps, hipStream_t st);
 
 // ---- HQ-VAE encode side (generator.py:298-310, 530-568; quantizer.py:91-133)
 // fp32 NCHW image [B, 3, R, R] -> NHWC [B, R, R, cpad] (channels >= 3 are zero) in the activation dtype

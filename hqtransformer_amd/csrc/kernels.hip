@@ -775,7 +775,8 @@ __device__ __forceinline__ void unpack8(const uint4& raw, float (&f)[8]) {
     for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); f[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
 }
 // thread t owns channels 8 (t % vpp) .. + 7 of pixels (t / vpp) + k rpi (vpp = C / 8 vectors per pixel, rpi = 256 / vpp)
-__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double* partial, int HW, int C, int groups, int nchunk, int chunk_pix) {
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* x, double* partial, int HW, int C, int groups, int nchunk, int chunk_pix) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* part = reinterpret_cast<float*>(smem_raw);      // [rpi][C] sums, then [rpi][C] sums of squares; later [C] + [C] totals
     const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
@@ -785,23 +786,21 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double
     float s[8], q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] = 0.0f; q[i] = 0.0f; }
-    const bf16_t* base = x + ((long long)b * HW) * C + cv * 8;
+    const T* base = x + ((long long)b * HW) * C + cv * 8;
     int p = p0 + pl;
-    for (; p + 3 * rpi < p1; p += 4 * rpi) {                // four independent 16-B loads in flight
-        uint4 r[4];
+    for (; p + 3 * rpi < p1; p += 4 * rpi) {                // four independent pixel loads in flight
+        float f[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(base + (long long)(p + u * rpi) * C);
+        for (int u = 0; u < 4; ++u) ld8<T>(base + (long long)(p + u * rpi) * C, f[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            float f[8];
-            unpack8(r[u], f);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] += f[i] * f[i]; }
+            for (int i = 0; i < 8; ++i) { s[i] += f[u][i]; q[i] += f[u][i] * f[u][i]; }
         }
     }
     for (; p < p1; p += rpi) {
         float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(base + (long long)p * C), f);
+        ld8<T>(base + (long long)p * C, f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] += f[i] * f[i]; }
     }
@@ -828,7 +827,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, double
     }
 }
 // channel counts the fixed mapping does not cover (C / 8 does not divide 256): one thread per 16-B vector, LDS float atomics
-__global__ __launch_bounds__(256) void gn_partial_generic_kernel(const bf16_t* x, double* partial, int HW, int C, int groups, int nchunk, int chunk_pix) {
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_generic_kernel(const T* x, double* partial, int HW, int C, int groups, int nchunk, int chunk_pix) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ssum = reinterpret_cast<float*>(smem_raw);      // [C] sum, [C] sumsq
     float* ssq = ssum + C;
@@ -838,10 +838,10 @@ __global__ __launch_bounds__(256) void gn_partial_generic_kernel(const bf16_t* x
     __syncthreads();
     const int vec_per_pix = C / 8;
     const int total = (p1 - p0) * vec_per_pix;
-    const bf16_t* base = x + ((long long)b * HW + p0) * C;
+    const T* base = x + ((long long)b * HW + p0) * C;
     for (int v = threadIdx.x; v < total; v += 256) {
         float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(base + (long long)v * 8), f);
+        ld8<T>(base + (long long)v * 8, f);
         const int c8 = (v % vec_per_pix) * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { atomicAdd(&ssum[c8 + i], f[i]); atomicAdd(&ssq[c8 + i], f[i] * f[i]); }
@@ -871,12 +871,13 @@ __global__ void gn_finalize_kernel(const double* partial, float* stats, int nchu
 }
 // (mean, rstd) from the per-tile partials a halo conv left behind: one wave per (image, group); lane l sums tiles
 // l, l + 64, ... in order and the lanes are combined by the fixed xor tree -> bit-reproducible, double accumulation
-__global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* partial, float* stats, int tiles, int groups, double count, float eps) {
+template <typename TP>
+__global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const TP* partial, float* stats, int tiles, int groups, double count, float eps) {
     const int bg = blockIdx.x;                                  // b * groups + g
     const int b = bg / groups, g = bg % groups;
     double a = 0.0, q = 0.0;
     for (int t = threadIdx.x; t < tiles; t += 64) {
-        const float* p = partial + (((long long)b * tiles + t) * groups + g) * 2;
+        const TP* p = partial + (((long long)b * tiles + t) * groups + g) * 2;
         a += (double)p[0];
         q += (double)p[1];
     }
@@ -890,7 +891,11 @@ __global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* part
     }
 }
 hipError_t launch_gn_finalize_tiles(const float* partial, float* stats, int B, int tiles, int HW, int C, int groups, float eps, hipStream_t st) {
-    gn_finalize_tiles_kernel<<<B * groups, 64, 0, st>>>(partial, stats, tiles, groups, (double)HW * (C / groups), eps);
+    gn_finalize_tiles_kernel<float><<<B * groups, 64, 0, st>>>(partial, stats, tiles, groups, (double)HW * (C / groups), eps);
+    return hipGetLastError();
+}
+hipError_t launch_gn_finalize_tiles_d(const double* partial, float* stats, int B, int tiles, int HW, int C, int groups, float eps, hipStream_t st) {
+    gn_finalize_tiles_kernel<double><<<B * groups, 64, 0, st>>>(partial, stats, tiles, groups, (double)HW * (C / groups), eps);
     return hipGetLastError();
 }
 size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups) {
@@ -899,14 +904,17 @@ size_t gn_stats_fast_partial_elems(int B, int HW, int C, int groups) {
     return (size_t)B * ((HW + cp - 1) / cp) * groups * 2;
 }
 hipError_t launch_gn_stats_fast(const void* x, float* stats, double* partial, int B, int HW, int C, int groups, float eps,
-                                hipStream_t st) {
+                                hipStream_t st, int dtype) {
     const int cp = gn_chunk_pix(HW);
     const int nchunk = (HW + cp - 1) / cp;
     if (gn_fixed_ok(C)) {
         const int rpi = 256 / (C / 8);
-        gn_partial_kernel<<<B * nchunk, 256, (size_t)(2 * rpi + 2) * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk, cp);
+        const size_t smem = (size_t)(2 * rpi + 2) * C * sizeof(float);
+        if (dtype == DT_F32) gn_partial_kernel<float><<<B * nchunk, 256, smem, st>>>((const float*)x, partial, HW, C, groups, nchunk, cp);
+        else gn_partial_kernel<bf16_t><<<B * nchunk, 256, smem, st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk, cp);
     } else {
-        gn_partial_generic_kernel<<<B * nchunk, 256, 2 * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk, cp);
+        if (dtype == DT_F32) gn_partial_generic_kernel<float><<<B * nchunk, 256, 2 * C * sizeof(float), st>>>((const float*)x, partial, HW, C, groups, nchunk, cp);
+        else gn_partial_generic_kernel<bf16_t><<<B * nchunk, 256, 2 * C * sizeof(float), st>>>((const bf16_t*)x, partial, HW, C, groups, nchunk, cp);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -1,0 +1,586 @@
+// SPLIT precision kernels (see split_kernels.h): fp32-accurate 3x3 convolutions and GEMMs on the gfx950 matrix cores,
+// fp16 hi/lo operand planes, three v_mfma_f32_32x32x16_f16 per fragment pair, fp32 accumulation.
+#include "split_kernels.h"
+#include "gemm_generic.h"
+#include <algorithm>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+namespace {
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split2(float x, half_t& hi, half_t& lo) {
+    hi = (half_t)x;                                   // round to nearest even
+    lo = (half_t)((x - (float)hi) * SPLIT_SCALE);     // the difference and the scaling are exact in fp32
+}
+__device__ __forceinline__ unsigned pack_h2(half_t a, half_t b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// same XCD-aware tile order as the FAST conv kernels (mfma_gemm.hip): every XCD owns a contiguous run of tiles, n fastest
+__device__ __forceinline__ void xcd_tile(int& tile_m, int& tile_n) {
+    const int nx = gridDim.x, total = gridDim.x * gridDim.y;
+    int id = blockIdx.x + nx * blockIdx.y;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    tile_m = id / nx;
+    tile_n = id - tile_m * nx;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// finalize: filters -> hi / lo planes
+// ---------------------------------------------------------------------------------------------
+__global__ void split_f32_kernel(const float* __restrict__ src, half_t* __restrict__ hi, half_t* __restrict__ lo, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) split2(src[i], hi[i], lo[i]);
+}
+hipError_t launch_split_f32(const float* src, half_t* hi, half_t* lo, size_t n, hipStream_t st) {
+    split_f32_kernel<<<(int)std::min<size_t>((n + 255) / 256, 4096), 256, 0, st>>>(src, hi, lo, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// operand pass: fp32 NHWC -> [pixel][hi C | lo C] fp16, GroupNorm (+swish) applied on the way (layers.py:17-21,115-133).
+// Same arithmetic as the EXACT path's operand loader: (x - mean) * rstd * gamma + beta, t / (1 + expf(-t)).
+// A thread keeps the parameters of its 8 channels in registers and streams pixels, four loads in flight.
+// ---------------------------------------------------------------------------------------------
+static inline int sp_chunk_pix(int HW) { int c = HW / 32; return c < 64 ? 64 : (c > 1024 ? 1024 : c); }
+static inline bool sp_fixed_ok(int C) { return C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0; }
+
+template <bool GN>
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int groups,
+                                                         int swish, int nchunk, int chunk_pix) {
+    const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+    const int p0 = ch * chunk_pix, p1 = min(HW, p0 + chunk_pix);
+    const int vpp = C / 8, rpi = 256 / vpp;
+    const int cv = threadIdx.x % vpp, pl = threadIdx.x / vpp;
+    float mu[8], rs[8], gm[8], bt[8];
+    if (GN) {
+        const int cpg = C / groups;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = cv * 8 + i;
+            const float* st = stats + ((long long)b * groups + c / cpg) * 2;
+            mu[i] = st[0]; rs[i] = st[1]; gm[i] = gamma[c]; bt[i] = beta[c];
+        }
+    }
+    const float* xb = x + ((long long)b * HW) * C + cv * 8;
+    half_t* yb = y + ((long long)b * HW) * 2 * C + cv * 8;
+    auto emit = [&](const float4& a0, const float4& a1, int pix) {
+        float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        half_t hi[8], lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = f[i];
+            if (GN) {
+                t = (t - mu[i]) * rs[i] * gm[i] + bt[i];
+                if (swish) t = t / (1.0f + expf(-t));
+            }
+            split2(t, hi[i], lo[i]);
+        }
+        const u32x4 vh = {pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])};
+        const u32x4 vl = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])};
+        half_t* dst = yb + (long long)pix * 2 * C;
+        *reinterpret_cast<u32x4*>(dst) = vh;
+        *reinterpret_cast<u32x4*>(dst + C) = vl;
+    };
+    int p = p0 + pl;
+    for (; p + 3 * rpi < p1; p += 4 * rpi) {
+        float4 r0[4], r1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* s = xb + (long long)(p + u * rpi) * C;
+            r0[u] = *reinterpret_cast<const float4*>(s);
+            r1[u] = *reinterpret_cast<const float4*>(s + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) emit(r0[u], r1[u], p + u * rpi);
+    }
+    for (; p < p1; p += rpi) {
+        const float* s = xb + (long long)p * C;
+        emit(*reinterpret_cast<const float4*>(s), *reinterpret_cast<const float4*>(s + 4), p);
+    }
+}
+// channel counts the fixed thread <-> channel mapping does not cover
+__global__ __launch_bounds__(256) void split_pack_generic_kernel(const float* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, long long total,
+                                                                 int HW, int C, int groups, int swish) {
+    const int cpg = stats ? C / groups : 1;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / C;
+        const int c = (int)(i - pix * C);
+        float t = x[i];
+        if (stats) {
+            const float* st = stats + ((pix / HW) * groups + c / cpg) * 2;
+            t = (t - st[0]) * st[1] * gamma[c] + beta[c];
+            if (swish) t = t / (1.0f + expf(-t));
+        }
+        half_t hi, lo;
+        split2(t, hi, lo);
+        y[pix * 2 * C + c] = hi;
+        y[pix * 2 * C + C + c] = lo;
+    }
+}
+hipError_t launch_split_pack(const float* x, half_t* y, const float* stats, const float* gamma, const float* beta, int B, int HW,
+                             int C, int groups, int swish, hipStream_t st) {
+    if (sp_fixed_ok(C)) {
+        const int cp = sp_chunk_pix(HW), nchunk = (HW + cp - 1) / cp;
+        if (stats) split_pack_kernel<true><<<B * nchunk, 256, 0, st>>>(x, y, stats, gamma, beta, HW, C, groups, swish, nchunk, cp);
+        else split_pack_kernel<false><<<B * nchunk, 256, 0, st>>>(x, y, nullptr, nullptr, nullptr, HW, C, groups, 0, nchunk, cp);
+        return hipGetLastError();
+    }
+    const long long total = (long long)B * HW * C;
+    split_pack_generic_kernel<<<(int)std::min<long long>((total + 255) / 256, 256 * 16), 256, 0, st>>>(x, y, stats, gamma, beta, total, HW, C, groups, swish);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 'same' convolution, input patch resident in LDS (the SPLIT counterpart of conv3x3_halo_kernel, mfma_gemm.hip).
+// One workgroup = an 8 x 16 pixel tile of one image x BN output channels.  Per 64-channel chunk the (8+2) x (16+2) input
+// patch -- both planes -- is DMA'd into LDS once and serves all nine taps; the filters of one (tap, chunk) k-tile, both
+// planes, are DMA'd per k-tile.  Both operand kinds are double-buffered: 2 x 2 x 23 KiB of patch + 2 x 2 x 16 KiB of
+// filters = 156 KiB, one workgroup (4 waves, one per SIMD) per CU.  Per k-tile a wave issues 48 MFMAs (16 fragment pairs
+// x 3) against 32 ds_read_b128 and ~9 DMA pieces: three times the matrix work of the bf16 kernel per byte staged.
+// Weights are the MFMA A operand (D rows = channels, D cols = pixels): a lane owns 4 consecutive output channels of one
+// pixel per register quad; the epilogue stages the fp32 tile through the dead operand buffers and writes whole NHWC
+// rows (two 16-B stores per lane), adding bias and the fp32 residual and reducing the GroupNorm statistics of the
+// output in a fixed order (double partials per tile and group).
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int S_TY = 8, S_TX = 16, S_PITCH = S_TX + 2;
+constexpr int S_ROWS = (S_TY + 2) * S_PITCH;                    // 180 patch rows (pixels) of 128 B per plane
+constexpr int S_PIECES = (S_ROWS + 7) / 8;                      // 23 DMA pieces of 8 rows
+constexpr int S_PATCH_BYTES = S_PIECES * 1024;                  // per plane
+constexpr int S_CPITCH = 128 * 4 + 16;                          // fp32 staging row (bytes)
+constexpr int split_conv3_lds(int BN) { return 4 * S_PATCH_BYTES + 4 * BN * 128; }
+static_assert(128 * S_CPITCH <= split_conv3_lds(32), "epilogue staging must fit in the operand buffers");
+static_assert(split_conv3_lds(128) <= 160 * 1024, "LDS budget");
+}  // namespace
+
+template <bool NCHW, int BN>
+__global__ __launch_bounds__(256, 1) void conv3x3_split_kernel(GemmArgs g) {
+    static_assert(BN == 128 || (BN == 32 && NCHW), "the 32-channel variant exists for the NCHW conv_out store only");
+    constexpr int WMW = BN == 128 ? 2 : 4, FJ = BN == 128 ? 2 : 1, B_BYTES = BN * 128;
+    constexpr int FI = (S_TY / 2) / WMW;                            // 32-pixel fragments per wave (2 | 1)
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    auto PATCH = [&](int s, int plane) -> char* { return lds_raw + (size_t)(s * 2 + plane) * S_PATCH_BYTES; };
+    auto BT = [&](int s, int plane) -> char* { return lds_raw + 4 * S_PATCH_BYTES + (size_t)(s * 2 + plane) * B_BYTES; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
+    const int fr = lane & 31, fh = lane >> 5;
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int n0 = tile_n * BN;
+    const int tiles_x = g.W / S_TX, tiles_y = g.H / S_TY;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * S_TY, tx0 = (trem % tiles_x) * S_TX;
+    const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
+    const half_t* Abase = reinterpret_cast<const half_t*>(g.A);                 // [pixel][hi Cin | lo Cin]
+    const half_t* Bhi = reinterpret_cast<const half_t*>(g.Bw);
+    const half_t* Blo = reinterpret_cast<const half_t*>(g.Bw_lo);
+    const half_t* zero = reinterpret_cast<const half_t*>(g.zero_page);
+
+    constexpr int PPW = (S_PIECES + 3) / 4;                         // patch pieces per wave and plane
+    constexpr int BPW = BN / 32;                                    // filter pieces per wave and plane (4 | 1)
+    long long boff[BPW];
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int row = (wave * BPW + i) * 8 + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        boff[i] = (n0 + row < g.N) ? (long long)(n0 + row) * g.ldb + ch : -1;
+    }
+    auto issue_patch = [&](int c, int s) {
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            if (wave + 4 * t < S_PIECES) {                          // wave-uniform
+                const int q = (wave + 4 * t) * 8 + (lane >> 3);
+                const int qy = (q * 3641) >> 16, qx = q - qy * S_PITCH;             // q / 18 for q < 328
+                const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+                const int ch = ((lane & 7) ^ ((q >> 1) & 7)) * 8;
+                const bool in = q < S_ROWS && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                const half_t* src = Abase + (((long long)img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * (2 * g.Cin) + ch + c * 64;
+#pragma unroll
+                for (int plane = 0; plane < 2; ++plane) {
+                    const half_t* sp = in ? src + plane * g.Cin : zero;
+                    char* dst = PATCH(s, plane) + (wave + 4 * t) * 1024;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+            }
+        }
+    };
+    auto issue_b = [&](int k0, int s) {
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const half_t* sh = boff[i] >= 0 ? Bhi + boff[i] + k0 : zero;
+            const half_t* sl = boff[i] >= 0 ? Blo + boff[i] + k0 : zero;
+            char* dh = BT(s, 0) + (wave * BPW + i) * 1024;
+            char* dl = BT(s, 1) + (wave * BPW + i) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sh, (__attribute__((address_space(3))) void*)dh, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sl, (__attribute__((address_space(3))) void*)dl, 16, 0, 0);
+        }
+    };
+
+    f32x16 accm[FI][FJ], accx[FI][FJ];                              // main (hi x hi) and cross (hi x lo + lo x hi, scaled 2^11)
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.0f; accx[i][j][r] = 0.0f; }
+
+    int qbase[FI];                                                  // patch row of tap (0, 0) for this lane's pixel of fragment i
+#pragma unroll
+    for (int i = 0; i < FI; ++i) qbase[i] = (wm * (2 * FI) + i * 2 + (fr >> 4)) * S_PITCH + (fr & 15);
+    int brd[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) brd[j] = wn * 64 + j * 32 + fr;
+
+    auto compute = [&](int ps, int bs, int tapoff) {
+        const char* Ph = PATCH(ps, 0);
+        const char* Pl = PATCH(ps, 1);
+        const char* Wh = BT(bs, 0);
+        const char* Wl = BT(bs, 1);
+        int qa[FI], sw[FI];
+#pragma unroll
+        for (int i = 0; i < FI; ++i) { qa[i] = (qbase[i] + tapoff) * 128; sw[i] = ((qbase[i] + tapoff) >> 1) & 7; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks * 2 + fh;
+            half8 ah[FI], al[FI], wh[FJ], wl[FJ];
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int o = qa[i] + ((c ^ sw[i]) << 4);
+                ah[i] = *reinterpret_cast<const half8*>(Ph + o);
+                al[i] = *reinterpret_cast<const half8*>(Pl + o);
+            }
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const int o = brd[j] * 128 + ((c ^ ((brd[j] >> 1) & 7)) << 4);
+                wh[j] = *reinterpret_cast<const half8*>(Wh + o);
+                wl[j] = *reinterpret_cast<const half8*>(Wl + o);
+            }
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], accm[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], accx[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    float bv[8];                                        // epilogue bias of this thread's 8 channels, fetched under the main loop
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (BN == 128 && g.bias && n0 + (tid & 15) * 8 + e < g.N) ? g.bias[n0 + (tid & 15) * 8 + e] : 0.0f;
+    const int NC = g.Cin / 64, KT = NC * 9;
+    issue_patch(0, 0);
+    issue_b(0, 0);
+    __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    int kt = 0;
+#pragma unroll 1
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++kt) {
+            if (kt + 1 < KT) {
+                const int tn = tap == 8 ? 0 : tap + 1, cn = tap == 8 ? c + 1 : c;
+                issue_b(tn * g.Cin + cn * 64, (kt + 1) & 1);
+                if (tap == 0 && c + 1 < NC) issue_patch(c + 1, (c + 1) & 1);
+            }
+            const int t3 = (tap * 11) >> 5;            // tap / 3 for tap < 9
+            compute(c & 1, kt & 1, t3 * S_PITCH + (tap - 3 * t3));
+            __syncthreads();
+        }
+    }
+    // ---- epilogue.  D map: col = lane & 31 -> pixel fr of block i; row = (r & 3) + 8 (r >> 2) + 4 fh -> channel
+    if (NCHW) {                                        // conv_out: fp32 NCHW (+clamp); lanes = consecutive pixels of a row
+        float* Cb = reinterpret_cast<float*>(g.C);
+        const long long hw = (long long)g.H * g.W;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int py = wm * (2 * FI) + i * 2 + (fr >> 4);
+            const long long pix = (long long)(ty0 + py) * g.W + tx0 + (fr & 15);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = n0 + wn * 64 + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    if (n >= g.N) continue;
+                    float v = (accm[i][j][e] + accx[i][j][e] * SPLIT_INV) * g.alpha + (g.bias ? g.bias[n] : 0.0f);
+                    if (g.clamp01) v = fminf(fmaxf(0.5f * v + 0.5f, 0.0f), 1.0f);
+                    Cb[((long long)img * g.N + n) * hw + pix] = v;
+                }
+        }
+        return;
+    }
+    if constexpr (BN == 128) {
+        const long long pix0 = ((long long)img * g.H + ty0) * g.W + tx0;         // NHWC row of tile pixel (0, 0)
+        char* stage = lds_raw;                              // [128 pixels][S_CPITCH] fp32; every operand read is behind the last barrier
+        float* Cb = reinterpret_cast<float*>(g.C);
+        const float* Rb = reinterpret_cast<const float*>(g.resid);
+        const int c8 = (tid & 15) * 8;                      // 8 consecutive channels per thread, 16 threads per pixel row
+        const int nn = n0 + c8;
+        float gs[8], gq[8];                                 // GroupNorm statistics of this thread's channels
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int r = wm * 64 + i * 32 + fr;            // pixel within the staged 128
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int nl = wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV;
+                    *reinterpret_cast<f32x4*>(stage + r * S_CPITCH + nl * 4) = v;
+                }
+        }
+        __syncthreads();
+        if (nn < g.N) {                                 // split_conv3_ok(): N % 8 == 0, so a thread's 8 channels are all in or all out
+            long long moff[8];
+            f32x4 r0[8], r1[8];
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {      // residual rows first: sixteen 16-B loads in flight
+                const int r = pass * 16 + (tid >> 4);
+                moff[pass] = (pix0 + (long long)(r >> 4) * g.W + (r & 15)) * g.ldc + nn;
+                if (Rb) { r0[pass] = *reinterpret_cast<const f32x4*>(Rb + moff[pass]); r1[pass] = *reinterpret_cast<const f32x4*>(Rb + moff[pass] + 4); }
+            }
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int r = pass * 16 + (tid >> 4);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * S_CPITCH + c8 * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * S_CPITCH + c8 * 4 + 16);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
+                if (Rb) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[pass][e]; v[4 + e] += r1[pass][e]; }
+                }
+                const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(Cb + moff[pass]) = o0;
+                *reinterpret_cast<f32x4*>(Cb + moff[pass] + 4) = o1;
+                if (g.gn_part_out_d) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+                }
+            }
+        }
+        if (g.gn_part_out_d) {                              // uniform branch (kernel argument): barriers are safe here
+            __syncthreads();                                // every staged value has been read
+            float* redw = reinterpret_cast<float*>(lds_raw);                    // [16 pixel rows][128 channels][2]; zeros from idle threads
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
+                redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
+            }
+            __syncthreads();
+            const float* red = reinterpret_cast<const float*>(lds_raw);
+            if (tid < 128) {                                // one channel per thread, then its group (cpg consecutive channels = lanes)
+                double sa = 0.0, sq = 0.0;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) { sa += (double)red[((rg * 128) + tid) * 2]; sq += (double)red[((rg * 128) + tid) * 2 + 1]; }
+                const int cpg = g.N / g.gn_out_groups;
+                for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
+                const int ch = n0 + tid;
+                if (ch < g.N && (tid & (cpg - 1)) == 0) {
+                    double* pp = g.gn_part_out_d + (((long long)img * (tiles_x * tiles_y) + trem) * g.gn_out_groups + ch / cpg) * 2;
+                    pp[0] = sa; pp[1] = sq;
+                }
+            }
+        }
+    }
+}
+
+bool split_conv3_ok(const GemmArgs& g) {
+    if (g.conv_taps != 9 || g.conv_stride2 || g.conv_nopad || !g.zero_page || g.gn_stats || g.a_packed_mb || g.batch > 1) return false;
+    if (!g.Bw_lo || g.Cin % 64 != 0 || g.ldb % 8 != 0 || g.K != 9 * g.Cin) return false;
+    if (g.H % S_TY != 0 || g.W % S_TX != 0 || g.M % (g.H * g.W) != 0) return false;
+    if (g.act != ACT_NONE) return false;
+    if (g.store == STORE_NCHW) return !g.resid && g.N <= 32;
+    return g.store == STORE_ROWS && g.rows_per_group == 0 && g.ldc % 8 == 0 && g.N % 8 == 0;
+}
+int split_conv3_tiles_per_image(const GemmArgs& g) { return (g.H / S_TY) * (g.W / S_TX); }
+hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st) {
+    if (g.store == STORE_NCHW) {
+        const dim3 grid(1, g.M / (S_TY * S_TX), 1);
+        conv3x3_split_kernel<true, 32><<<grid, 256, split_conv3_lds(32), st>>>(g);
+    } else {
+        const dim3 grid((g.N + 127) / 128, g.M / (S_TY * S_TX), 1);
+        conv3x3_split_kernel<false, 128><<<grid, 256, split_conv3_lds(128), st>>>(g);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolutions / plain GEMMs: C[m][n] = alpha sum_k A[m][k] W[n][k] (+bias) (+resid), 128 x 128 x 64 tiles, both
+// operands (two planes each) staged by LDS-DMA into two LDS stages (128 KiB, one workgroup per CU), 4 waves x (64 x 64).
+// A rows are [m][hi K | lo K] (lda elements per row, lo at +a_lo_off); same source-side bank swizzle as conv_glds_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void split_gemm_kernel(GemmArgs g, int a_lo_off) {
+    constexpr int BM = 128, BN = 128, BKG = 64, ROWB = 128, OPB = 128 * ROWB;       // bytes per operand plane and stage
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];                   // [2 stages][A hi, A lo, B hi, B lo][128 * 128 B]
+    auto LDS = [&](int stage, int op) -> char* { return lds_raw + (size_t)(stage * 4 + op) * OPB; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bz = blockIdx.z;
+    int tile_m, tile_n;
+    xcd_tile(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const half_t* Abase = reinterpret_cast<const half_t*>(g.A) + (long long)bz * g.a_batch_stride;
+    const half_t* Bhi = reinterpret_cast<const half_t*>(g.Bw) + (long long)bz * g.b_batch_stride;
+    const half_t* Blo = reinterpret_cast<const half_t*>(g.Bw_lo) + (long long)bz * g.b_batch_stride;
+    const half_t* zero = reinterpret_cast<const half_t*>(g.zero_page);
+    long long aoff[4], boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        aoff[i] = (m0 + row < g.M) ? (long long)(m0 + row) * g.lda + ch : -1;
+        boff[i] = (n0 + row < g.N) ? (long long)(n0 + row) * g.ldb + ch : -1;
+    }
+    auto issue = [&](int kt, int buf) {
+        const int k0 = kt * BKG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const half_t* s[4] = {aoff[i] >= 0 ? Abase + aoff[i] + k0 : zero, aoff[i] >= 0 ? Abase + aoff[i] + a_lo_off + k0 : zero,
+                                  boff[i] >= 0 ? Bhi + boff[i] + k0 : zero, boff[i] >= 0 ? Blo + boff[i] + k0 : zero};
+#pragma unroll
+            for (int op = 0; op < 4; ++op) {
+                char* dst = LDS(buf, op) + (wave * 4 + i) * 8 * ROWB;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s[op],
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.0f; accx[i][j][r] = 0.0f; }
+    const int KT = g.K / BKG;
+    const int fr = lane & 31, fh = lane >> 5;
+    auto compute = [&](int buf) {
+        const char *Ah = LDS(buf, 0), *Al = LDS(buf, 1), *Wh = LDS(buf, 2), *Wl = LDS(buf, 3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks * 2 + fh;
+            half8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 64 + i * 32 + fr;
+                const int o = r * ROWB + ((c ^ ((r >> 1) & 7)) << 4);
+                ah[i] = *reinterpret_cast<const half8*>(Ah + o);
+                al[i] = *reinterpret_cast<const half8*>(Al + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wn * 64 + j * 32 + fr;
+                const int o = r * ROWB + ((c ^ ((r >> 1) & 7)) << 4);
+                wh[j] = *reinterpret_cast<const half8*>(Wh + o);
+                wl[j] = *reinterpret_cast<const half8*>(Wl + o);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {                               // D rows = n, cols = m
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], accm[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], accx[i][j], 0, 0, 0);
+                }
+        }
+    };
+    issue(0, 0);
+    __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+        compute(buf);
+        __syncthreads();
+    }
+    // epilogue: a lane owns 4 consecutive columns of one row per register quad
+    float* Cb = reinterpret_cast<float*>(g.C) + (long long)bz * g.c_batch_stride;
+    const float* Rb = g.resid ? reinterpret_cast<const float*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
+    const bool plain = g.store == STORE_ROWS && g.rows_per_group == 0 && (g.N & 3) == 0 && (g.ldc & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int n4 = n0 + wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                if (n4 >= g.N) continue;
+                float s[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV;
+                if (plain) {
+                    const long long idx = (long long)m * g.ldc + n4;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(s[e] * g.alpha + (g.bias ? g.bias[n4 + e] : 0.0f), g.act);
+                    if (Rb) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(Rb + idx);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    const f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(Cb + idx) = o;
+                } else if (g.store == STORE_NCHW) {         // per-image transposed store (V^T of the decoder attention: layers.py:180-183)
+                    const int img = m / g.rows_per_image, pix = m - img * g.rows_per_image;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n4 + e < g.N) {
+                            float x = s[e] * g.alpha + (g.bias ? g.bias[n4 + e] : 0.0f);
+                            if (g.clamp01) x = fminf(fmaxf(0.5f * x + 0.5f, 0.0f), 1.0f);
+                            Cb[((long long)img * g.N + n4 + e) * g.rows_per_image + pix] = x;
+                        }
+                } else {                                      // ragged N / ldc: element-wise rows
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n4 + e < g.N) {
+                            const long long idx = (long long)m * g.ldc + n4 + e;
+                            float x = apply_act(s[e] * g.alpha + (g.bias ? g.bias[n4 + e] : 0.0f), g.act);
+                            if (Rb) x += Rb[idx];
+                            Cb[idx] = x;
+                        }
+                }
+            }
+    }
+}
+
+bool split_gemm_ok(const GemmArgs& g) {
+    if (!g.zero_page || !g.Bw_lo || g.gn_stats || g.a_packed_mb || g.a_rows_per_group) return false;
+    if (g.conv_taps > 1 || g.conv_stride2 || g.upsample) return false;
+    if (g.K % 64 != 0 || g.ldb % 8 != 0) return false;
+    if (g.store != STORE_ROWS && g.store != STORE_NCHW) return false;
+    if (g.store == STORE_ROWS && g.rows_per_group != 0) return false;
+    if (g.store == STORE_NCHW && (g.resid || g.act != ACT_NONE)) return false;
+    return true;
+}
+hipError_t launch_split_gemm(const GemmArgs& g0, hipStream_t st) {
+    GemmArgs g = g0;
+    if (g.conv_taps == 1) { g.lda = 2 * g.Cin; g.conv_taps = 0; }        // a 1x1 conv over [pixel][hi C | lo C] is a plain GEMM with lda = 2 C
+    const int a_lo_off = g.lda / 2;
+    const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
+    split_gemm_kernel<<<grid, 256, 2 * 4 * 128 * 128, st>>>(g, a_lo_off);
+    return hipGetLastError();
+}
+
+hipError_t split_kernels_configure() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(128));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(32));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 128);
+}

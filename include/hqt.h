@@ -40,8 +40,13 @@ enum { HQT_COND_NONE = 0, HQT_COND_CLASS = 1, HQT_COND_TEXT = 2 };
 enum { HQT_EMB_TRANSFORMER1 = 0, HQT_EMB_REDUCE = 1 };
 /* arithmetic of a call.  EXACT = fp32 weights/activations/accumulation (what the reference computes
  * on its CPU path, where autocast is off); FAST = bf16 weights and MFMA, fp32 accumulation, fp32
- * softmax/normalisation/sampler (the counterpart of the reference's use_fp16=True autocast path). */
-enum { HQT_PRECISION_EXACT = 0, HQT_PRECISION_FAST = 1 };
+ * softmax/normalisation/sampler (the counterpart of the reference's use_fp16=True autocast path).
+ * SPLIT (stage-1 entry points: decode / encode) = fp32 tensors, fp32 GroupNorm / softmax / activations, and the
+ * convolutions on the matrix cores with every fp32 operand carried as two fp16 values (hi, lo * 2^11): three
+ * v_mfma_f32_32x32x16_f16 per product term, fp32 accumulation -- fp32-accurate (2^-22 per operand), what the reference's
+ * fp32 decode (measure_throughput/__main__.py:108-113, outside autocast) computes up to summation order, at matrix-core
+ * speed; layers whose shapes the split kernels do not take run the EXACT kernels. */
+enum { HQT_PRECISION_EXACT = 0, HQT_PRECISION_FAST = 1, HQT_PRECISION_SPLIT = 2 };
 enum { HQT_DTYPE_F32 = 0 };
 
 typedef struct hqt_handle hqt_handle;

@@ -1,0 +1,126 @@
+"""SPLIT precision (fp32-accurate convolutions on the matrix cores: fp16 hi/lo operands, fp32 accumulation) against the
+CPU oracle and the reference-generated fixtures.  The bar is the EXACT one: decoded pixels within 1e-4 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hqtransformer_amd import synth
+from hqtransformer_amd._lib import PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT
+from hqtransformer_amd.engine import Engine
+from hqtransformer_amd.spec import Stage1Spec
+from oracle import hqt_oracle as O
+from tests.helpers import load, stage1_from_fixture
+
+pytestmark = pytest.mark.gpu
+PIXEL_TOL = 1e-4
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def engine_s1(spec, weights, max_batch):
+    e = Engine(None, spec, dev(), max_batch)
+    e.load(stage1=weights)
+    e.finalize()
+    return e
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def kernels_run(eng, fn):
+    eng.timing(True)
+    eng.timing_reset()
+    out = fn()
+    torch.cuda.synchronize()
+    rep = eng.timing_report()
+    eng.timing(False)
+    return out, rep
+
+
+def test_split_decode_wide_config_vs_oracle():
+    """A config every layer of which the split kernels take (channel counts multiples of 64): 3x3 halo-tile convs incl. the
+    upsampling one and conv_out's NCHW store, the 1x1 GEMM kernel (post_quant, nin_shortcut, attention q/k/v/proj with the V^T
+    store), fused GroupNorm statistics -- pixels within 1e-4 of the oracle, on a NaN-poisoned workspace, and batch-invariant."""
+    spec = Stage1Spec(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=64, z_channels=64,
+                      embed_dim=32, n_embed=256)
+    weights = synth.stage1_weights(spec, 31, 'fixture')
+    r = np.random.default_rng(32)
+    ct, cb = r.integers(0, 256, (3, 8, 8)), r.integers(0, 256, (3, 16, 16))
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    os.environ['HQT_POISON_WORKSPACE'] = '1'
+    try:
+        eng = engine_s1(spec, weights, 3)
+    finally:
+        del os.environ['HQT_POISON_WORKSPACE']
+    tct, tcb = torch.from_numpy(ct), torch.from_numpy(cb)
+    got, rep = kernels_run(eng, lambda: np_(eng.decode(tct, tcb, precision=PRECISION_SPLIT)))
+    assert rep.get('split_pack', (0, 0))[0] >= 10, rep            # the matrix-core path ran (not the EXACT fallback)
+    err = np.abs(got - want).max()
+    assert err <= PIXEL_TOL, err
+    exact = np_(eng.decode(tct, tcb, precision=PRECISION_EXACT))
+    assert np.abs(exact - want).max() <= PIXEL_TOL
+    one = np_(eng.decode(tct[1:2], tcb[1:2], precision=PRECISION_SPLIT))
+    assert np.array_equal(one[0], got[1])                          # same bits whatever the batch
+    again = np_(eng.decode(tct, tcb, precision=PRECISION_SPLIT))
+    assert np.array_equal(again, got)                              # run-to-run deterministic
+    cl = np_(eng.decode(tct, tcb, precision=PRECISION_SPLIT, clamp01=True))
+    np.testing.assert_allclose(cl, O.postprocess(want), atol=PIXEL_TOL)
+    top_only = np_(eng.decode(tct[:1], None, precision=PRECISION_SPLIT))
+    assert np.abs(top_only - O.OracleStage1(spec, weights).decode_code(ct[:1], None)).max() <= PIXEL_TOL
+
+
+def test_split_decode_reference_fixtures():
+    """The reference's own decode_code outputs (fixtures G5): narrow layers fall back to the fp32 vector kernels inside SPLIT
+    mode; every mix of the two must stay within 1e-4."""
+    for name in ('g5_decode_64.npz', 'g5_decode_256.npz'):
+        fx = load(name)
+        spec, weights = stage1_from_fixture(fx)
+        eng = engine_s1(spec, weights, 2)
+        px = np_(eng.decode(torch.from_numpy(fx['code_t']), torch.from_numpy(fx['code_b']), precision=PRECISION_SPLIT))
+        assert np.abs(px - fx['pixels']).max() <= PIXEL_TOL, name
+
+
+def test_imagenet_size_decoder_all_precisions_vs_oracle():
+    """The benchmark's own decoder (configs/imagenet-12l.yaml: ch 128, ch_mult [1, 2, 4, 4], 53.95 M parameters, 256 x 256)
+    on 2 images of random codes against the CPU oracle: EXACT and SPLIT within 1e-4 (north_star's pixel bar), FAST (bf16)
+    within max 0.1 / mean 0.01."""
+    from hqtransformer_amd.config import load_config
+    from hqtransformer_amd.spec import stage1_spec_from_config
+    spec = stage1_spec_from_config(load_config(os.path.join(ROOT, 'configs', 'imagenet-12l.yaml')))
+    weights = synth.stage1_weights(spec, 1, 'bench')
+    r = np.random.default_rng(7)
+    ct, cb = r.integers(0, spec.n_embed, (2, 8, 8)), r.integers(0, spec.n_embed, (2, 16, 16))
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    eng = engine_s1(spec, weights, 2)
+    tct, tcb = torch.from_numpy(ct), torch.from_numpy(cb)
+    split, rep = kernels_run(eng, lambda: np_(eng.decode(tct, tcb, precision=PRECISION_SPLIT)))
+    assert 'conv3x3' in rep and rep.get('split_pack', (0, 0))[0] >= 30, rep
+    e_split = np.abs(split - want).max()
+    assert e_split <= PIXEL_TOL, e_split
+    exact = np_(eng.decode(tct, tcb, precision=PRECISION_EXACT))
+    e_exact = np.abs(exact - want).max()
+    assert e_exact <= PIXEL_TOL, e_exact
+    fast = np_(eng.decode(tct, tcb, precision=PRECISION_FAST))
+    d = np.abs(fast - want)
+    assert d.max() <= 0.1 and d.mean() <= 1e-2, (d.max(), d.mean())
+    print(f'imagenet-size decoder vs oracle: exact {e_exact:.2e}, split {e_split:.2e}, fast max {d.max():.3f} mean {d.mean():.4f}, '
+          f'output std {want.std():.3f}')
+
+
+def test_split_is_rejected_by_the_sampler():
+    from tests.helpers import stage2_from_fixture
+    fx = load('g4_tiny_cls.npz')
+    spec, weights = stage2_from_fixture(fx)
+    e = Engine(spec, None, dev(), 2, 8)
+    e.load(stage2=weights)
+    e.finalize()
+    from hqtransformer_amd._lib import HqtError
+    with pytest.raises(HqtError):
+        e.sample(2, torch.tensor([1, 2]), 4, precision=PRECISION_SPLIT)
