@@ -48,7 +48,12 @@ def parse():
     p.add_argument('--warmup', type=int, default=3)
     p.add_argument('--config', default=os.path.join(ROOT, 'configs', 'imagenet-12l.yaml'))
     p.add_argument('--batch', type=int, default=64, help='images per GPU per step')
-    p.add_argument('--precision', choices=['fast', 'exact'], default='fast')
+    p.add_argument('--precision', choices=['fast', 'exact'], default='fast',
+                   help='AR loop arithmetic: fast = bf16 MFMA (the counterpart of the reference harness\'s fp16 autocast), exact = fp32')
+    p.add_argument('--decode-precision', choices=['split', 'fast', 'exact'], default=None,
+                   help='HQ-VAE decode arithmetic.  The reference harness decodes outside autocast, i.e. in fp32 (measure_throughput/__main__.py:108-113): '
+                        'the default is split = fp32-accurate on the matrix cores (fp16 hi/lo operands, fp32 accumulate; pixels within 1e-4 of the '
+                        'fp32 oracle); fast = bf16 (NOT like for like: 0.04 max pixel error), exact = fp32 FMA chains on the vector ALUs')
     p.add_argument('--gather', choices=['pixels', 'codes', 'none'], default='none',
                    help='optional RCCL gather of every step\'s result to rank 0; the path itself has no exchange step, so the default is none')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -151,6 +156,7 @@ def main():
     if args.positions:
         n_pos = min(n_pos, args.positions)
     fast = args.precision == 'fast'
+    dec_prec = args.decode_precision or ('split' if fast else 'exact')
     classes = synth.class_ids(1000 + rank, args.steps + args.warmup + 4, max(s2.n_classes, 1))
     txt_cond = s2.cond == 2                 # text-conditional configs (BASELINE configs[4]): synthetic prompt ids, resident in HBM
     prompts = [torch.from_numpy(synth.text_ids(2000 + 131 * rank + i, B, s2.ctx_len_txt, s2.vocab_txt)).to(dev)
@@ -178,11 +184,11 @@ def main():
 
     def decode(ct, cb, m=None):
         if three:
-            return (m or model).stage1.decode_sequences([ct] + list(cb), precision=args.precision, clamp01=True)
+            return (m or model).stage1.decode_sequences([ct] + list(cb), precision=dec_prec, clamp01=True)
         if n_pos < n_full:      # debug runs: pad the code grids so the decoder still sees full-size inputs
             ct = torch.cat([ct, ct.new_zeros(B, n_full - n_pos)], 1)
             cb = torch.cat([cb, cb.new_zeros(B, n_full - n_pos, 4)], 1)
-        return (m or model).stage1.decode_sequences(ct, cb, precision=args.precision, clamp01=True)
+        return (m or model).stage1.decode_sequences(ct, cb, precision=dec_prec, clamp01=True)
 
     def step(i, graph=True):
         ct, cb = sample_codes(i, graph and not args.no_graph)
@@ -224,13 +230,13 @@ def main():
     debug_short = n_pos < n_full            # --positions (counter collection): the padded decode of step(), one lane, no pipeline
     for li in range(0 if debug_short else max(inflight, args.warmup)):  # every lane at least once: workspace, graph capture
         pipe.submit(B, cond_of(li), seed=1000 + li, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
-                    use_graph=not args.no_graph, after=after)
+                    use_graph=not args.no_graph, after=after, precision=dec_prec)
     pipe.drain()
     barrier()
     t0 = time.perf_counter()
     kept = [step(args.warmup + k) for k in range(args.steps)] if debug_short else \
            [pipe.submit(B, cond_of(args.warmup + k), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
-                        sample_offset=rank * B, use_graph=not args.no_graph, after=after,
+                        sample_offset=rank * B, use_graph=not args.no_graph, after=after, precision=dec_prec,
                         order_after_current=not os.environ.get('HQT_BENCH_NO_ORDER')) for k in range(args.steps)]
     pipe.drain()
     barrier()
@@ -288,7 +294,11 @@ def main():
             'config': {'workload': (f'text-to-image ({s2.ctx_len_txt}-token synthetic prompts, prefill + ' if txt_cond else 'imagenet256-classcond (') + f'hq-vae({"8x8+16x16+32x32, three code levels" if three else "8x8+16x16"})+hq-transformer {s2.n_layers}L/{s2.embed_dim}d), '
                                    f'batch {B}/GPU, {n_pos} top positions, top_k=top_p=None, T=[1,1]',
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
-                       'precision': 'FAST: bf16 weights+MFMA, fp32 accumulate' if fast else 'EXACT: fp32',
+                       'precision': {'ar': 'FAST: bf16 weights + MFMA, fp32 accumulate / LayerNorm / softmax / sampler (the reference harness samples under fp16 autocast)' if fast else 'EXACT: fp32',
+                                     'decode': {'split': 'SPLIT: fp32-accurate on the matrix cores (fp16 hi/lo operands, 3 MFMAs per term, fp32 accumulate); pixels within 1e-4 of the fp32 oracle '
+                                                         '(the reference harness decodes in fp32, outside autocast)',
+                                                'fast': 'FAST: bf16 MFMA (0.04 max pixel error: NOT the reference harness\'s fp32 decode)',
+                                                'exact': 'EXACT: fp32 FMA chains on the vector ALUs'}[dec_prec]},
                        'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph,
                        'pipeline': (f'{inflight} steps in flight per GPU (round-robin over {inflight} lanes: own HIP stream, KV cache and '
                                     f'activations, shared weights, throughput-oriented GEMM tiles); each step is one full batch-{B} pass') if inflight > 1 else 'serial'},
@@ -356,11 +366,17 @@ def main():
         if conv_ms > 0:
             n_l = sum(v[0] for v in conv.values())
             ach = cflops / (conv_ms * 1e-3) / 1e12
-            peak = MFMA_BF16_PEAK_TFLOPS if fast else F32_PEAK_TFLOPS
-            fam.append({'kernel': 'conv3x3_halo_kernel (+ conv_glds_kernel for 1x1): HQ-VAE decoder conv family', 'bound': 'mfma', 'achieved': round(ach, 2),
-                        'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': pmc_traffic('decoder_conv'), 'launches': n_l,
+            peak = MFMA_BF16_PEAK_TFLOPS if dec_prec != 'exact' else F32_PEAK_TFLOPS
+            mfma_per_flop = 3 if dec_prec == 'split' else 1           # SPLIT issues three fp16 MFMAs per product term
+            kname = {'split': 'conv3x3_split_wide_kernel (+ split_gemm_kernel for 1x1): HQ-VAE decoder conv family, fp16 hi/lo split operands',
+                     'fast': 'conv3x3_halo_kernel (+ conv_glds_kernel for 1x1): HQ-VAE decoder conv family, bf16',
+                     'exact': 'gemm_tile_kernel: HQ-VAE decoder conv family, fp32 vector ALUs'}[dec_prec]
+            fam.append({'kernel': kname, 'bound': 'mfma', 'achieved': round(ach * mfma_per_flop, 2),
+                        'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach * mfma_per_flop / peak, 4), 'traffic': pmc_traffic('decoder_conv'), 'launches': n_l,
                         'avg_launch_us': round(1000 * conv_ms / n_l, 3), 'total_ms': round(conv_ms, 3),
-                        'algorithmic_flops_per_launch': round(cflops / n_l)})
+                        'algorithmic_flops_per_launch': round(cflops / n_l), 'matrix_flops_per_algorithmic_flop': mfma_per_flop,
+                        'achieved_algorithmic_tflops': round(ach, 2),
+                        'note': 'achieved / peak count the MFMA work actually issued (3x the algorithmic FLOPs in SPLIT precision) against the dense f16/bf16 MFMA peak'})
         fam.sort(key=lambda f: -f['total_ms'])
         if fam:
             out['roofline'] = fam[0]

@@ -8,8 +8,9 @@ Same dot-list keys and defaults (``Experiment`` dataclass, :34-48), same loop ac
 "ar", then code rearrange + ``stage1.decode_code`` + ``clamp(0.5 x + 0.5, 0, 1)`` timed as "decode", GPU events for
 both, and the same printed lines (``ms/sample (ar: .., decode: ..)``).  Random-init weights, like the reference.
 Differences, stated: the whole batch is decoded in one call instead of ``batch_size`` calls of one image
-(``decode_batch=1`` restores the reference's chunking), and ``decode_precision=exact`` selects the reference's
-fp32 decode arithmetic (default ``fast`` = bf16 MFMA).  ``inflight=N`` (default 1 = the reference's order) keeps N
+(``decode_batch=1`` restores the reference's chunking).  The reference decodes in fp32 (outside autocast, :108-113); the
+default ``decode_precision=split`` is fp32-accurate on the matrix cores (pixels within 1e-4 of the fp32 result), ``exact`` runs
+fp32 FMA chains on the vector ALUs, ``fast`` bf16 MFMA (faster, 0.04 max pixel error).  ``inflight=N`` (default 1 = the reference's order) keeps N
 iterations in flight on N lanes (``hqtransformer_amd.pipeline``): same iterations, same accounting of the loop's wall
 time; the per-phase figures then are lane times, which overlap.
 """
@@ -27,7 +28,7 @@ from .models import ImageGPT2
 from .sampling import rearrange_codes, rearrange_codes3, sampling_hqtransformer, sampling_ihqgpt
 
 EXPERIMENT_DEFAULTS = dict(f=32, model='huge', d=4, c=16384, batch_size=50, n_loop=6, warmup=1, model_path='',
-                           top_resolution=8, code_levels=2, decode_batch=0, decode_precision='fast', seed=0, inflight=1)
+                           top_resolution=8, code_levels=2, decode_batch=0, decode_precision='split', seed=0, inflight=1)
 
 
 def iterations_per_loop(batch_size: int) -> int:

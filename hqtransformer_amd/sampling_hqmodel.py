@@ -39,7 +39,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--num-classes', type=int, default=1000)
     p.add_argument('--samples-per-class', type=int, default=None, help='default 50000 // num_classes')
-    p.add_argument('--decode-precision', choices=['exact', 'fast'], default='exact')
+    p.add_argument('--decode-precision', choices=['split', 'exact', 'fast'], default='split',
+                   help='the reference decodes in fp32: split = fp32-accurate on the matrix cores (default), exact = fp32 vector ALUs, fast = bf16')
     return p
 
 

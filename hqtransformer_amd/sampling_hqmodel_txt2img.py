@@ -46,7 +46,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--reference-root', type=str, default=os.environ.get('HQT_REFERENCE_ROOT'),
                    help='checkout of kakaobrain/hqtransformer to take the bundled bpe-16k vocabulary from')
     p.add_argument('--synthetic-prompts', type=int, default=0, help='N random-id prompts instead of captions (smoke runs)')
-    p.add_argument('--decode-precision', choices=['exact', 'fast'], default='exact')
+    p.add_argument('--decode-precision', choices=['split', 'exact', 'fast'], default='split',
+                   help='the reference decodes in fp32: split = fp32-accurate on the matrix cores (default), exact = fp32 vector ALUs, fast = bf16')
     return p
 
 

@@ -1,0 +1,91 @@
+// Micro-benchmark: the SPLIT 3x3 conv kernel (fp16 hi/lo operands, 3 MFMAs per term) on the HQ-VAE decoder's layer shapes
+// (batch 64), with ablations that separate the epilogue, the DMA, the fragment reads and the bare MFMA stream.
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/micro/bench_split.hip -o tools/micro/bench_split
+#include "../../hqtransformer_amd/csrc/split_conv.hip"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Shape { const char* name; int res, cin, cout, up; };
+
+template <int PC, int ABL>
+static float run(const GemmArgs& g, hipStream_t st, int reps) {
+    const dim3 grid((g.N + 127) / 128, g.M / 128, 1);
+    auto* k = conv3x3_split_kernel<false, 128, PC, ABL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(128)));
+    k<<<grid, PC ? 512 : 256, split_conv3_lds(128), st>>>(g);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) k<<<grid, PC ? 512 : 256, split_conv3_lds(128), st>>>(g);
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return 1000.f * ms / reps;
+}
+
+template <int ABL>
+static float run_wide(const GemmArgs& g, hipStream_t st, int reps) {
+    const dim3 grid((g.N + 127) / 128, g.M / 256, 1);
+    auto* k = conv3x3_split_wide_kernel<false, 128, ABL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, split_wide_lds(128)));
+    k<<<grid, 512, split_wide_lds(128), st>>>(g);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) k<<<grid, 512, split_wide_lds(128), st>>>(g);
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return 1000.f * ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 64;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    const Shape shapes[] = {
+        {"res16  512->512", 16, 512, 512, 0}, {"res32  512->512", 32, 512, 512, 0}, {"up64   512->512 (x2)", 64, 512, 512, 1},
+        {"res64  256->256", 64, 256, 256, 0}, {"up128  256->256 (x2)", 128, 256, 256, 1}, {"res128 128->128", 128, 128, 128, 0},
+        {"up256  128->128 (x2)", 256, 128, 128, 1},
+    };
+    const size_t amax = (size_t)B * 256 * 256 * 128, wmax = (size_t)512 * 9 * 512;
+    half_t *A, *Wh, *Wl; float *C, *bias; void* zero;
+    CK(hipMalloc(&A, amax * 4)); CK(hipMalloc(&C, amax * 4)); CK(hipMalloc(&Wh, wmax * 2)); CK(hipMalloc(&Wl, wmax * 2));
+    CK(hipMalloc(&bias, 512 * 4)); CK(hipMalloc(&zero, 256));
+    {   // random-ish operand bits (fp16 values in [0.5, 2) and small lo parts): MFMA power depends on the data
+        std::vector<unsigned short> hbuf(1 << 22);
+        unsigned x = 12345u;
+        for (auto& v : hbuf) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3800u + ((x >> 16) & 0x07ffu) + ((x >> 8) & 0x8000u)); }
+        for (size_t off = 0; off < amax * 2; off += hbuf.size()) CK(hipMemcpy(A + off, hbuf.data(), std::min(hbuf.size(), amax * 2 - off) * 2, hipMemcpyHostToDevice));
+        for (size_t off = 0; off < wmax; off += hbuf.size()) {
+            CK(hipMemcpy(Wh + off, hbuf.data(), std::min(hbuf.size(), wmax - off) * 2, hipMemcpyHostToDevice));
+            CK(hipMemcpy(Wl + off, hbuf.data() + 77, std::min(hbuf.size() - 77, wmax - off) * 2, hipMemcpyHostToDevice));
+        }
+    }
+    CK(hipMemset(bias, 0, 512 * 4)); CK(hipMemset(zero, 0, 256));
+    printf("%-22s %8s | %7s %7s %7s | %7s %7s %7s %7s | %7s %7s\n", "layer (batch 64)", "GF x3", "pc1 us", "TF eq", "pc0 us", "no-epi", "no-dma", "dma", "mfma", "pc0nodma", "pc0 mfma");
+    double tot = 0, totf = 0;
+    for (const Shape& s : shapes) {
+        GemmArgs g{};
+        g.A = A; g.conv_taps = 9; g.H = s.res; g.W = s.res; g.Cin = s.cin; g.upsample = s.up;
+        g.Bw = Wh; g.Bw_lo = Wl; g.ldb = 9 * s.cin; g.C = C; g.ldc = s.cout; g.M = B * s.res * s.res; g.N = s.cout; g.K = 9 * s.cin; g.batch = 1;
+        g.bias = bias; g.alpha = 1.f; g.store = STORE_ROWS; g.zero_page = zero;
+        const double fl = 3 * 2.0 * g.M * g.N * g.K;
+        const int reps = 3;
+        const float t0 = run<1, 0>(g, st, reps), p0 = run<0, 0>(g, st, reps), t1 = run<1, 1>(g, st, reps), t2 = run<1, 2>(g, st, reps),
+                    t3 = run<1, 3>(g, st, reps), t4 = run<1, 4>(g, st, reps), q2 = run<0, 2>(g, st, reps), q4 = run<0, 4>(g, st, reps);
+        printf("%-22s %8.1f | %7.1f %7.1f %7.1f | %7.1f %7.1f %7.1f %7.1f | %7.1f %7.1f\n", s.name, fl * 1e-9, t0, fl / t0 * 1e-6, p0, t1, t2, t3, t4, q2, q4);
+        const float w0 = run_wide<0>(g, st, reps), w1 = run_wide<1>(g, st, reps), w2 = run_wide<2>(g, st, reps), w3 = run_wide<3>(g, st, reps), w4 = run_wide<4>(g, st, reps), w6 = run_wide<6>(g, st, reps), w5 = run_wide<5>(g, st, reps);
+        printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7.1f %7.1f | contiguous-src %7.1f stagger %7.1f\n", "   wide tile 16x16", "", w0, fl / w0 * 1e-6, "", w1, w2, w3, w4, w6, w5);
+        {
+            static long long* dbg = nullptr;
+            if (!dbg) CK(hipMalloc(&dbg, 8 * 8 * 8));
+            CK(hipMemset(dbg, 0, 8 * 8 * 8));
+            GemmArgs gd = g; gd.am_best = reinterpret_cast<unsigned long long*>(dbg);
+            run_wide<9>(gd, st, 1);
+            long long hd[64]; CK(hipMemcpy(hd, dbg, sizeof(hd), hipMemcpyDeviceToHost));
+            for (int w : {0, 4}) printf("      wave %d cycles per k-tile: staging first %.0f, reads+mfma %.0f, staging last %.0f, barrier %.0f | loop total %.0f (%lld k-tiles)\n", w,
+                   hd[w * 8] / (double)hd[w * 8 + 5], hd[w * 8 + 1] / (double)hd[w * 8 + 5], hd[w * 8 + 2] / (double)hd[w * 8 + 5], hd[w * 8 + 3] / (double)hd[w * 8 + 5],
+                   hd[w * 8 + 4] / (double)hd[w * 8 + 5], hd[w * 8 + 5]);
+        }
+        tot += std::min(t0, w0); totf += fl;
+    }
+    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent\n", tot, totf / tot * 1e-6);
+    return 0;
+}
