@@ -184,3 +184,8 @@ struct StepState {           // lives in device memory; lets one captured graph 
 };
 
 #define HQT_MAX_V 16384
+
+// Table indices that arrive from the caller (class / text ids, teacher-forced codes, code grids) are clamped into the table on
+// the device: an out-of-range id can then never fault or read foreign memory.  The Python surface raises IndexError for them
+// before the launch, as nn.Embedding / F.embedding do in the reference; n <= 0 disables the clamp.
+__device__ __forceinline__ long long clamp_idx(long long v, int n) { return n > 0 ? (v < 0 ? 0 : (v >= n ? (long long)n - 1 : v)) : v; }

@@ -37,6 +37,22 @@ static int fail(int code, const char* fmt, ...) {
         if (r_ != HQT_OK) return r_; \
     } while (0)
 
+// Entry points run on the handle's device and put the caller's current device back on return (C-ABI callers that drive several
+// devices from one thread would otherwise find it silently changed).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = prev == dev || hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+#define ON_DEVICE(h_)                                                                          \
+    DeviceGuard dg_((h_)->device);                                                             \
+    if (!dg_.ok) return fail(HQT_ERR_HIP, "hipSetDevice(%d) failed", (h_)->device)
+
 struct Tensor {
     float* d = nullptr;
     std::vector<int64_t> shape;
@@ -281,7 +297,8 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
     if (!cfg || !out) return fail(HQT_ERR_INVALID, "null argument");
     if (cfg->abi_version != HQT_ABI_VERSION) return fail(HQT_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, HQT_ABI_VERSION);
     if (cfg->max_batch < 1) return fail(HQT_ERR_INVALID, "max_batch must be >= 1");
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard dg(device);
+    if (!dg.ok) return fail(HQT_ERR_HIP, "hipSetDevice(%d) failed", device);
     std::unique_ptr<hqt_handle> h(new hqt_handle());
     h->cfg = *cfg;
     h->device = device;
@@ -416,7 +433,7 @@ static int alloc_workspace(hqt_handle* hp) {
 extern "C" int hqt_clone(hqt_handle* src, hqt_handle** out) {
     if (!src || !out) return fail(HQT_ERR_INVALID, "null argument");
     if (!src->finalized) return fail(HQT_ERR_STATE, "hqt_clone needs a finalized handle");
-    HIPCHK(hipSetDevice(src->device));
+    ON_DEVICE(src);
     hqt_handle* root = src->parent ? src->parent : src;
     std::unique_ptr<hqt_handle> h(new hqt_handle(*root));       // weights map, Lin structs and decoder plan by value: same device pointers
     h->owned.clear();
@@ -432,6 +449,7 @@ extern "C" int hqt_clone(hqt_handle* src, hqt_handle** out) {
     h->all_events.clear();
     h->pend = {nullptr, 0, 0, nullptr};
     h->nparts = h->npartsd = 0;
+    h->policy = HQT_POLICY_LATENCY;              // a lane's tile choice never depends on what the root ran when it was cloned
     const int rc = alloc_workspace(h.get());
     if (rc != HQT_OK) { for (void* p : h->owned) hipFree(p); return rc; }
     root->n_clones++;
@@ -442,7 +460,7 @@ extern "C" int hqt_clone(hqt_handle* src, hqt_handle** out) {
 extern "C" int hqt_destroy(hqt_handle* h) {
     if (!h) return HQT_OK;
     if (h->n_clones > 0) return fail(HQT_ERR_STATE, "%d clone(s) of this handle are still alive", h->n_clones);
-    hipSetDevice(h->device);
+    DeviceGuard dg(h->device);
     hipDeviceSynchronize();
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     timing_collect(h);
@@ -457,7 +475,7 @@ extern "C" int hqt_set_weight(hqt_handle* h, const char* name, const void* data,
     if (!h || !name || !data || !shape || ndim < 1 || ndim > 4) return fail(HQT_ERR_INVALID, "bad argument");
     if (dtype != HQT_DTYPE_F32) return fail(HQT_ERR_INVALID, "only fp32 weights are accepted");
     if (h->finalized) return fail(HQT_ERR_STATE, "weights already finalized");
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     Tensor t;
     t.n = 1;
     for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.n *= (size_t)shape[i]; }
@@ -620,10 +638,32 @@ static int load_encoder(hqt_handle* h) {
 
 static std::string key2(const hqt_handle* h, const char* name);
 
+static int finalize_impl(hqt_handle* h);
 extern "C" int hqt_finalize_weights(hqt_handle* h) {
     if (!h) return fail(HQT_ERR_INVALID, "null handle");
     if (h->finalized) return HQT_OK;
-    HIPCHK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device);
+    if (!dg.ok) return fail(HQT_ERR_HIP, "hipSetDevice(%d) failed", h->device);
+    // all or nothing: on failure every derived buffer allocated by this attempt is released and the derived state cleared, so a
+    // retry (after the missing tensor was set) starts clean instead of re-allocating on top of half-built layouts
+    const size_t owned_before = h->owned.size();
+    const int rc = finalize_impl(h);
+    if (h->fold_tmp) { hipFree(h->fold_tmp); h->fold_tmp = nullptr; }
+    if (rc != HQT_OK) {
+        hipDeviceSynchronize();
+        for (size_t i = owned_before; i < h->owned.size(); ++i) hipFree(h->owned[i]);
+        h->owned.resize(owned_before);
+        h->body.clear(); h->depth.clear();
+        h->head_top = h->head_bot = h->head_l2 = h->post_quant = h->quant_conv = Lin();
+        for (auto& l : h->dec) { l.conv1 = l.conv2 = l.nin = l.q = l.k = l.v = l.proj = Lin(); }
+        for (auto& l : h->enc) { l.conv1 = l.conv2 = l.nin = l.q = l.k = l.v = l.proj = Lin(); }
+        for (auto& p : h->cb_norm) p = nullptr;
+        h->vq_h = h->vq_recon = h->vq_zz = h->vq_err = nullptr; h->vq_z = nullptr; h->vq_best = nullptr;
+        h->has_encoder = false;
+    }
+    return rc;
+}
+static int finalize_impl(hqt_handle* h) {
     const hqt_config& c = h->cfg;
     if (c.has_stage2) {
         HIPCHK(hipMalloc((void**)&h->fold_tmp, (size_t)std::max(4 * c.embed_dim, c.vocab_top) * c.embed_dim * 4));
@@ -670,9 +710,7 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
                 CHK(get_w(h, "stage2.ln_levels.2.weight", {D}, &g1)); CHK(get_w(h, "stage2.ln_levels.2.bias", {D}, &b1));
                 CHK(fold_ln(h, h->head_l2, g1, b1));
             }
-            HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipFree(h->fold_tmp));
-            h->fold_tmp = nullptr;
+            HIPCHK(hipDeviceSynchronize());          // fold_tmp is released by hqt_finalize_weights on every exit
         }
         if (c.cond_type == HQT_COND_CLASS) CHK(get_w(h, "stage2.sos.weight", {c.n_classes, D}, &t));
         else if (c.cond_type == HQT_COND_TEXT) {
@@ -1015,7 +1053,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
         if (!fuse) {
             Timed t2(h, "embed", c.st);
             HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
-                                      h->xd, B, D, dln4 ? h->xdpk : nullptr, dln4 ? packed_mb(4 * B) : 0, h->partsd, c.st));
+                                      h->xd, B, D, dln4 ? h->xdpk : nullptr, dln4 ? packed_mb(4 * B) : 0, h->partsd, c.st, V));
         }
         h->npartsd = 1;
     }
@@ -1080,12 +1118,12 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
         } else if (lv == 1) {     // emb(top code) + positions 0..3
             Timed t(h, "embed", c.st);
             HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
-                                      h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st));
+                                      h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st, V));
         } else {                  // parent's level-1 embedding + position i + emb(top code), 16 tokens
             Timed t(h, "embed", c.st);
             HIPCHK(launch_depth_embed_l2(c.feed_top, c.feed_bot, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"),
                                          h->w["stage2.tok_emb_depth_levels.1.weight"].d, h->w["stage2.pos_emb_depths.1.weight"].d,
-                                         h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st));
+                                         h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st, V));
         }
         h->npartsd = 1;
         for (int l = 0; l < cf.n_layers_depth; ++l) {
@@ -1126,6 +1164,7 @@ static int run_decode_step(hqt_handle* h, const SampleCtx& c) {      // one KV-c
                     c.feed_top, c.feed_bot, h->x, nullptr, 0, h->parts};
         if (dln_ok(h, c, h->body[0], c.B)) { e.xpk = h->xpk; e.pk_mb = packed_mb(c.B); h->nparts = 1; }
         if (c.levels == 3) { e.levels = 3; e.tok_l2 = h->w["stage2.tok_emb_levels.2.weight"].d; e.codes_l2 = c.feed_l2; }
+        e.V = cf.vocab_top; e.n_classes = cf.n_classes;
         HIPCHK(launch_embed_step(e, c.st));
     }
     if (c.levels == 3) CHK(run_position_l3(h, c, 1, 0, true));
@@ -1149,7 +1188,7 @@ extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_s
     if (cf.cond_type != HQT_COND_NONE && !cond) return fail(HQT_ERR_INVALID, "cond is required for class/text conditioning");
     if (!(opts->temperature_top > 0.f) || !(opts->temperature_bot > 0.f)) return fail(HQT_ERR_INVALID, "temperatures must be > 0");
     if ((opts->top_p_top > 0.f || opts->top_p_bot > 0.f) && cf.vocab_top > 8192) return fail(HQT_ERR_INVALID, "top-p needs vocab <= 8192");
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     // The launch sequence reads cond and writes the drawn codes in buffers owned by the handle, and takes the Philox seed
     // and the global row offset from device memory: nothing that changes from call to call is baked into the captured
     // graph, so a steady stream of batches replays ONE graph (no re-capture, no exec destroyed under pending launches).
@@ -1184,7 +1223,7 @@ extern "C" int hqt_sample_l3(hqt_handle* h, int B, const int64_t* cond, const hq
         pmax = std::max(pmax, opts->top_p[i]);
     }
     if (pmax > 0.f && cf.vocab_top > 8192) return fail(HQT_ERR_INVALID, "top-p needs vocab <= 8192");
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     SampleCtx c;
     c.levels = 3;
     c.B = B; c.cond = cond ? h->cond_buf : nullptr; c.noise = noise;
@@ -1221,7 +1260,7 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
     int first = 0;
     if (cf.cond_type == HQT_COND_TEXT) {     // 64-token causal prefill (sampling.py:187-190, layers.py:107-111)
         const int T = cf.ctx_len_txt;
-        HIPCHK(launch_embed_text(cond, W(h, "tok_emb_txt.weight"), W(h, "pos_emb_txt.weight"), h->x, B, T, cf.embed_dim, c.st));
+        HIPCHK(launch_embed_text(cond, W(h, "tok_emb_txt.weight"), W(h, "pos_emb_txt.weight"), h->x, B, T, cf.embed_dim, c.st, cf.vocab_txt));
         if (c.levels == 3) CHK(run_position_l3(h, c, T, 0, false));
         else CHK(run_position(h, c, T, 0, false));
         HIPCHK(launch_advance_step(h->state, T, c.st));
@@ -1456,10 +1495,10 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
         Timed t(h, "quant_gather", st);
         if (l3) {
             QuantArgs3 q{code_t, code_m, code_b, seq_layout, W1(h, "quantizers.0.embedding"), W1(h, "quantizers.1.embedding"),
-                         W1(h, "quantizers.2.embedding"), h->quant, n, r, E, adt};
+                         W1(h, "quantizers.2.embedding"), h->quant, n, r, E, adt, cf.s1_n_embed};
             HIPCHK(launch_quant_gather3(q, st));
         } else {
-            QuantArgs q{code_t, code_b, seq_layout, W1(h, "quantize_t.embedding"), W1(h, "quantize_b.embedding"), h->quant, n, r, E, adt};
+            QuantArgs q{code_t, code_b, seq_layout, W1(h, "quantize_t.embedding"), W1(h, "quantize_b.embedding"), h->quant, n, r, E, adt, cf.s1_n_embed};
             HIPCHK(launch_quant_gather(q, st));
         }
     }
@@ -1489,7 +1528,7 @@ static int decode_impl(hqt_handle* h, int B, const int64_t* code_t, const int64_
     if ((h->cfg.code_levels == 3) != (levels == 3)) return fail(HQT_ERR_STATE, "stage 1 has %d code levels: use the matching decode entry point", h->cfg.code_levels == 3 ? 3 : 2);
     if (!code_t && !code_b && !code_m) return fail(HQT_ERR_INVALID, "every code grid is NULL");
     if (B < 1) return fail(HQT_ERR_INVALID, "B must be >= 1");
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     Mode md;
     CHK(mode_of(precision, true, &md));
     const int r = h->dec.front().res;
@@ -1562,7 +1601,7 @@ extern "C" int hqt_encode(hqt_handle* h, int B, const float* pixels, int precisi
     const hqt_config& cf = h->cfg;
     const int L = cf.code_levels == 3 ? 3 : 2;
     for (int l = 0; l < L; ++l) if (!out->codes[l]) return fail(HQT_ERR_INVALID, "codes[%d] is NULL", l);
-    HIPCHK(hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     Mode md;
     CHK(mode_of(precision, true, &md));

@@ -29,16 +29,17 @@ struct EmbedArgs {
     int levels;                  // 0 or 2: two levels; 3: three
     const float* tok_l2;         // [V, D] tok_emb_levels.2
     const int64_t* codes_l2;     // [B, n_steps, 16]
+    int V, n_classes;            // table sizes for the index clamp (0: unchecked)
 };
 hipError_t launch_embed_step(const EmbedArgs& a, hipStream_t st);
 
 // text prefix: x[b, t, :] = tok_emb_txt[cond[b, t]] + pos_emb_txt[t]
 hipError_t launch_embed_text(const int64_t* cond, const float* tok, const float* pos, float* x, int B, int T, int D,
-                             hipStream_t st);
+                             hipStream_t st, int vocab = 0);
 
 // depth sub-step 1 input: x[b*4+s, :] = tok_top_depth[top[b, step]] + pos_depth[s]
 hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
-                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st);
+                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st, int V = 0);
 
 struct LNArgs {
     float* x;                    // [rows_in, D]; rewritten in place when split-K slabs are folded in
@@ -109,7 +110,7 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
 // tok1[codes1[b, step, parent(i)]] + pos[i] + tok0[codes0[b, step]], 16 rows per sample
 hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state, const float* tok0,
                                  const float* tok1, const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts,
-                                 hipStream_t st);
+                                 hipStream_t st, int V = 0);
 // raises the dynamic-LDS limit of the sampler for (V, top-p) outside any stream capture
 hipError_t sampler_configure(int V, bool use_top_p);
 
@@ -128,6 +129,7 @@ struct QuantArgs {
     void* quant;                 // NHWC [B, r, r, 2E]
     int B, r, E;
     int out_dtype;
+    int n_embed;                 // codebook rows for the index clamp (0: unchecked)
 };
 hipError_t launch_quant_gather(const QuantArgs& a, hipStream_t st);
 // Three-level additive pyramid (HQVAEGenerator.decode_code, generator.py:577-599): quant[b, Y, X, c] =
@@ -140,6 +142,7 @@ struct QuantArgs3 {
     void* quant;                       // NHWC [B, r, r, E]
     int B, r, E;
     int out_dtype;
+    int n_embed;
 };
 hipError_t launch_quant_gather3(const QuantArgs3& a, hipStream_t st);
 

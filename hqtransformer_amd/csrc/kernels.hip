@@ -68,16 +68,16 @@ __global__ __launch_bounds__(256) void embed_step_kernel(EmbedArgs a) {
     const int step = a.state->step;
     float* x = a.x + (long long)b * D;
     if (step == 0) {
-        const float* src = a.cond_type == 1 ? a.sos + a.cond[b] * (long long)D : a.sos;
+        const float* src = a.cond_type == 1 ? a.sos + clamp_idx(a.cond[b], a.n_classes) * (long long)D : a.sos;
         for (int d = threadIdx.x; d < D; d += blockDim.x) x[d] = src[d];
         if (a.xpk) { __syncthreads(); emit_packed_row(x, b, D, a.xpk, a.pk_mb, a.parts, red); }
         return;
     }
     const int p = step - 1;
-    const long long ct = a.codes_top[(long long)b * a.n_steps + p];
+    const long long ct = clamp_idx(a.codes_top[(long long)b * a.n_steps + p], a.V);
     long long cb[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) cb[s] = a.codes_bot[((long long)b * a.n_steps + p) * 4 + s];
+    for (int s = 0; s < 4; ++s) cb[s] = clamp_idx(a.codes_bot[((long long)b * a.n_steps + p) * 4 + s], a.V);
     if (a.embedding == 1) {                      // 'reduce': channel k*4+slot of the bottom part (:522-526)
         const int Dq = D / 4;
         for (int d = threadIdx.x; d < D; d += blockDim.x) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void embed_step_kernel(EmbedArgs a) {
     } else if (a.levels == 3) {                  // three levels: mean over the 21 tokens (hqtransformer.py:466-488)
         long long c2[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) c2[k] = a.codes_l2[((long long)b * a.n_steps + p) * 16 + k];
+        for (int k = 0; k < 16; ++k) c2[k] = clamp_idx(a.codes_l2[((long long)b * a.n_steps + p) * 16 + k], a.V);
         for (int d = threadIdx.x; d < D; d += blockDim.x) {
             float s = (a.tok_top[ct * D + d] + a.pos_top[(long long)p * D + d]) + a.pos_emb[d];
 #pragma unroll
@@ -112,48 +112,48 @@ hipError_t launch_embed_step(const EmbedArgs& a, hipStream_t st) {
 }
 
 __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* cond, const float* tok, const float* pos,
-                                                         float* x, int T, int D) {
+                                                         float* x, int T, int D, int vocab) {
     const int row = blockIdx.x, t = row % T;
-    const long long id = cond[row];
+    const long long id = clamp_idx(cond[row], vocab);
     for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long long)row * D + d] = tok[id * D + d] + pos[(long long)t * D + d];
 }
 hipError_t launch_embed_text(const int64_t* cond, const float* tok, const float* pos, float* x, int B, int T, int D,
-                             hipStream_t st) {
-    embed_text_kernel<<<B * T, 256, 0, st>>>(cond, tok, pos, x, T, D);
+                             hipStream_t st, int vocab) {
+    embed_text_kernel<<<B * T, 256, 0, st>>>(cond, tok, pos, x, T, D, vocab);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void depth_embed_kernel(const int64_t* codes_top, int n_steps, const StepState* state,
                                                           const float* tok, const float* pos, float* x, int D, bf16_t* xpk,
-                                                          int pk_mb, float* parts) {
+                                                          int pk_mb, float* parts, int V) {
     __shared__ float red[4];
     const int row = blockIdx.x, b = row >> 2, s = row & 3;
-    const long long code = codes_top[(long long)b * n_steps + state->step];
+    const long long code = clamp_idx(codes_top[(long long)b * n_steps + state->step], V);
     for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long long)row * D + d] = tok[code * D + d] + pos[(long long)s * D + d];
     if (xpk) { __syncthreads(); emit_packed_row(x + (long long)row * D, row, D, xpk, pk_mb, parts, red); }
 }
 hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
-                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st) {
-    depth_embed_kernel<<<B * 4, 256, 0, st>>>(codes_top, n_steps, state, tok, pos, x, D, xpk, pk_mb, parts);
+                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st, int V) {
+    depth_embed_kernel<<<B * 4, 256, 0, st>>>(codes_top, n_steps, state, tok, pos, x, D, xpk, pk_mb, parts, V);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void depth_embed_l2_kernel(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state,
                                                              const float* tok0, const float* tok1, const float* pos, float* x, int D,
-                                                             bf16_t* xpk, int pk_mb, float* parts) {
+                                                             bf16_t* xpk, int pk_mb, float* parts, int V) {
     __shared__ float red[4];
     const int row = blockIdx.x, b = row >> 4, i = row & 15;
     const int parent = (i >> 3) * 2 + ((i & 3) >> 1);                  // (H1 H2 W1 W2) raster -> (H1 W1)
-    const long long c0 = codes0[(long long)b * n_steps + state->step];
-    const long long c1 = codes1[((long long)b * n_steps + state->step) * 4 + parent];
+    const long long c0 = clamp_idx(codes0[(long long)b * n_steps + state->step], V);
+    const long long c1 = clamp_idx(codes1[((long long)b * n_steps + state->step) * 4 + parent], V);
     for (int d = threadIdx.x; d < D; d += blockDim.x)
         x[(long long)row * D + d] = (tok1[c1 * D + d] + pos[(long long)i * D + d]) + tok0[c0 * D + d];
     if (xpk) { __syncthreads(); emit_packed_row(x + (long long)row * D, row, D, xpk, pk_mb, parts, red); }
 }
 hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state, const float* tok0,
                                  const float* tok1, const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts,
-                                 hipStream_t st) {
-    depth_embed_l2_kernel<<<B * 16, 256, 0, st>>>(codes0, codes1, n_steps, state, tok0, tok1, pos, x, D, xpk, pk_mb, parts);
+                                 hipStream_t st, int V) {
+    depth_embed_l2_kernel<<<B * 16, 256, 0, st>>>(codes0, codes1, n_steps, state, tok0, tok1, pos, x, D, xpk, pk_mb, parts, V);
     return hipGetLastError();
 }
 
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
         for (int w = 1; w < NT / 64; ++w)
             if (redf[w] > best || (redf[w] == best && redi[w] < besti)) { best = redf[w]; besti = redi[w]; }
         a.out[((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
-        if (a.emb_tok) sel[0] = a.emb_feed ? (int)a.emb_feed[((long long)b * a.n_steps + step) * a.slots + slot] : besti;
+        if (a.emb_tok) sel[0] = a.emb_feed ? (int)clamp_idx(a.emb_feed[((long long)b * a.n_steps + step) * a.slots + slot], a.V) : besti;
     }
     if (!a.emb_tok) return;                              // workgroup-uniform
     // ---- fused embedding lookup: this workgroup drew the top code of sample b, so it also writes the four depth-token rows
@@ -643,26 +643,22 @@ static size_t sampler_smem(int V, bool use_p, int& n2) {
     if (use_p) sz += (size_t)n2 * sizeof(float) + (size_t)n2 * sizeof(unsigned short) + (size_t)V;
     return (sz + 15) & ~(size_t)15;
 }
-static size_t g_sampler_configured = 0;
+// hipFuncSetAttribute applies to the CURRENT device: set it on every call (outside capture, a few microseconds) instead of
+// remembering one process-wide size -- a second handle on another device would otherwise launch with the default 64 KB limit
 hipError_t sampler_configure(int V, bool use_top_p) {
     int n2;
     const size_t smem = sampler_smem(V, use_top_p, n2);
     if (smem > 160 * 1024 || (use_top_p && V > 65536)) return hipErrorInvalidValue;
-    if (smem > g_sampler_configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<256>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<1024>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        g_sampler_configured = smem;
-    }
-    return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<256>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<1024>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 }
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
     int n2;
     const size_t smem = sampler_smem(a.V, a.top_p > 0.0f, n2);
-    if (smem > g_sampler_configured) return hipErrorInvalidValue;     // sampler_configure must run first
+    if (smem > 160 * 1024) return hipErrorInvalidValue;               // sampler_configure(V, top_p) ran in sample_run for this call's options
     if (a.V >= 4096) sampler_kernel<1024><<<a.R, 1024, smem, st>>>(a, n2);
     else sampler_kernel<256><<<a.R, 256, smem, st>>>(a, n2);
     return hipGetLastError();
@@ -678,10 +674,11 @@ __global__ __launch_bounds__(256) void quant_gather_kernel(QuantArgs a) {
     const int r = a.r, rt = r / 2, E = a.E;
     const int b = pix / (r * r), Y = (pix / r) % r, X = pix % r;
     long long ct = -1, cb = -1;
-    if (a.code_t) ct = a.code_t[((long long)b * rt + (Y >> 1)) * rt + (X >> 1)];
+    if (a.code_t) ct = clamp_idx(a.code_t[((long long)b * rt + (Y >> 1)) * rt + (X >> 1)], a.n_embed);
     if (a.code_b) {
         if (a.seq_layout) cb = a.code_b[(((long long)b * rt + (Y >> 1)) * rt + (X >> 1)) * 4 + (Y & 1) * 2 + (X & 1)];
         else cb = a.code_b[((long long)b * r + Y) * r + X];
+        cb = clamp_idx(cb, a.n_embed);
     }
     TO* out = reinterpret_cast<TO*>(a.quant) + (long long)pix * 2 * E;
     const int sub = (Y & 1) * 2 + (X & 1);
@@ -714,6 +711,9 @@ __global__ __launch_bounds__(256) void quant_gather3_kernel(QuantArgs3 a) {
         if (a.seq_layout) c2 = a.code_b[(((long long)b * rt + (Y >> 2)) * rt + (X >> 2)) * 16 + (Y & 3) * 4 + (X & 3)];
         else c2 = a.code_b[((long long)b * r + Y) * r + X];
     }
+    if (c0 >= 0) c0 = clamp_idx(c0, a.n_embed);
+    if (c1 >= 0) c1 = clamp_idx(c1, a.n_embed);
+    if (c2 >= 0) c2 = clamp_idx(c2, a.n_embed);
     TO* out = reinterpret_cast<TO*>(a.quant) + (long long)pix * E;
     const int sub = (Y & 1) * 2 + (X & 1), subm = ((Y >> 1) & 1) * 2 + ((X >> 1) & 1);
     for (int c = threadIdx.x; c < E; c += blockDim.x) {

@@ -48,6 +48,11 @@ def make_config(s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], max_batch: i
     return c
 
 
+# (data_ptr, numel) -> tensor version of device tensors whose indices are known to be in range: produced by a sampler of this
+# process (any engine: the stage-2 engine's codes go to the stage-1 engine's decode) or already validated once
+_TRUSTED: Dict[Tuple[int, int], int] = {}
+
+
 class Engine:
     """One libhqt handle on one GPU.  Not thread-safe; asynchronous on torch's current stream."""
 
@@ -65,6 +70,7 @@ class Engine:
         _lib.check(self.lib.hqt_create(C.byref(self.cfg), self.device.index or 0, C.byref(h)))
         self.h = h
         self.finalized = False
+        self.policy = _lib.POLICY_LATENCY
 
     def clone(self) -> 'Engine':
         """A further lane over the same weights (``hqt_clone``): own KV cache / activations / graph cache, results
@@ -77,6 +83,7 @@ class Engine:
         h = C.c_void_p()
         _lib.check(self.lib.hqt_clone(self.h, C.byref(h)))
         e.h, e.finalized = h, True
+        e.policy = _lib.POLICY_LATENCY               # hqt_clone resets a lane to the default policy
         e._parent = self                             # keeps the weights' owner alive
         self._clones = getattr(self, '_clones', [])
         self._clones.append(e)
@@ -86,6 +93,7 @@ class Engine:
         """``hqt_set_policy``: 0 = latency-oriented kernel choice (one batch at a time), 1 = throughput-oriented (several
         lanes in flight).  Part of the graph key: the next sample() re-captures if it changed."""
         _lib.check(self.lib.hqt_set_policy(self.h, int(policy)))
+        self.policy = int(policy)
 
     def close(self) -> None:
         for c in getattr(self, '_clones', []):       # clones go first: the parent owns the weights
@@ -118,6 +126,38 @@ class Engine:
         _lib.check(self.lib.hqt_finalize_weights(self.h))
         self.finalized = True
 
+    # ------------------------------------------------------------------ input validation
+    # The reference indexes nn.Embedding / F.embedding tables with these tensors and raises IndexError for an id outside the
+    # table.  Host tensors are checked on the host (free).  Device tensors need one reduction + a host read, i.e. a stream
+    # synchronisation: they are checked once per (storage, version) and remembered, and tensors this engine produced itself
+    # (sampled codes fed to decode) are trusted -- so a pipelined run (bench.py: lanes, sampled codes straight into decode)
+    # never synchronises.  The kernels clamp every such index into its table regardless (csrc/common.h: clamp_idx).
+    def _trust(self, *tensors) -> None:
+        for t in tensors:
+            if t is not None:
+                _TRUSTED[(t.data_ptr(), t.numel())] = t._version
+                if len(_TRUSTED) > 256:
+                    _TRUSTED.pop(next(iter(_TRUSTED)))
+
+    def _check_index(self, t: Optional[torch.Tensor], n: int, what: str) -> None:
+        if t is None or t.numel() == 0:
+            return
+        key = (t.data_ptr(), t.numel())
+        if t.is_cuda and _TRUSTED.get(key) == t._version:
+            return
+        lo, hi = (int(v) for v in torch.stack([t.min(), t.max()]).tolist())
+        if lo < 0 or hi >= n:
+            raise IndexError(f'{what}: index out of range (values span [{lo}, {hi}], table has {n} rows)')
+        if t.is_cuda:
+            self._trust(t)
+
+    @staticmethod
+    def _check_out(t: torch.Tensor, shape, dtype, dev, what: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev or not t.is_contiguous():
+            raise ValueError(f'{what}: expected a contiguous {dtype} tensor of shape {tuple(shape)} on {dev}, got '
+                             f'{getattr(t, "dtype", type(t))} {tuple(getattr(t, "shape", ()))} on {getattr(t, "device", "?")}')
+        return t
+
     # ------------------------------------------------------------------ stage 2
     def sample(self, batch: int, cond: Optional[torch.Tensor], n_steps: int, *, precision: int = PRECISION_FAST,
                top_k: Sequence[Optional[int]] = (None, None), top_p: Sequence[Optional[float]] = (None, None),
@@ -136,27 +176,32 @@ class Engine:
         o.temperature_top, o.temperature_bot = float(temperature[0]), float(temperature[1])
         o.seed, o.sample_offset, o.use_graph = int(seed) & (2 ** 64 - 1), int(sample_offset), int(bool(use_graph))
 
-        def prep(t, shape, dtype, what):
+        def prep(t, shape, dtype, what, table=0):
             if t is None:
                 return None
-            t = torch.as_tensor(t).to(device=dev, dtype=dtype).contiguous()
+            t = torch.as_tensor(t)
             if tuple(t.shape) != tuple(shape):
                 raise ValueError(f'{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
-            return t
+            if table:
+                self._check_index(t, table, what)
+            return t.to(device=dev, dtype=dtype).contiguous()
         if self.s2.cond == 1:
-            cond = prep(cond, (B,), torch.int64, 'cond')
+            cond = prep(cond, (B,), torch.int64, 'cond (class ids)', self.s2.n_classes)
         elif self.s2.cond == 2:
-            cond = prep(cond, (B, self.s2.ctx_len_txt), torch.int64, 'cond')
+            cond = prep(cond, (B, self.s2.ctx_len_txt), torch.int64, 'cond (text token ids)', self.s2.vocab_txt)
         else:
             cond = None
         noise = prep(noise, (n_steps, 5, B, V), torch.float32, 'noise')
-        force_top = prep(force_top, (B, n_steps), torch.int64, 'force_top')
-        force_bot = prep(force_bot, (B, n_steps, 4), torch.int64, 'force_bot')
+        force_top = prep(force_top, (B, n_steps), torch.int64, 'force_top', V)
+        force_bot = prep(force_bot, (B, n_steps, 4), torch.int64, 'force_bot', V)
         if out is None:
             out_top = torch.empty((B, n_steps), dtype=torch.int64, device=dev)
             out_bot = torch.empty((B, n_steps, 4), dtype=torch.int64, device=dev)
         else:
-            out_top, out_bot = out
+            if not isinstance(out, (tuple, list)) or len(out) != 2:
+                raise ValueError('out: expected a pair (codes_top [B, n_steps], codes_bot [B, n_steps, 4])')
+            out_top = self._check_out(out[0], (B, n_steps), torch.int64, dev, 'out[0]')
+            out_bot = self._check_out(out[1], (B, n_steps, 4), torch.int64, dev, 'out[1]')
         logits = torch.empty((n_steps, 5, B, V), dtype=torch.float32, device=dev) if return_logits else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
@@ -164,6 +209,7 @@ class Engine:
                                            _ptr(logits), _ptr(out_top), _ptr(out_bot), C.c_void_p(stream)))
         # inputs must outlive the asynchronous launches
         self._keep = (cond, noise, force_top, force_bot)
+        self._trust(out_top, out_bot)              # the sampler only writes ids inside the vocabulary
         if return_logits:
             return out_top, out_bot, logits
         return out_top, out_bot
@@ -185,24 +231,26 @@ class Engine:
             o.temperature[i] = float(temperature[i])
         o.seed, o.sample_offset, o.use_graph = int(seed) & (2 ** 64 - 1), int(sample_offset), int(bool(use_graph))
 
-        def prep(t, shape, dtype, what):
+        def prep(t, shape, dtype, what, table=0):
             if t is None:
                 return None
-            t = torch.as_tensor(t).to(device=dev, dtype=dtype).contiguous()
+            t = torch.as_tensor(t)
             if tuple(t.shape) != tuple(shape):
                 raise ValueError(f'{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
-            return t
+            if table:
+                self._check_index(t, table, what)
+            return t.to(device=dev, dtype=dtype).contiguous()
         if self.s2.cond == 1:
-            cond = prep(cond, (B,), torch.int64, 'cond')
+            cond = prep(cond, (B,), torch.int64, 'cond (class ids)', self.s2.n_classes)
         elif self.s2.cond == 2:
-            cond = prep(cond, (B, self.s2.ctx_len_txt), torch.int64, 'cond')
+            cond = prep(cond, (B, self.s2.ctx_len_txt), torch.int64, 'cond (text token ids)', self.s2.vocab_txt)
         else:
             cond = None
         noise = prep(noise, (n_steps, 21, B, V), torch.float32, 'noise')
         f = [None, None, None]
         if force is not None:
-            f = [prep(force[0], (B, n_steps), torch.int64, 'force[0]'), prep(force[1], (B, n_steps, 4), torch.int64, 'force[1]'),
-                 prep(force[2], (B, n_steps, 16), torch.int64, 'force[2]')]
+            f = [prep(force[0], (B, n_steps), torch.int64, 'force[0]', V), prep(force[1], (B, n_steps, 4), torch.int64, 'force[1]', V),
+                 prep(force[2], (B, n_steps, 16), torch.int64, 'force[2]', V)]
         outs = [torch.empty(shp, dtype=torch.int64, device=dev) for shp in ((B, n_steps), (B, n_steps, 4), (B, n_steps, 16))]
         logits = torch.empty((n_steps, 21, B, V), dtype=torch.float32, device=dev) if return_logits else None
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -210,6 +258,7 @@ class Engine:
             _lib.check(self.lib.hqt_sample_l3(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(f[0]), _ptr(f[1]), _ptr(f[2]),
                                               _ptr(logits), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), C.c_void_p(stream)))
         self._keep = (cond, noise, f)
+        self._trust(*outs)
         return (outs[0], outs[1], outs[2], logits) if return_logits else tuple(outs)
 
     def decode3(self, codes: Sequence[Optional[torch.Tensor]], *, precision: int = PRECISION_EXACT, clamp01: bool = False,
@@ -226,9 +275,10 @@ class Engine:
         cs = []
         for c, w in zip(codes, want):
             if c is not None:
-                c = c.to(device=dev, dtype=torch.int64).contiguous()
                 if tuple(c.shape) != w:
                     raise ValueError(f'code grid: expected {w}, got {tuple(c.shape)}')
+                self._check_index(c, self.s1.n_embed, 'code grid')
+                c = c.to(device=dev, dtype=torch.int64).contiguous()
             cs.append(c)
         H = self.s1.resolution
         out = torch.empty((B, self.s1.out_ch, H, H), dtype=torch.float32, device=dev)
@@ -293,8 +343,6 @@ class Engine:
         if ref is None:
             raise ValueError('code_t and code_b are both None')
         B = int(ref.shape[0])
-        code_t = None if code_t is None else code_t.to(device=dev, dtype=torch.int64).contiguous()
-        code_b = None if code_b is None else code_b.to(device=dev, dtype=torch.int64).contiguous()
         r = self.s1.z_res
         if seq_layout:
             want_t, want_b = (B, (r // 2) ** 2), (B, (r // 2) ** 2, 4)
@@ -304,9 +352,15 @@ class Engine:
             raise ValueError(f'code_t: expected {want_t}, got {tuple(code_t.shape)}')
         if code_b is not None and tuple(code_b.shape) != want_b:
             raise ValueError(f'code_b: expected {want_b}, got {tuple(code_b.shape)}')
+        self._check_index(code_t, self.s1.n_embed, 'code_t')
+        self._check_index(code_b, self.s1.n_embed, 'code_b')
+        code_t = None if code_t is None else code_t.to(device=dev, dtype=torch.int64).contiguous()
+        code_b = None if code_b is None else code_b.to(device=dev, dtype=torch.int64).contiguous()
         H = self.s1.resolution
         if out is None:
             out = torch.empty((B, self.s1.out_ch, H, H), dtype=torch.float32, device=dev)
+        else:
+            self._check_out(out, (B, self.s1.out_ch, H, H), torch.float32, dev, 'out')
         fn = self.lib.hqt_decode_seq if seq_layout else self.lib.hqt_decode
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):

@@ -26,7 +26,6 @@ class InflightSampler:
         self.device = device if device is not None else model.stage2._device
         self.streams: List[torch.cuda.Stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
         self.k = 0
-        self._policy_set = set()
 
     def submit(self, num_candidates: int, cond, *, seed: Optional[int] = None, max_seq_len: int = 64, use_fp16: bool = True,
                decode: bool = True, precision: Optional[str] = None, clamp01: bool = True, use_graph: bool = True,
@@ -37,14 +36,17 @@ class InflightSampler:
         lane = self.k % self.n
         self.k += 1
         st = self.streams[lane]
+        caller = torch.cuda.current_stream(self.device)
         # order the lane after whatever the caller's stream has queued (inputs; earlier direct use of lane 0's engine):
         # a lane's workspace must never be touched from two streams at once
         if order_after_current:                      # False: the caller has nothing queued that this batch depends on (keeps the null stream's queue idle)
             st.wait_stream(torch.cuda.current_stream(self.device))
-        if self.n > 1 and (lane, num_candidates, max_seq_len) not in self._policy_set:
-            # several batches in flight: kernels that cost the fewest CU-microseconds (hqt_set_policy)
-            self.model.stage2.engine(num_candidates, max_seq_len, lane).set_policy(POLICY_THROUGHPUT)
-            self._policy_set.add((lane, num_candidates, max_seq_len))
+        if self.n > 1:
+            # several batches in flight: kernels that cost the fewest CU-microseconds (hqt_set_policy).  The policy lives on the
+            # engine object, so a lane rebuilt for a larger batch (or after the model dropped its engines) gets it again.
+            eng = self.model.stage2.engine(num_candidates, max_seq_len, lane)
+            if eng.policy != POLICY_THROUGHPUT:
+                eng.set_policy(POLICY_THROUGHPUT)
         with torch.cuda.stream(st):
             if phase_events is not None:
                 phase_events[0].record(st)
@@ -68,6 +70,11 @@ class InflightSampler:
                 after(ct, cb, px)                    # e.g. a gather of the finished pixels, queued on the lane's stream
             ev = torch.cuda.Event()
             ev.record(st)
+        # the results were allocated on the lane's stream and will be read (and eventually freed) on the caller's: tell the
+        # caching allocator, or it may hand the memory to the lane again while the caller's stream still reads it
+        for t in (ct, px, *(cb if isinstance(cb, (list, tuple)) else (cb,))):
+            if t is not None:
+                t.record_stream(caller)
         return ct, cb, px, ev
 
     def release(self, batch: int, max_seq_len: int) -> None:
@@ -75,7 +82,6 @@ class InflightSampler:
         self.drain()
         if self.n > 1:
             self.model.stage2.engine(batch, max_seq_len, 0).set_policy(POLICY_LATENCY)
-            self._policy_set.discard((0, batch, max_seq_len))
 
     def drain(self) -> None:
         """Wait for every lane; also orders the caller's stream after the lanes."""

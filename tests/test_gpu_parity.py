@@ -19,7 +19,7 @@ from hqtransformer_amd._lib import PRECISION_EXACT, PRECISION_FAST
 from hqtransformer_amd.engine import Engine
 from hqtransformer_amd.spec import Stage1Spec, Stage2Spec
 from oracle import hqt_oracle as O
-from tests.helpers import load, oracle_stage1, oracle_stage2, stage1_from_fixture, stage2_from_fixture
+from tests.helpers import gate, load, oracle_stage1, oracle_stage2, stage1_from_fixture, stage2_from_fixture
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 2e-4
@@ -120,7 +120,7 @@ def test_tiny_txt_prefill():
         _, _, lf = eng2.sample(B, torch.from_numpy(txt), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise), force_top=ft,
                                force_bot=fb, return_logits=True, use_graph=graph)
         err = np.abs(np_(lf)[fx['keep_steps']] - fx['logits']).max()
-        assert err <= 0.15, f'FAST text-conditional logits differ from the reference by {err}'
+        gate(f'tiny_txt_prefill.fast_logits(graph={graph})', err, 0.15)
 
 
 def test_ragged_batches_and_b1_vs_oracle(tiny_cls):
@@ -171,8 +171,9 @@ def test_philox_draws_follow_the_softmax(tiny_cls):
 
 def test_fast_precision_teacher_forced(tiny_cls):
     """FAST (bf16) arithmetic cannot be bit-exact against an fp32 reference; it is gated by teacher-forced
-    logits (|diff| <= 0.15 on logits of std ~3, i.e. a few bf16 ulps through 8 blocks) and by agreement of
-    the drawn codes under identical noise (>= 90 %)."""
+    logits (|diff| <= 0.15 on logits of std ~3, i.e. a few bf16 ulps through 8 blocks; measured 0.090) and by agreement of
+    the drawn codes under identical noise (>= 96 %; measured 98.2 %).  Every FAST gate of this suite sits at about twice the
+    figure measured on the MI355X (profiles/r02_fast_gates.txt)."""
     fx, spec, weights, eng = tiny_cls
     B, n = int(fx['B']), 16
     noise = synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:n]
@@ -184,9 +185,9 @@ def test_fast_precision_teacher_forced(tiny_cls):
         ex = eng.sample(B, torch.full((B,), 7), n, precision=PRECISION_EXACT, noise=torch.from_numpy(noise),
                         force_top=ft, force_bot=fb, return_logits=True, use_graph=False)
         err = (lg - ex[2]).abs().max().item()
-        assert err <= 0.15, f'FAST logits differ from EXACT by {err}'
+        gate(f'tiny_cls.fast_logits(graph={graph})', err, 0.15)
         agree = ((ct == ex[0]).float().mean().item() + (cb == ex[1]).float().mean().item()) / 2
-        assert agree >= 0.9, f'code agreement {agree}'
+        gate(f'tiny_cls.fast_code_agreement(graph={graph})', agree, 0.96, '>=')
 
 
 def test_fast_single_key_shortcut_is_bit_identical(tiny_cls):
@@ -231,7 +232,7 @@ def test_imagenet_head_geometry_vs_oracle(B):
                               temperature=(1.0, 0.9), noise=torch.from_numpy(noise), force_top=ft, force_bot=fb,
                               return_logits=True, use_graph=graph)
         err = np.abs(np_(lf) - want[2]).max()
-        assert err <= 0.1, f'FAST logits differ from the oracle by {err} (B={B}, graph={graph})'
+        gate(f'imagenet_head_geometry.fast_logits(B={B},graph={graph})', err, 0.1)
     # throughput-oriented tile shapes (hqt_set_policy; what several lanes in flight run): same bar
     eng.set_policy(1)
     try:
@@ -240,8 +241,8 @@ def test_imagenet_head_geometry_vs_oracle(B):
                                   temperature=(1.0, 0.9), noise=torch.from_numpy(noise), force_top=ft, force_bot=fb,
                                   return_logits=True, use_graph=graph)
             err = np.abs(np_(lt) - want[2]).max()
-            assert err <= 0.1, f'FAST (throughput policy) logits differ from the oracle by {err} (B={B}, graph={graph})'
-            assert np.abs(np_(lt) - np_(lf)).max() <= 0.05           # the two policies differ by fp32 summation order only
+            gate(f'imagenet_head_geometry.fast_logits_throughput_policy(B={B},graph={graph})', err, 0.1)
+            gate(f'imagenet_head_geometry.policy_difference(B={B},graph={graph})', np.abs(np_(lt) - np_(lf)).max(), 0.05)   # fp32 summation order only
     finally:
         eng.set_policy(0)
 
@@ -302,7 +303,8 @@ def test_decode_fast_tolerance():
         eng = engine_s1(spec, weights, 2)
         px = np_(eng.decode(torch.from_numpy(fx['code_t']), torch.from_numpy(fx['code_b']), precision=PRECISION_FAST))
         d = np.abs(px - fx['pixels'])
-        assert d.max() <= 0.1 and d.mean() <= 1e-2, (name, d.max(), d.mean())
+        gate(f'decode_fast.{name}.max', d.max(), 0.06 if '64' in name else 0.12)
+        gate(f'decode_fast.{name}.mean', d.mean(), 1e-2)
 
 
 def test_decode_fast_big_tile_kernels_vs_oracle():
@@ -325,7 +327,8 @@ def test_decode_fast_big_tile_kernels_vs_oracle():
         del os.environ['HQT_FORCE_TILE128']
     assert np.abs(exact - want).max() <= PIXEL_TOL
     d = np.abs(got - want)
-    assert d.max() <= 0.1 and d.mean() <= 1e-2, (d.max(), d.mean())
+    gate('decode_fast_big_tile.max', d.max(), 0.06)
+    gate('decode_fast_big_tile.mean', d.mean(), 1e-2)
 
 
 def test_decode_fast_halo_conv_matches_generic_implicit_gemm():
@@ -420,7 +423,7 @@ def test_l3_sampling_vs_reference_fixture_and_oracle():
         fa = eng.sample3(B, torch.full((B,), 7), 16, precision=PRECISION_FAST, noise=torch.from_numpy(noise[:16]),
                          force=[f[:, :16] for f in force], return_logits=True, use_graph=graph)
         err = (fa[3] - ex[3]).abs().max().item()
-        assert err <= 0.15, f'FAST three-level logits differ from EXACT by {err}'
+        gate(f'l3_tiny.fast_logits(graph={graph})', err, 0.12)
 
 
 def test_l3_wide_batch_vs_oracle():
@@ -442,7 +445,7 @@ def test_l3_wide_batch_vs_oracle():
         fa = eng.sample3(B, torch.from_numpy(cond), n, precision=PRECISION_FAST, top_k=(None, 64, 32), top_p=(None, 0.9, None),
                          temperature=(1.0, 0.9, 0.8), noise=torch.from_numpy(noise), force=force, return_logits=True, use_graph=graph)
         err = np.abs(np_(fa[3]) - want[3]).max()
-        assert err <= 0.15, f'FAST three-level logits differ from the oracle by {err} (graph={graph})'
+        gate(f'l3_wide.fast_logits(graph={graph})', err, 0.12)
 
 
 def test_l3_decode_vs_reference_fixture():
@@ -556,9 +559,9 @@ def test_encode_wide_config_exact_and_fast_vs_oracle():
     for l in range(2):
         resid, codes = np_(fa['resid'][l]), np_(fa['codes'][l])
         assert _excess_distance(resid, cbs[l], codes).max() <= 1e-4, l
-    assert np.abs(np_(fa['resid'][0]) - want['resid'][0]).max() <= 0.15
+    gate('encode_wide.fast_feature_map', np.abs(np_(fa['resid'][0]) - want['resid'][0]).max(), 0.08)
     agree = np.mean(np_(fa['codes'][0]) == want['codes'][0])
-    assert agree >= 0.6, agree
+    gate('encode_wide.fast_code_agreement', agree, 0.95, '>=')
 
 
 def test_encode_batch_chunking_is_batch_invariant():
@@ -650,9 +653,63 @@ def test_fast_vs_exact_at_the_benchmark_model_size():
     ct, cb, lg_e = eng.sample(B, cond, n, precision=PRECISION_EXACT, noise=noise, return_logits=True, use_graph=False)
     _, _, lg_f = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, force_top=ct, force_bot=cb, return_logits=True, use_graph=True)
     le, lf = lg_e.double(), lg_f.double()
-    assert float((le - lf).abs().max()) <= 0.1
+    gate('benchmark_model.fast_logits', (le - lf).abs().max(), 0.06)             # measured 0.0275 (tools/fast_ar_error.py)
     pe, pf = torch.softmax(le, -1), torch.softmax(lf, -1)
     kl = (pe * (torch.log(pe.clamp_min(1e-300)) - torch.log(pf.clamp_min(1e-300)))).sum(-1)
-    assert float(kl.max()) <= 1e-3
+    gate('benchmark_model.fast_kl_max', kl.max(), 1e-4)                           # measured 1.4e-5 nats per draw (mean)
     q = noise.to(le.device).double()
-    assert float((torch.argmax(pe / q, -1) == torch.argmax(pf / q, -1)).double().mean()) >= 0.98
+    gate('benchmark_model.fast_identical_draws', (torch.argmax(pe / q, -1) == torch.argmax(pf / q, -1)).double().mean(), 0.99, '>=')   # measured 0.997
+
+
+# ----------------------------------------------------------------------------------------- the benchmark's own shapes
+def test_full_benchmark_model_exact_vs_oracle():
+    """The whole ImageNet model of the benchmark (12 body + 4 depth layers, D = 1536, 24 heads, V = 8192, 530.8 M parameters,
+    random-init 'bench' weights as the harness uses) at the benchmark's batch, B = 64, two top positions, against the CPU oracle
+    (about 2 s per position on the GPU box's host): EXACT sampled codes bit-exact under the same noise and fp32 logits within
+    2e-4; FAST (what bench.py times: streaming GEMMs, deferred LayerNorm, single-key shortcut, fused embedding, one hipGraph)
+    teacher-forced on the oracle's codes within the gate of test_fast_vs_exact_at_the_benchmark_model_size."""
+    import os
+    from hqtransformer_amd.config import load_config
+    from hqtransformer_amd.spec import stage2_spec_from_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s2 = stage2_spec_from_config(load_config(os.path.join(root, 'configs', 'imagenet-12l.yaml')))
+    assert (s2.n_layers, s2.n_layers_depth, s2.embed_dim, s2.vocab_top) == (12, 4, 1536, 8192)
+    weights = synth.stage2_weights(s2, 0, 'bench')
+    B, n = 64, 2
+    noise = synth.exp_noise(11, n, B, s2.vocab_top)
+    cond = synth.class_ids(12, B, s2.n_classes)
+    want = O.OracleStage2(s2, weights).sample(cond, B, n, noise, return_logits=True)
+    eng = engine_s2(s2, weights, B, 8)
+    ct, cb, lg = eng.sample(B, torch.from_numpy(cond), n, precision=PRECISION_EXACT, noise=torch.from_numpy(noise), return_logits=True,
+                            use_graph=False)
+    err = np.abs(np_(lg) - want[2]).max()
+    assert err <= LOGIT_TOL, f'EXACT logits of the full model differ from the oracle by {err}'
+    assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all(), 'EXACT codes of the full model differ from the oracle'
+    _, _, lf = eng.sample(B, torch.from_numpy(cond), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise),
+                          force_top=torch.from_numpy(want[0]), force_bot=torch.from_numpy(want[1]), return_logits=True, use_graph=True)
+    gate('benchmark_model_B64.fast_logits_vs_oracle', np.abs(np_(lf) - want[2]).max(), 0.06)
+    print(f'full 12+4-layer model, B = 64: EXACT logits vs oracle {err:.2e} (std {want[2].std():.3f}), FAST {np.abs(np_(lf) - want[2]).max():.4f}')
+
+
+def test_text_prefill_at_the_cc15m_shape_vs_oracle():
+    """BASELINE configs[4]: the 64-token causal prompt prefill at its real shape -- D = 1536, 24 heads, ctx_len_txt = 64, B = 64, i.e.
+    4096 rows through the tiled MFMA kernels (FAST) / the fp32 tile kernel (EXACT) with the fused QKV split + KV-cache append and
+    the causal attention over 64 queries -- one body + one depth layer (the oracle's cost), then two cached positions.  EXACT:
+    codes bit-exact, logits within 2e-4; FAST: teacher-forced logits within the bf16 gate, eager and graph."""
+    spec = Stage2Spec(embed_dim=1536, n_layers=1, n_heads=24, n_layers_depth=1, vocab_top=1024, vocab_bot=1024, vocab_txt=16384,
+                      ctx_len_img=64, ctx_len_txt=64, n_classes=0, cond=2, embedding=0)
+    weights = synth.stage2_weights(spec, 301, 'fixture')
+    B, n = 64, 3
+    noise = synth.exp_noise(302, n, B, spec.vocab_top)
+    txt = synth.text_ids(303, B, spec.ctx_len_txt, spec.vocab_txt)
+    want = O.OracleStage2(spec, weights).sample(txt, B, n, noise, return_logits=True)
+    eng = engine_s2(spec, weights, B, 8)
+    ct, cb, lg = eng.sample(B, torch.from_numpy(txt), n, precision=PRECISION_EXACT, noise=torch.from_numpy(noise), return_logits=True,
+                            use_graph=False)
+    assert np.abs(np_(lg) - want[2]).max() <= LOGIT_TOL
+    assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all()
+    ft, fb = torch.from_numpy(want[0]), torch.from_numpy(want[1])
+    for graph in (False, True):
+        _, _, lf = eng.sample(B, torch.from_numpy(txt), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise), force_top=ft, force_bot=fb,
+                              return_logits=True, use_graph=graph)
+        gate(f'cc15m_prefill_shape.fast_logits(graph={graph})', np.abs(np_(lf) - want[2]).max(), 0.1)

@@ -90,7 +90,7 @@ def test_split_decode_reference_fixtures():
 def test_imagenet_size_decoder_all_precisions_vs_oracle():
     """The benchmark's own decoder (configs/imagenet-12l.yaml: ch 128, ch_mult [1, 2, 4, 4], 53.95 M parameters, 256 x 256)
     on 2 images of random codes against the CPU oracle: EXACT and SPLIT within 1e-4 (north_star's pixel bar), FAST (bf16)
-    within max 0.1 / mean 0.01."""
+    within max 0.08 / mean 0.01 (measured 0.043 / 0.0058)."""
     from hqtransformer_amd.config import load_config
     from hqtransformer_amd.spec import stage1_spec_from_config
     spec = stage1_spec_from_config(load_config(os.path.join(ROOT, 'configs', 'imagenet-12l.yaml')))
@@ -109,7 +109,7 @@ def test_imagenet_size_decoder_all_precisions_vs_oracle():
     assert e_exact <= PIXEL_TOL, e_exact
     fast = np_(eng.decode(tct, tcb, precision=PRECISION_FAST))
     d = np.abs(fast - want)
-    assert d.max() <= 0.1 and d.mean() <= 1e-2, (d.max(), d.mean())
+    assert d.max() <= 0.08 and d.mean() <= 1e-2, (d.max(), d.mean())      # measured 0.043 / 0.0058
     print(f'imagenet-size decoder vs oracle: exact {e_exact:.2e}, split {e_split:.2e}, fast max {d.max():.3f} mean {d.mean():.4f}, '
           f'output std {want.std():.3f}')
 
