@@ -97,6 +97,17 @@ class _Stage:
         self._drop_engine()
         return missing, unexpected
 
+    def from_ckpt(self, path: str, strict: bool = True, ignore_keys=None, strip_prefix: int = 0) -> None:
+        """``iHQGPT.from_ckpt`` (hierarchical_ar.py:880-886) / ``SimRQGAN2Generator.from_ckpt`` (generator.py:389-395): a Lightning
+        checkpoint's ``state_dict`` straight into this stage.  ``strip_prefix`` characters are cut from every key first (the
+        stage-1 generator's own from_ckpt cuts 10, ``'generator.'``); ``ignore_keys`` are dropped as the stage-2 method does."""
+        sd = torch.load(path, map_location='cpu')['state_dict']
+        sd = {k[strip_prefix:]: v for k, v in sd.items()}
+        for k in (ignore_keys or []):
+            del sd[k]
+        self.load_state_dict(sd, strict=strict)
+        print(f'{path} successfully restored..')
+
     def _need_gpu(self):
         if self._device.type != 'cuda':
             raise _lib.HqtLibraryError('the model is on the CPU: call .to("cuda") first (hqtransformer_amd has no CPU compute path)')
@@ -160,6 +171,9 @@ class HQVAEStage1(_Stage):
 
     def _ignored(self, key: str) -> bool:
         return stage1_is_ignored(key)
+
+    def from_ckpt(self, path: str, strict: bool = True) -> None:       # generator.py:389-395: keys lose their first 10 characters
+        super().from_ckpt(path, strict=strict, strip_prefix=10)
 
     def _prec(self, precision: Optional[str]) -> int:
         name = precision or self.precision

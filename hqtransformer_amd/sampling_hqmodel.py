@@ -52,7 +52,18 @@ def remap_legacy_keys(sd):
     return out
 
 
+def read_checkpoint(path: str):
+    """A checkpoint file as the reference writes them: Lightning's ``{'state_dict': ...}`` (``ckpt/last.ckpt``,
+    sampling_hqmodel.py:77) or a bare state dict (``ckpt/state_dict.ckpt``, eval_stage1.py:164-166)."""
+    obj = torch.load(path, map_location='cpu')
+    return obj['state_dict'] if isinstance(obj, dict) and 'state_dict' in obj and not torch.is_tensor(obj['state_dict']) else obj
+
+
 def load_model(model_path: str, device='cuda') -> ImageGPT2:
+    """The ``-m`` forms of the reference's drivers: a result directory (``config.yaml`` + ``ckpt/state_dict.ckpt`` if present,
+    else ``ckpt/last.ckpt``: eval_stage1.py:156-170, sampling_hqmodel.py:64-82), a checkpoint file inside ``<result>/ckpt/``
+    (sampling_hqmodel.py:65-66), or -- no reference counterpart -- a bare YAML config (random-init weights, what
+    measure_throughput builds).  Legacy ``stage1`` key prefixes are remapped (load_model_legacy, :45-61)."""
     if model_path.endswith(('.yaml', '.yml')):
         return ImageGPT2(load_config(model_path)).to(device)
     if 'ckpt' in model_path:
@@ -60,10 +71,19 @@ def load_model(model_path: str, device='cuda') -> ImageGPT2:
         ckpt_path = model_path
     else:
         config_path = os.path.join(model_path, 'config.yaml')
-        ckpt_path = os.path.join(model_path, 'ckpt/last.ckpt')
+        ckpt_path = os.path.join(model_path, 'ckpt/state_dict.ckpt')
+        if not os.path.exists(ckpt_path):
+            ckpt_path = os.path.join(model_path, 'ckpt/last.ckpt')
     print(ckpt_path)
     model = ImageGPT2(load_config(config_path))
-    sd = torch.load(ckpt_path, map_location='cpu')['state_dict']
+    model.load_state_dict(remap_legacy_keys(read_checkpoint(ckpt_path)), strict=True)
+    return model.to(device)
+
+
+def load_model_legacy(result_path: str, device='cuda') -> ImageGPT2:
+    """sampling_hqmodel.py:45-61: ``<result>/ckpt/last.ckpt`` whose stage-1 keys carry a 17-character legacy prefix."""
+    model = ImageGPT2(load_config(os.path.join(result_path, 'config.yaml')))
+    sd = torch.load(os.path.join(result_path, 'ckpt/last.ckpt'), map_location='cpu')['state_dict']
     model.load_state_dict(remap_legacy_keys(sd), strict=True)
     return model.to(device)
 

@@ -1,0 +1,60 @@
+"""Sample-sharded sampling with the real engine on more than one process: 2 ranks on the one visible GPU, gloo
+rendezvous, fresh child processes.  `sample_and_decode_sharded` keys class ids and Philox noise by the GLOBAL sample index
+(`sample_offset`), so the gathered result of the ragged 3 + 2 split must equal the unsharded run of the same global batch bit
+for bit -- codes AND pixels (EXACT arithmetic is batch-invariant)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_ranks(tmp_path, world, gb, steps, mode):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / f'sharded_{mode}.npz')
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dist_gpu_worker.py'), out, str(gb), str(steps), mode],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    return np.load(out), json.load(open(out + '.json'))
+
+
+@pytest.mark.parametrize('mode', ['exact', 'fast'])
+def test_two_ranks_on_one_gpu_equal_the_unsharded_run(tmp_path, mode):
+    gb, steps = 5, 64
+    got, info = run_ranks(tmp_path, 2, gb, steps, mode)
+    sys.path.insert(0, ROOT)
+    from hqtransformer_amd import synth
+    from hqtransformer_amd.config import load_config
+    from hqtransformer_amd.models import ImageGPT2
+    from hqtransformer_amd.sampling import sampling_ihqgpt
+    dev = torch.device('cuda:0')
+    model = ImageGPT2(load_config(os.path.join(ROOT, 'configs', 'tiny-cls.yaml')), seed=5).to(dev)
+    cond = torch.from_numpy(synth.class_ids(7, gb, model.stage2.spec.n_classes))
+    fast = mode == 'fast'
+    ct, cb = sampling_ihqgpt(model.stage2, num_candidates=gb, cond=cond, top_k_top=50, top_p_top=0.9, top_k_bot=None, top_p_bot=None,
+                             softmax_temperature=[1.0, 0.9], use_fp16=fast, is_tqdm=False, max_seq_len=steps, seed=1234, sample_offset=0)
+    px = model.stage1.decode_sequences(ct, cb, precision='fast' if fast else 'exact')
+    torch.cuda.synchronize()
+    assert np.array_equal(got['codes_top'], ct.cpu().numpy()) and np.array_equal(got['codes_bot'], cb.cpu().numpy())
+    if fast:       # bf16 GEMM tiles depend on the row count (3 / 2 / 5 rows pad differently): same codes, pixels to bf16 accuracy
+        assert np.abs(got['pixels'] - px.cpu().numpy()).max() <= 0.05
+    else:
+        assert np.array_equal(got['pixels'], px.cpu().numpy())
+    assert len(info['host_ms_per_submit_3_lanes']) == 2
+    print('host ms per submitted step (3 lanes) per rank:', [round(v, 3) for v in info['host_ms_per_submit_3_lanes']])

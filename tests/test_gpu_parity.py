@@ -713,3 +713,35 @@ def test_text_prefill_at_the_cc15m_shape_vs_oracle():
         _, _, lf = eng.sample(B, torch.from_numpy(txt), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise), force_top=ft, force_bot=fb,
                               return_logits=True, use_graph=graph)
         gate(f'cc15m_prefill_shape.fast_logits(graph={graph})', np.abs(np_(lf) - want[2]).max(), 0.1)
+
+
+@pytest.mark.parametrize('name', ['imagenet-24l', 'imagenet-42l', 'ffhq-24l'])
+def test_other_released_shapes_head_geometry_vs_oracle(name):
+    """The released configs beyond the benchmark's (configs/*.yaml, state-dict shapes pinned to the reference by fixture G11):
+    24 and 42 layers with the 6-layer depth head (hparams_dec), FFHQ's D = 1024 / 16 heads / 'reduce' embedding / unconditional
+    sos.  Shape-true in everything but the number of body layers (2, the oracle's cost): real width, heads, depth-head length,
+    vocabulary 8192, B = 64.  EXACT codes bit-exact and logits <= 2e-4; FAST teacher-forced within the bf16 gate."""
+    import dataclasses
+    import os
+    from hqtransformer_amd.config import load_config
+    from hqtransformer_amd.spec import stage2_spec_from_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = stage2_spec_from_config(load_config(os.path.join(root, 'configs', name + '.yaml')))
+    spec = dataclasses.replace(full, n_layers=2, ctx_len_img=64)
+    assert spec.n_layers_depth == (6 if name == 'imagenet-42l' else 4) and spec.vocab_top == 8192
+    weights = synth.stage2_weights(spec, 401, 'fixture')
+    B, n = 64, 2
+    noise = synth.exp_noise(402, n, B, spec.vocab_top)
+    cond = synth.class_ids(403, B, spec.n_classes) if spec.cond == 1 else None
+    want = O.OracleStage2(spec, weights).sample(cond, B, n, noise, (2048, None), (1.0, None), (0.95, 1.0), return_logits=True)
+    eng = engine_s2(spec, weights, B, 8)
+    tc = None if cond is None else torch.from_numpy(cond)
+    ct, cb, lg = eng.sample(B, tc, n, precision=PRECISION_EXACT, top_k=(2048, None), top_p=(1.0, None), temperature=(0.95, 1.0),
+                            noise=torch.from_numpy(noise), return_logits=True, use_graph=False)
+    assert np.abs(np_(lg) - want[2]).max() <= LOGIT_TOL
+    assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all()
+    for graph in (False, True):
+        _, _, lf = eng.sample(B, tc, n, precision=PRECISION_FAST, top_k=(2048, None), top_p=(1.0, None), temperature=(0.95, 1.0),
+                              noise=torch.from_numpy(noise), force_top=torch.from_numpy(want[0]), force_bot=torch.from_numpy(want[1]),
+                              return_logits=True, use_graph=graph)
+        gate(f'{name}.head_geometry.fast_logits(graph={graph})', np.abs(np_(lf) - want[2]).max(), 0.12)

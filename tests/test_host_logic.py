@@ -136,3 +136,21 @@ def test_text_front_end(tmp_path):
     (tmp_path / 'plain.txt').write_text('a cat\na dog\n')
     assert T.read_captions(str(tmp_path / 'val_list.txt')) == ['a cat', 'a dog'] == T.read_captions(str(tmp_path / 'plain.txt'))
     assert T.find_reference_vocab(str(tmp_path)) is None
+
+
+@pytest.mark.parametrize('name', ['imagenet-12l', 'imagenet-24l', 'imagenet-42l', 'ffhq-24l', 'cc15m-12l-txt'])
+def test_released_configs_match_the_reference_state_dict(name):
+    """Every released two-level stage-2 config (12 / 24 / 42 layers with the 6-layer depth head, FFHQ D = 1024 / 16 heads / 'reduce',
+    CC-15M text): the YAML of this repository yields exactly the state-dict keys and shapes of the reference's own iHQGPT built
+    from ITS YAML (fixture G11, tools/gen_released_shapes.py: the reference module on the meta device)."""
+    import json
+    want = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g11_released_shapes.json')))[name]
+    spec = stage2_spec_from_config(load_config(os.path.join(ROOT, 'configs', name + '.yaml')))
+    got = {k: list(v) for k, v in stage2_param_shapes(spec).items()}
+    ignore = {k for k in want['shapes'] if k not in got}
+    from hqtransformer_amd.spec import STAGE2_UNUSED
+    assert ignore <= set(STAGE2_UNUSED) | {k for k in ignore if k.endswith(('.mask', 'mask'))}, sorted(ignore)[:5]
+    assert {k: want['shapes'][k] for k in got} == got
+    n = sum(int(np.prod(v)) for v in got.values())
+    unused = sum(int(np.prod(want['shapes'][k])) for k in ignore)
+    assert n + unused == want['n_params']
