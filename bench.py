@@ -44,8 +44,12 @@ F32_PEAK_TFLOPS = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=12)
-    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--steps', type=int, default=100, help='timed steps; the default keeps the timed region above 5 s')
+    p.add_argument('--warmup', type=int, default=6)
+    p.add_argument('--sampler', choices=['harness', 'quality'], default='harness',
+                   help='harness: top_k = top_p = None, T = [1, 1] (measure_throughput/__main__.py:93-101, the headline); quality: top_k = 2048, '
+                        'top_p = 1.0, T = 0.95 on every level (checkpoints/README.md:6, the defaults of sampling_hqmodel.py:27-31) -- exercises the '
+                        'radix top-k and the sorted fp64-prefix top-p of the sampler kernel')
     p.add_argument('--config', default=os.path.join(ROOT, 'configs', 'imagenet-12l.yaml'))
     p.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     p.add_argument('--precision', choices=['fast', 'exact'], default='fast',
@@ -61,6 +65,8 @@ def parse():
     p.add_argument('--no-graph', action='store_true')
     p.add_argument('--inflight', type=int, default=3, help='batches in flight per GPU: consecutive steps are round-robined over this many '
                    'lanes (own HIP stream, KV cache and activations; shared weights).  1 = the serial order of the reference harness')
+    p.add_argument('--merge', type=int, default=4, help='execute this many queued steps as ONE pass of merge x batch rows (every step keeps its own class id, '
+                   'Philox seed and global row indices: per step the same draws as unmerged; the weights are streamed once for all of them)')
     p.add_argument('--overlap', action='store_true', help='EXPERIMENT: run the decode of batch k on a second stream underneath the AR '
                    'loop of batch k+1 (measured slower on MI355X: the decoder starves the latency-bound AR kernels)')
     p.add_argument('--positions', type=int, default=0, help='DEBUG ONLY (counter collection): sample this many top positions '
@@ -157,6 +163,8 @@ def main():
         n_pos = min(n_pos, args.positions)
     fast = args.precision == 'fast'
     dec_prec = args.decode_precision or ('split' if fast else 'exact')
+    quality = args.sampler == 'quality'
+    tk, tp, T = (2048, 1.0, 0.95) if quality else (None, None, 1.0)
     classes = synth.class_ids(1000 + rank, args.steps + args.warmup + 4, max(s2.n_classes, 1))
     txt_cond = s2.cond == 2                 # text-conditional configs (BASELINE configs[4]): synthetic prompt ids, resident in HBM
     prompts = [torch.from_numpy(synth.text_ids(2000 + 131 * rank + i, B, s2.ctx_len_txt, s2.vocab_txt)).to(dev)
@@ -170,16 +178,18 @@ def main():
         gathered = [torch.empty((B, s1.out_ch, H, H), dtype=torch.float32, device=dev) for _ in range(world)]
 
     three = s2.levels == 3
+    samp_kw = (dict(top_k=[tk] * 3, top_p=[tp] * 3, softmax_temperature=[T] * 3) if three else
+               dict(top_k_top=tk, top_p_top=tp, top_k_bot=tk, top_p_bot=tp, softmax_temperature=[T, T]))
 
     def sample_codes(i, graph):
         """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels)."""
         if three:
-            c = sampling_hqtransformer(model.stage2, num_candidates=B, cond=cond_of(i), top_k=[None] * 3, top_p=[None] * 3,
-                                       softmax_temperature=[1.0] * 3, use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i,
+            c = sampling_hqtransformer(model.stage2, num_candidates=B, cond=cond_of(i), top_k=[tk] * 3, top_p=[tp] * 3,
+                                       softmax_temperature=[T] * 3, use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i,
                                        sample_offset=rank * B, use_graph=graph)
             return c[0], c[1:]
-        return sampling_ihqgpt(model.stage2, num_candidates=B, cond=cond_of(i), top_k_top=None, top_p_top=None, top_k_bot=None,
-                               top_p_bot=None, softmax_temperature=[1.0, 1.0], use_fp16=fast, is_tqdm=False, max_seq_len=n_pos,
+        return sampling_ihqgpt(model.stage2, num_candidates=B, cond=cond_of(i), top_k_top=tk, top_p_top=tp, top_k_bot=tk,
+                               top_p_bot=tp, softmax_temperature=[T, T], use_fp16=fast, is_tqdm=False, max_seq_len=n_pos,
                                model_stage1=None, seed=1 + i, sample_offset=rank * B, use_graph=graph)
 
     def decode(ct, cb, m=None):
@@ -219,7 +229,12 @@ def main():
     #      one complete batch-B pass (64-position AR loop + decode + clamp [+ gather]); lanes only change the schedule.
     from hqtransformer_amd.pipeline import InflightSampler
     inflight = max(1, args.inflight)
-    pipe = InflightSampler(model, lanes=inflight, device=dev)
+    merge = max(1, args.merge)
+    if txt_cond or three or args.positions:
+        merge = 1                                  # merged steps: class-conditional / unconditional two-level sampling only
+    if args.steps % merge:
+        raise SystemExit(f'--steps must be divisible by --merge ({merge})')
+    pipe = InflightSampler(model, lanes=inflight, device=dev, merge=merge)
 
     def after(ct, cb, px):
         if dist is not None and args.gather == 'pixels':
@@ -228,16 +243,17 @@ def main():
             dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
 
     debug_short = n_pos < n_full            # --positions (counter collection): the padded decode of step(), one lane, no pipeline
-    for li in range(0 if debug_short else max(inflight, args.warmup)):  # every lane at least once: workspace, graph capture
+    for li in range(0 if debug_short else max(inflight, args.warmup) * merge):  # every lane at least once: workspace, graph capture
         pipe.submit(B, cond_of(li), seed=1000 + li, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
-                    use_graph=not args.no_graph, after=after, precision=dec_prec)
+                    use_graph=not args.no_graph, after=after, precision=dec_prec, **samp_kw)
     pipe.drain()
     barrier()
     t0 = time.perf_counter()
     kept = [step(args.warmup + k) for k in range(args.steps)] if debug_short else \
            [pipe.submit(B, cond_of(args.warmup + k), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
                         sample_offset=rank * B, use_graph=not args.no_graph, after=after, precision=dec_prec,
-                        order_after_current=not os.environ.get('HQT_BENCH_NO_ORDER')) for k in range(args.steps)]
+                        order_after_current=not os.environ.get('HQT_BENCH_NO_ORDER'), **samp_kw) for k in range(args.steps)]
+    host_submit_s = time.perf_counter() - t0      # when the last step was handed to HIP (host-bound if this is the whole region)
     pipe.drain()
     barrier()
     elapsed_lanes = time.perf_counter() - t0
@@ -292,7 +308,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if fast else 'f32', 'data': 'synthetic',
             'config': {'workload': (f'text-to-image ({s2.ctx_len_txt}-token synthetic prompts, prefill + ' if txt_cond else 'imagenet256-classcond (') + f'hq-vae({"8x8+16x16+32x32, three code levels" if three else "8x8+16x16"})+hq-transformer {s2.n_layers}L/{s2.embed_dim}d), '
-                                   f'batch {B}/GPU, {n_pos} top positions, top_k=top_p=None, T=[1,1]',
+                                   f'batch {B}/GPU, {n_pos} top positions, ' + (f'top_k={tk}, top_p={tp}, T={T} (quality-mode sampler)' if quality else 'top_k=top_p=None, T=[1,1]'),
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
                        'precision': {'ar': 'FAST: bf16 weights + MFMA, fp32 accumulate / LayerNorm / softmax / sampler (the reference harness samples under fp16 autocast)' if fast else 'EXACT: fp32',
                                      'decode': {'split': 'SPLIT: fp32-accurate on the matrix cores (fp16 hi/lo operands, 3 MFMAs per term, fp32 accumulate); pixels within 1e-4 of the fp32 oracle '
@@ -301,7 +317,11 @@ def main():
                                                 'exact': 'EXACT: fp32 FMA chains on the vector ALUs'}[dec_prec]},
                        'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph,
                        'pipeline': (f'{inflight} steps in flight per GPU (round-robin over {inflight} lanes: own HIP stream, KV cache and '
-                                    f'activations, shared weights, throughput-oriented GEMM tiles); each step is one full batch-{B} pass') if inflight > 1 else 'serial'},
+                                    f'activations, shared weights, throughput-oriented GEMM tiles); each step is one full batch-{B} pass') if inflight > 1 else 'serial',
+                       'merge': (f'{merge} consecutive steps execute as one pass of {merge * B} rows (own class id, Philox seed and global row indices per step: '
+                                 f'the draws of a step do not depend on what it is merged with)') if merge > 1 else 'none'},
+            'host_ms_per_step': round(1000 * host_submit_s / args.steps, 3),
+            'env_switches': {k: v for k, v in sorted(os.environ.items()) if k.startswith('HQT_')},
             'serial': {'value': round(serial_value, 2), 'ms_per_step': round(serial_ms, 3), 'steps': n_serial,
                        'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
                        'note': 'the same steps one at a time on one lane (the reference harness order)'},
@@ -359,6 +379,9 @@ def main():
                         'traffic': pmc_traffic('stream_gemm'), 'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3),
                         'total_ms': round(gemm_ms, 3), 'algorithmic_bytes_per_launch': round(wbytes / n_l),
                         'eager_to_graph_scale': round(ar_scale, 4),
+                        'frac_timed_region': round(wbytes * args.steps / elapsed_lanes / 1e9 / HBM_PEAK_GBS, 4),
+                        'traffic_source': 'profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of a bounded run of this kernel family, '
+                                          'committed with the repository; NOT collected by this invocation',
                         'note': 'per-launch figure of the kernels the timed region runs (throughput policy when several steps are in flight), '
                                 'measured one lane at a time; with several lanes launches overlap',
                         'ar_ms_one_lane_this_policy': round(ar_ms, 3), 'ar_ms_one_lane_latency_policy': round(ar_ms_serial, 3),
@@ -385,6 +408,12 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, s2, s1, B)
+        if not txt_cond and not three and s2.n_layers == 12:
+            # the reference ITSELF (PyTorch CPU, fp32, 8 threads) as measured once in the build container, BASELINE.md section 2 -- it cannot
+            # run on the GPU box (its sources do not travel); quoted so that the port above can be compared with the real thing
+            out['cpu_baseline_reference'] = {'value': 0.40, 'unit': 'images/s', 'cores': 8, 'kind': 'reference',
+                                             'sample': 'kakaobrain/hqtransformer on torch CPU in the build container: sampling_ihqgpt 2.19 s per 8 of 64 positions at B = 8 '
+                                                       '(2.2 s/image) + decode_code 0.334 s/image at batch 1 = 2.52 s/image (BASELINE.md section 2); not re-measured by this run'}
 
     if rank == 0:
         print(json.dumps(out))

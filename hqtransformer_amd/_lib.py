@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'mfma_gemm.hip', 'split_conv.hip']
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT = 0, 1, 2
 PRECISIONS = {'exact': PRECISION_EXACT, 'fast': PRECISION_FAST, 'split': PRECISION_SPLIT}
@@ -59,6 +59,7 @@ class hqt_sample_opts(C.Structure):
         ('temperature_top', C.c_float), ('temperature_bot', C.c_float),
         ('seed', C.c_uint64), ('sample_offset', C.c_int64),
         ('use_graph', C.c_int32),
+        ('row_seeds', C.c_void_p), ('row_offsets', C.c_void_p),
     ]
 
 
@@ -68,6 +69,7 @@ class hqt_sample_opts_l3(C.Structure):
         ('top_k', C.c_int32 * 3), ('top_p', C.c_float * 3), ('temperature', C.c_float * 3),
         ('seed', C.c_uint64), ('sample_offset', C.c_int64),
         ('use_graph', C.c_int32),
+        ('row_seeds', C.c_void_p), ('row_offsets', C.c_void_p),
     ]
 
 

@@ -179,8 +179,10 @@ struct GemmArgs {
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call
     int step;                // current top position (0-based)
     int t_base;              // KV rows already in the body cache
-    unsigned long long seed; // Philox key of this hqt_sample call
-    long long sample_offset; // global index of row 0 of this call
+};
+struct RowKey {              // per batch row, device memory owned by the handle: the Philox key of the row's call and its global index
+    unsigned long long seed;
+    long long global_row;
 };
 
 #define HQT_MAX_V 16384

@@ -119,6 +119,8 @@ struct hqt_handle {
     size_t splitk_elems = 0;
     struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
     StepState* state = nullptr;
+    RowKey* rows = nullptr;                   // [max_batch] Philox seed + global row of every batch row of the current call
+    std::vector<RowKey> rows_host;
     int64_t *cond_buf = nullptr, *codes_top = nullptr, *codes_bot = nullptr;   // call-independent homes of cond / the drawn codes
     int64_t* codes_l2 = nullptr;              // third level: [B, max_steps, 16]
     Lin head_l2;                              // head_levels.2 (three-level models; head_top / head_bot hold levels 0 / 1)
@@ -372,6 +374,7 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), (void**)&h->xs_ctr, 4096 * 4, true));
         HIPCHK(hipMemset(h->xs_ctr, 0, 4096 * 4));
         CHK(dev_alloc(h.get(), (void**)&h->state, sizeof(StepState), true));
+        CHK(dev_alloc(h.get(), (void**)&h->rows, B * sizeof(RowKey), true));
         CHK(dev_alloc(h.get(), (void**)&h->cond_buf, B * (size_t)std::max(1, c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1) * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->codes_top, B * (size_t)c.max_steps * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->codes_bot, B * (size_t)c.max_steps * 4 * 8, true));
@@ -1039,7 +1042,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     {
         Timed t(h, "sampler", c.st);
         SamplerArgs s{h->logits, B, V, 1, B, c.o.temperature_top, c.o.top_k_top, c.o.top_p_top, c.noise, 0,
-                      h->state, c.o.n_steps, c.out_top, c.logits_out};
+                      h->state, h->rows, c.o.n_steps, c.out_top, c.logits_out};
         // the draw and the embedding lookup of the drawn code in one kernel: the sampler's workgroup of sample b also writes the
         // four input rows of depth sub-step 1 (HQT_NO_FUSED_EMBED=1: separate depth_embed_kernel, for A/B runs)
         static const bool fuse = !getenv("HQT_NO_FUSED_EMBED");
@@ -1076,7 +1079,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     {
         Timed t(h, "sampler", c.st);
         SamplerArgs s{h->logits, 4 * B, V, 4, B, c.o.temperature_bot, c.o.top_k_bot, c.o.top_p_bot, c.noise, 1,
-                      h->state, c.o.n_steps, c.out_bot, c.logits_out};
+                      h->state, h->rows, c.o.n_steps, c.out_bot, c.logits_out};
         HIPCHK(launch_sampler(s, c.st));
     }
     return HQT_OK;
@@ -1146,7 +1149,7 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
         {
             Timed t(h, "sampler", c.st);
             SamplerArgs sa{h->logits, M, V, Tq, B, c.temperature[lv], c.top_k[lv], c.top_p[lv], c.noise, draw0[lv],
-                           h->state, c.o.n_steps, outs[lv], c.logits_out, 21};
+                           h->state, h->rows, c.o.n_steps, outs[lv], c.logits_out, 21};
             HIPCHK(launch_sampler(sa, c.st));
         }
     }
@@ -1229,7 +1232,7 @@ extern "C" int hqt_sample_l3(hqt_handle* h, int B, const int64_t* cond, const hq
     c.B = B; c.cond = cond ? h->cond_buf : nullptr; c.noise = noise;
     c.o = hqt_sample_opts{};                        // the shared loop reads n_steps / seed / offsets / graph flag from here
     c.o.precision = opts->precision; c.o.n_steps = opts->n_steps; c.o.seed = opts->seed; c.o.sample_offset = opts->sample_offset;
-    c.o.use_graph = opts->use_graph;
+    c.o.use_graph = opts->use_graph; c.o.row_seeds = opts->row_seeds; c.o.row_offsets = opts->row_offsets;
     c.o.top_k_top = opts->top_k[0]; c.o.top_k_bot = opts->top_k[1]; c.o.top_p_top = opts->top_p[0]; c.o.top_p_bot = std::max(opts->top_p[1], opts->top_p[2]);
     c.o.temperature_top = opts->temperature[0]; c.o.temperature_bot = opts->temperature[1];
     for (int i = 0; i < 3; ++i) { c.top_k[i] = opts->top_k[i]; c.top_p[i] = opts->top_p[i]; c.temperature[i] = opts->temperature[i]; }
@@ -1256,7 +1259,16 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
     const float* noise = c.noise;
     float* logits_out = c.logits_out;
     HIPCHK(sampler_configure(cf.vocab_top, opts->top_p_top > 0.f || opts->top_p_bot > 0.f));
-    HIPCHK(launch_set_step(h->state, 0, 0, opts->seed, opts->sample_offset, c.st));
+    HIPCHK(launch_set_step(h->state, 0, 0, c.st));
+    if (opts->row_seeds || opts->row_offsets) {      // merged steps: per-row Philox keys (host arrays, staged through pinned-free pageable copies: B <= max_batch entries)
+        if (!opts->row_seeds || !opts->row_offsets) return fail(HQT_ERR_INVALID, "row_seeds and row_offsets come together");
+        std::vector<RowKey>& rk = h->rows_host;      // handle-owned staging (a pageable source is copied out before hipMemcpyAsync returns;
+        rk.resize((size_t)B);                        //  keeping it alive anyway costs nothing and needs no stream synchronisation)
+        for (int b = 0; b < B; ++b) { rk[b].seed = opts->row_seeds[b]; rk[b].global_row = opts->row_offsets[b]; }
+        HIPCHK(hipMemcpyAsync(h->rows, rk.data(), (size_t)B * sizeof(RowKey), hipMemcpyHostToDevice, c.st));
+    } else {
+        HIPCHK(launch_set_rows(h->rows, B, opts->seed, opts->sample_offset, c.st));
+    }
     int first = 0;
     if (cf.cond_type == HQT_COND_TEXT) {     // 64-token causal prefill (sampling.py:187-190, layers.py:107-111)
         const int T = cf.ctx_len_txt;

@@ -88,7 +88,8 @@ struct SamplerArgs {
     float top_p;                 // <= 0: none
     const float* noise;          // [n_steps, 5, B, V] or NULL
     int draw0;                   // first draw index of slot 0 (0 for top, 1 for bottom; 5 for the third level)
-    const StepState* state;      // step, Philox seed and global row offset of the current call
+    const StepState* state;      // step of the current call
+    const RowKey* rows;          // [B] Philox seed and global row index of every batch row (merged steps: they differ per row)
     int n_steps;
     int64_t* out;                // top: [B, n_steps]; bottom: [B, n_steps, 4]
     float* logits_out;           // optional [n_steps, draws, B, V]
@@ -115,7 +116,9 @@ hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, i
 hipError_t sampler_configure(int V, bool use_top_p);
 
 hipError_t launch_advance_step(StepState* state, int d_tbase, hipStream_t st);
-hipError_t launch_set_step(StepState* state, int step, int t_base, uint64_t seed, int64_t sample_offset, hipStream_t st);
+hipError_t launch_set_step(StepState* state, int step, int t_base, hipStream_t st);
+// rows[b] = (seed, sample_offset + b) for b < B
+hipError_t launch_set_rows(RowKey* rows, int B, uint64_t seed, int64_t sample_offset, hipStream_t st);
 
 // int64 codes [B, n_steps(,4)] written by the sampler are final; this copies forced codes into the
 // feed-back arrays when teacher forcing is on.

@@ -47,15 +47,21 @@ __device__ __forceinline__ void emit_packed_row(const float* x, int m, int D, bf
 // step state
 // ---------------------------------------------------------------------------------------------
 __global__ void advance_step_kernel(StepState* s, int d_tbase) { s->step += 1; s->t_base += d_tbase; }
-__global__ void set_step_kernel(StepState* s, int step, int t_base, unsigned long long seed, long long sample_offset) {
-    s->step = step; s->t_base = t_base; s->seed = seed; s->sample_offset = sample_offset;
+__global__ void set_step_kernel(StepState* s, int step, int t_base) { s->step = step; s->t_base = t_base; }
+__global__ void set_rows_kernel(RowKey* rows, int B, unsigned long long seed, long long sample_offset) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { rows[b].seed = seed; rows[b].global_row = sample_offset + b; }
+}
+hipError_t launch_set_rows(RowKey* rows, int B, uint64_t seed, int64_t sample_offset, hipStream_t st) {
+    set_rows_kernel<<<(B + 255) / 256, 256, 0, st>>>(rows, B, (unsigned long long)seed, (long long)sample_offset);
+    return hipGetLastError();
 }
 hipError_t launch_advance_step(StepState* s, int d_tbase, hipStream_t st) {
     advance_step_kernel<<<1, 1, 0, st>>>(s, d_tbase);
     return hipGetLastError();
 }
-hipError_t launch_set_step(StepState* s, int step, int t_base, uint64_t seed, int64_t sample_offset, hipStream_t st) {
-    set_step_kernel<<<1, 1, 0, st>>>(s, step, t_base, (unsigned long long)seed, (long long)sample_offset);
+hipError_t launch_set_step(StepState* s, int step, int t_base, hipStream_t st) {
+    set_step_kernel<<<1, 1, 0, st>>>(s, step, t_base);
     return hipGetLastError();
 }
 
@@ -560,9 +566,9 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
     // ---- draw: argmax_i p_i / q_i, lowest index on ties
     float best = -1.0f;
     int besti = 0;
-    const uint64_t seed = a.state->seed;                 // per-call values live in device memory: the captured graph is call-independent
+    const uint64_t seed = a.rows[b].seed;                // per-call / per-row values live in device memory: the captured graph is call-independent
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    const uint64_t grow = (uint64_t)(a.state->sample_offset + b);
+    const uint64_t grow = (uint64_t)a.rows[b].global_row;
     for (int i4 = tid; i4 * 4 < V; i4 += NT) {
         float q[4];
         if (a.noise) {

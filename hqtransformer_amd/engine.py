@@ -158,13 +158,28 @@ class Engine:
                              f'{getattr(t, "dtype", type(t))} {tuple(getattr(t, "shape", ()))} on {getattr(t, "device", "?")}')
         return t
 
+    @staticmethod
+    def _row_keys(o, B: int, row_seeds, row_offsets):
+        """Fills ``o.row_seeds`` / ``o.row_offsets`` (host arrays of B entries) and returns them so that they outlive the call."""
+        if row_seeds is None and row_offsets is None:
+            return None
+        if row_seeds is None or row_offsets is None or len(row_seeds) != B or len(row_offsets) != B:
+            raise ValueError(f'row_seeds and row_offsets come together, {B} entries each')
+        rs = (C.c_uint64 * B)(*[int(v) & (2 ** 64 - 1) for v in row_seeds])
+        ro = (C.c_int64 * B)(*[int(v) for v in row_offsets])
+        o.row_seeds, o.row_offsets = C.cast(rs, C.c_void_p), C.cast(ro, C.c_void_p)
+        return rs, ro
+
     # ------------------------------------------------------------------ stage 2
     def sample(self, batch: int, cond: Optional[torch.Tensor], n_steps: int, *, precision: int = PRECISION_FAST,
                top_k: Sequence[Optional[int]] = (None, None), top_p: Sequence[Optional[float]] = (None, None),
                temperature: Sequence[float] = (1.0, 1.0), noise: Optional[torch.Tensor] = None, seed: int = 0,
                sample_offset: int = 0, force_top: Optional[torch.Tensor] = None, force_bot: Optional[torch.Tensor] = None,
                return_logits: bool = False, use_graph: bool = True,
-               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+               row_seeds: Optional[Sequence[int]] = None, row_offsets: Optional[Sequence[int]] = None):
+        """``row_seeds`` / ``row_offsets`` (both or neither, ``batch`` entries): merged steps -- row b draws what the row with
+        global index ``row_offsets[b]`` of a call seeded ``row_seeds[b]`` draws (``hqt_sample_opts.row_seeds``)."""
         dev = self.device
         B, V = int(batch), self.s2.vocab_top
         o = hqt_sample_opts()
@@ -175,6 +190,7 @@ class Engine:
         o.top_p_bot = float(top_p[1]) if top_p[1] else 0.0
         o.temperature_top, o.temperature_bot = float(temperature[0]), float(temperature[1])
         o.seed, o.sample_offset, o.use_graph = int(seed) & (2 ** 64 - 1), int(sample_offset), int(bool(use_graph))
+        rows = self._row_keys(o, B, row_seeds, row_offsets)
 
         def prep(t, shape, dtype, what, table=0):
             if t is None:
@@ -208,7 +224,7 @@ class Engine:
             _lib.check(self.lib.hqt_sample(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(force_top), _ptr(force_bot),
                                            _ptr(logits), _ptr(out_top), _ptr(out_bot), C.c_void_p(stream)))
         # inputs must outlive the asynchronous launches
-        self._keep = (cond, noise, force_top, force_bot)
+        self._keep = (cond, noise, force_top, force_bot, rows)
         self._trust(out_top, out_bot)              # the sampler only writes ids inside the vocabulary
         if return_logits:
             return out_top, out_bot, logits
@@ -219,7 +235,7 @@ class Engine:
                 top_k: Sequence[Optional[int]] = (None, None, None), top_p: Sequence[Optional[float]] = (None, None, None),
                 temperature: Sequence[float] = (1.0, 1.0, 1.0), noise: Optional[torch.Tensor] = None, seed: int = 0,
                 sample_offset: int = 0, force: Optional[Sequence[torch.Tensor]] = None, return_logits: bool = False,
-                use_graph: bool = True):
+                use_graph: bool = True, row_seeds: Optional[Sequence[int]] = None, row_offsets: Optional[Sequence[int]] = None):
         """Three-level sampling: returns (codes0 [B, n], codes1 [B, n, 4], codes2 [B, n, 16][, logits [n, 21, B, V]])."""
         dev = self.device
         B, V = int(batch), self.s2.vocab_top
@@ -230,6 +246,7 @@ class Engine:
             o.top_p[i] = float(top_p[i]) if top_p[i] else 0.0
             o.temperature[i] = float(temperature[i])
         o.seed, o.sample_offset, o.use_graph = int(seed) & (2 ** 64 - 1), int(sample_offset), int(bool(use_graph))
+        rows = self._row_keys(o, B, row_seeds, row_offsets)
 
         def prep(t, shape, dtype, what, table=0):
             if t is None:
@@ -257,7 +274,7 @@ class Engine:
         with torch.cuda.device(dev):
             _lib.check(self.lib.hqt_sample_l3(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(f[0]), _ptr(f[1]), _ptr(f[2]),
                                               _ptr(logits), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), C.c_void_p(stream)))
-        self._keep = (cond, noise, f)
+        self._keep = (cond, noise, f, rows)
         self._trust(*outs)
         return (outs[0], outs[1], outs[2], logits) if return_logits else tuple(outs)
 

@@ -6,6 +6,11 @@ of the 256 CUs busy and is bound by per-CU latency; independent chains interleav
 therefore round-robins consecutive batches over N *lanes*: every lane has its own stream, KV cache and activations
 (``hqt_clone``) and shares the weights, every batch is still one complete ``sampling_ihqgpt`` + ``decode_code`` pass
 of the configured batch size, and results do not depend on the lane (bit-identical, tests/test_gpu_surface.py).
+
+``merge=k`` additionally executes k queued steps as ONE pass of k x B rows: the steps stay independent -- every row keeps the class
+id, the Philox seed and the global row index of its own step (``hqt_sample_opts.row_seeds`` / ``row_offsets``), so in EXACT
+arithmetic each step's codes are bit-identical to the unmerged call (tests/test_gpu_surface.py) -- but the weights are streamed
+once for all of them instead of once per step.
 """
 from __future__ import annotations
 
@@ -17,11 +22,26 @@ from ._lib import POLICY_LATENCY, POLICY_THROUGHPUT
 from .sampling import sampling_hqtransformer, sampling_ihqgpt
 
 
+class Pending:
+    """Result of a step queued on a merging sampler: filled when its group is launched (``InflightSampler.flush`` / ``drain``)."""
+    __slots__ = ('value',)
+
+    def __init__(self):
+        self.value = None
+
+    def get(self):
+        if self.value is None:
+            raise RuntimeError('the step has not been launched yet: call flush() or drain() first')
+        return self.value
+
+
 class InflightSampler:
-    def __init__(self, model, lanes: int = 3, device: Optional[torch.device] = None):
-        if lanes < 1:
-            raise ValueError('lanes must be >= 1')
+    def __init__(self, model, lanes: int = 3, device: Optional[torch.device] = None, merge: int = 1):
+        if lanes < 1 or merge < 1:
+            raise ValueError('lanes and merge must be >= 1')
         self.model = model
+        self.merge = int(merge)
+        self._queue: list = []
         self.n = int(lanes)
         self.device = device if device is not None else model.stage2._device
         self.streams: List[torch.cuda.Stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
@@ -33,6 +53,65 @@ class InflightSampler:
         """Queue one batch on the next lane; returns (codes_top, codes_bot, pixels or None, done_event) immediately.
         The tensors are valid once ``done_event`` has completed (or after ``drain()``).  ``phase_events``: three timing
         events recorded on the lane's stream at AR start / AR end / decode end (lane time: phases of different lanes overlap)."""
+        if self.merge > 1:
+            if decode is False or phase_events is not None or sample_kw.get('noise') is not None or getattr(self.model.stage2, 'use_txt_cond', False):
+                raise ValueError('merged steps support the plain class-conditional / unconditional sample + decode step only')
+            p = Pending()
+            self._queue.append((p, num_candidates, cond, seed, max_seq_len, use_fp16, precision, clamp01, use_graph, after, order_after_current, sample_kw))
+            if len(self._queue) >= self.merge:
+                self.flush()
+            return p
+        return self._launch(num_candidates, cond, seed=seed, max_seq_len=max_seq_len, use_fp16=use_fp16, decode=decode, precision=precision,
+                            clamp01=clamp01, use_graph=use_graph, after=after, phase_events=phase_events, order_after_current=order_after_current,
+                            **sample_kw)
+
+    def flush(self) -> None:
+        """Launch the queued steps (merge > 1) as one pass; their Pending objects receive (codes_top, codes_bot, pixels, done_event)."""
+        q, self._queue = self._queue, []
+        if not q:
+            return
+        ref = q[0]
+
+        def settings(e):
+            return (e[4], e[5], e[6], e[7], e[8], {k: v for k, v in e[11].items() if k != 'sample_offset'})
+        for e in q[1:]:
+            if settings(e) != settings(ref):
+                raise ValueError('steps merged into one pass must share max_seq_len, precision and sampler settings')
+        sizes = [e[1] for e in q]
+        kw = dict(ref[11])
+        offs = [int(e[11].get('sample_offset', 0)) for e in q]
+        kw.pop('sample_offset', None)
+        cls = getattr(self.model.stage2, 'use_cls_cond', False)
+        cond = None
+        if cls:
+            parts = []
+            for e, n in zip(q, sizes):
+                c = torch.as_tensor(e[2]).reshape(-1).to('cpu', torch.int64)
+                parts.append(c.expand(n) if c.numel() == 1 else c)
+            cond = torch.cat(parts)
+        seeds = [int(e[3]) if e[3] is not None else int(torch.randint(0, 2 ** 62, (1,)).item()) for e in q]
+        row_seeds = [s for s, n in zip(seeds, sizes) for _ in range(n)]
+        row_offsets = [o + i for o, n in zip(offs, sizes) for i in range(n)]
+        afters = [e[9] for e in q]
+
+        def split_after(ct, cb, px):
+            lo = 0
+            for n, a in zip(sizes, afters):
+                if a is not None:
+                    a(ct[lo:lo + n], [c[lo:lo + n] for c in cb] if isinstance(cb, (list, tuple)) else cb[lo:lo + n], None if px is None else px[lo:lo + n])
+                lo += n
+        ct, cb, px, ev = self._launch(sum(sizes), cond, seed=seeds[0], max_seq_len=ref[4], use_fp16=ref[5], decode=True, precision=ref[6], clamp01=ref[7],
+                                      use_graph=ref[8], after=split_after if any(a is not None for a in afters) else None,
+                                      order_after_current=any(e[10] for e in q), row_seeds=row_seeds, row_offsets=row_offsets, **kw)
+        lo = 0
+        for e, n in zip(q, sizes):
+            e[0].value = (ct[lo:lo + n], [c[lo:lo + n] for c in cb] if isinstance(cb, (list, tuple)) else cb[lo:lo + n],
+                          None if px is None else px[lo:lo + n], ev)
+            lo += n
+
+    def _launch(self, num_candidates: int, cond, *, seed: Optional[int] = None, max_seq_len: int = 64, use_fp16: bool = True,
+                decode: bool = True, precision: Optional[str] = None, clamp01: bool = True, use_graph: bool = True,
+                after=None, phase_events=None, order_after_current: bool = True, **sample_kw):
         lane = self.k % self.n
         self.k += 1
         st = self.streams[lane]
@@ -84,7 +163,8 @@ class InflightSampler:
             self.model.stage2.engine(batch, max_seq_len, 0).set_policy(POLICY_LATENCY)
 
     def drain(self) -> None:
-        """Wait for every lane; also orders the caller's stream after the lanes."""
+        """Launch what is still queued (merge > 1), wait for every lane; also orders the caller's stream after the lanes."""
+        self.flush()
         cur = torch.cuda.current_stream(self.device)
         for st in self.streams:
             cur.wait_stream(st)

@@ -36,7 +36,9 @@ def sampling_ihqgpt(model,
                     sample_offset: int = 0,
                     seed: Optional[int] = None,
                     use_graph: bool = True,
-                    lane: int = 0):
+                    lane: int = 0,
+                    row_seeds=None,
+                    row_offsets=None):
     """Returns ``(codes_top int64 [B, max_seq_len], codes_bot int64 [B, max_seq_len, 4])`` on the model's GPU.
 
     ``model`` is ``ImageGPT2.stage2``.  ``cond``: python int (class id, repeated for every candidate), an
@@ -46,7 +48,9 @@ def sampling_ihqgpt(model,
     are accepted and ignored (the latter only feeds a dead branch, hierarchical_ar.py:697-699).
     Extensions: ``noise`` fp32 [max_seq_len, 5, B, V] Exp(1) variates (draw = argmax(p/q), the multinomial
     identity) for bit-reproducible runs; ``sample_offset``/``seed`` for sharded batches; ``lane`` selects one of
-    several workspaces over the same weights (one per batch in flight, see ``hqtransformer_amd.pipeline``).
+    several workspaces over the same weights (one per batch in flight, see ``hqtransformer_amd.pipeline``);
+    ``row_seeds`` / ``row_offsets`` (B entries each): merged steps -- row b draws what global row ``row_offsets[b]`` of a call
+    seeded ``row_seeds[b]`` would draw, so several independent calls can share one pass over the weights.
     """
     spec = model.spec
     if model.use_txt_cond:
@@ -80,7 +84,8 @@ def sampling_ihqgpt(model,
         seed = _seed_from_torch()
     return eng.sample(B, cond, max_seq_len, precision=PRECISION_FAST if use_fp16 else PRECISION_EXACT,
                       top_k=(top_k_top, top_k_bot), top_p=(top_p_top, top_p_bot), temperature=softmax_temperature,
-                      noise=noise, seed=seed or 0, sample_offset=sample_offset, force_top=force_top, use_graph=use_graph)
+                      noise=noise, seed=seed or 0, sample_offset=sample_offset, force_top=force_top, use_graph=use_graph,
+                      row_seeds=row_seeds, row_offsets=row_offsets)
 
 
 def sampling_hqtransformer(model,
@@ -97,7 +102,9 @@ def sampling_hqtransformer(model,
                            sample_offset: int = 0,
                            seed: Optional[int] = None,
                            use_graph: bool = True,
-                           lane: int = 0):
+                           lane: int = 0,
+                           row_seeds=None,
+                           row_offsets=None):
     """Counterpart of ``hqvae.utils.sampling.sampling_hqtransformer`` (sampling.py:240-307) for the three-level
     HQTransformer: returns ``[codes0 int64 [B, L], codes1 [B, L, 4], codes2 [B, L, 16]]`` on the model's GPU.
     ``top_k`` / ``top_p`` / ``softmax_temperature`` are per-level lists (None = no cut-off); ``cond`` as in
@@ -129,7 +136,8 @@ def sampling_hqtransformer(model,
     if seed is None and noise is None:
         seed = _seed_from_torch()
     return list(eng.sample3(B, cond, max_seq_len, precision=PRECISION_FAST if use_fp16 else PRECISION_EXACT, top_k=top_k, top_p=top_p,
-                            temperature=softmax_temperature, noise=noise, seed=seed or 0, sample_offset=sample_offset, use_graph=use_graph))
+                            temperature=softmax_temperature, noise=noise, seed=seed or 0, sample_offset=sample_offset, use_graph=use_graph,
+                            row_seeds=row_seeds, row_offsets=row_offsets))
 
 
 def rearrange_codes3(codes: List[torch.Tensor], top_resolution: int):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HQT_ABI_VERSION 3
+#define HQT_ABI_VERSION 4
 
 typedef enum {
     HQT_OK = 0,
@@ -93,6 +93,13 @@ typedef struct {
     int64_t sample_offset;          /* global index of row 0 (sharded batches draw the noise of the
                                        global batch: Philox counters are keyed by global row) */
     int32_t use_graph;              /* 1: replay the per-position launch sequence from a hipGraph */
+    /* Merged steps: several independent sampling_ihqgpt calls (each with its own seed and global offset) executed as ONE
+     * batch, so that the weights are streamed once for all of them.  Optional HOST arrays of B entries: row b then draws
+     * exactly what row (b - first row of its call) of a separate hqt_sample call with (row_seeds[b], sample_offset =
+     * row_offsets[b] - that row index) would draw -- Philox counters are keyed by (seed, global row), nothing else.
+     * NULL: every row uses `seed` and `sample_offset + b`. */
+    const uint64_t* row_seeds;
+    const int64_t* row_offsets;
 } hqt_sample_opts;
 
 /* hqt_create -- replaces ImageGPT2(config) construction (hqvae/models/__init__.py:92-174) for the
@@ -159,6 +166,8 @@ typedef struct {
     uint64_t seed;
     int64_t sample_offset;
     int32_t use_graph;
+    const uint64_t* row_seeds;      /* as in hqt_sample_opts */
+    const int64_t* row_offsets;
 } hqt_sample_opts_l3;
 int hqt_sample_l3(hqt_handle* h, int B, const int64_t* cond, const hqt_sample_opts_l3* opts, const float* noise,
                   const int64_t* force0, const int64_t* force1, const int64_t* force2, float* logits_out,

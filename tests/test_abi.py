@@ -34,10 +34,32 @@ def test_abi_version_and_error_paths_without_gpu(lib):
 
 
 def test_struct_layout_matches_header():
+    """sizeof / offsetof of every ABI struct as the C compiler sees include/hqt.h against the ctypes mirror in _lib.py."""
     import ctypes as C
-    assert C.sizeof(_lib.hqt_config) == 4 * (1 + 1 + 4 + 3 + 3 + 3 + 1 + 2 + 8 + 1 + 1 + 4 + 5 + 3 + 2 + 1)
-    assert C.sizeof(_lib.hqt_sample_opts) == 56
-    assert C.sizeof(_lib.hqt_sample_opts_l3) == 72 and _lib.hqt_sample_opts_l3.seed.offset == 48
+    import subprocess
+    import tempfile
+    checks = {'hqt_config': ['abi_version', 'has_stage1', 's1_ch_mult', 's1_attn_res', 'max_batch', 'code_levels'],
+              'hqt_sample_opts': ['precision', 'top_p_top', 'seed', 'sample_offset', 'use_graph', 'row_seeds', 'row_offsets'],
+              'hqt_sample_opts_l3': ['top_k', 'top_p', 'temperature', 'seed', 'use_graph', 'row_seeds', 'row_offsets'],
+              'hqt_encode_out': ['codes', 'quant', 'resid', 'recon', 'diff']}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "hqt.h")}"', 'int main(void) {']
+    for st, fields in checks.items():
+        lines.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for f in fields:
+            lines.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    lines += ['  return 0;', '}']
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, 'l.c'), os.path.join(d, 'l')
+        open(src, 'w').write('\n'.join(lines))
+        subprocess.run(['gcc', '-o', exe, src], check=True)
+        out = subprocess.run([exe], check=True, stdout=subprocess.PIPE, text=True).stdout
+    want = dict(l.split() for l in out.strip().splitlines())
+    for st, fields in checks.items():
+        cls = getattr(_lib, st)
+        assert C.sizeof(cls) == int(want[st]), (st, C.sizeof(cls), want[st])
+        for f in fields:
+            assert getattr(cls, f).offset == int(want[f'{st}.{f}']), (st, f)
+    assert C.sizeof(_lib.hqt_sample_opts) == 72 and C.sizeof(_lib.hqt_sample_opts_l3) == 88
 
 
 def test_no_cpu_fallback():

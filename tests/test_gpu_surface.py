@@ -231,3 +231,40 @@ def test_three_level_encode_surface(tmp_path):
     grids = m.stage1.code_grids(xt)
     assert torch.equal(m.stage1(xt), m.stage1.decode_code(list(grids)))
     assert [c.reshape(-1).tolist() for c in grids] == [c.tolist() for c in m.stage1.get_codes(xt)]
+
+
+def test_merged_steps_draw_what_the_separate_calls_draw(model):
+    """`InflightSampler(merge=k)`: k independent steps (own class id, own seed, own global offset) executed as one pass of k x B
+    rows.  In EXACT arithmetic every step's codes and pixels must be bit-identical to the separate call; in FAST arithmetic the
+    GEMM tiles depend on the row count, so the gate is agreement of the drawn codes."""
+    from hqtransformer_amd.pipeline import InflightSampler
+    from hqtransformer_amd.sampling import sampling_ihqgpt
+    B, n = 3, 64
+    steps = [(5, 11, 0), (2, 12, 64), (9, 13, 7)]          # (class id, seed, sample_offset)
+    for fast in (False, True):
+        sep = []
+        for cls, seed, off in steps:
+            ct, cb = sampling_ihqgpt(model.stage2, num_candidates=B, cond=cls, top_k_top=100, top_p_top=0.95, top_k_bot=None, top_p_bot=None,
+                                     softmax_temperature=[1.0, 0.9], use_fp16=fast, is_tqdm=False, max_seq_len=n, seed=seed, sample_offset=off)
+            px = model.stage1.decode_sequences(ct, cb, precision='exact', clamp01=True)
+            sep.append((ct.clone(), cb.clone(), px.clone()))
+        pipe = InflightSampler(model, lanes=1, merge=3)
+        pend = [pipe.submit(B, cls, seed=seed, max_seq_len=n, use_fp16=fast, precision='exact', sample_offset=off, top_k_top=100, top_p_top=0.95,
+                            top_k_bot=None, top_p_bot=None, softmax_temperature=[1.0, 0.9]) for cls, seed, off in steps]
+        pipe.drain()
+        torch.cuda.synchronize()
+        for p, (ct, cb, px) in zip(pend, sep):
+            mct, mcb, mpx, _ = p.get()
+            if fast:
+                agree = ((mct == ct).float().mean().item() + (mcb == cb).float().mean().item()) / 2
+                assert agree >= 0.95, agree
+            else:
+                assert torch.equal(mct, ct) and torch.equal(mcb, cb), 'merged EXACT codes differ from the separate call'
+                assert torch.equal(mpx, px)
+    # a partial group is launched by drain()
+    pipe = InflightSampler(model, lanes=1, merge=4)
+    p = pipe.submit(B, 1, seed=3, max_seq_len=n, use_fp16=True)
+    with pytest.raises(RuntimeError):
+        p.get()
+    pipe.drain()
+    assert p.get()[0].shape == (B, n)
