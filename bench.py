@@ -181,14 +181,15 @@ def main():
     samp_kw = (dict(top_k=[tk] * 3, top_p=[tp] * 3, softmax_temperature=[T] * 3) if three else
                dict(top_k_top=tk, top_p_top=tp, top_k_bot=tk, top_p_bot=tp, softmax_temperature=[T, T]))
 
-    def sample_codes(i, graph):
-        """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels)."""
+    def sample_codes(i, graph, nb=None):
+        """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels).  nb: rows of the pass (default: one step's batch)."""
+        nb = nb or B
         if three:
-            c = sampling_hqtransformer(model.stage2, num_candidates=B, cond=cond_of(i), top_k=[tk] * 3, top_p=[tp] * 3,
+            c = sampling_hqtransformer(model.stage2, num_candidates=nb, cond=cond_of(i), top_k=[tk] * 3, top_p=[tp] * 3,
                                        softmax_temperature=[T] * 3, use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i,
                                        sample_offset=rank * B, use_graph=graph)
             return c[0], c[1:]
-        return sampling_ihqgpt(model.stage2, num_candidates=B, cond=cond_of(i), top_k_top=tk, top_p_top=tp, top_k_bot=tk,
+        return sampling_ihqgpt(model.stage2, num_candidates=nb, cond=cond_of(i), top_k_top=tk, top_p_top=tp, top_k_bot=tk,
                                top_p_bot=tp, softmax_temperature=[T, T], use_fp16=fast, is_tqdm=False, max_seq_len=n_pos,
                                model_stage1=None, seed=1 + i, sample_offset=rank * B, use_graph=graph)
 
@@ -196,12 +197,12 @@ def main():
         if three:
             return (m or model).stage1.decode_sequences([ct] + list(cb), precision=dec_prec, clamp01=True)
         if n_pos < n_full:      # debug runs: pad the code grids so the decoder still sees full-size inputs
-            ct = torch.cat([ct, ct.new_zeros(B, n_full - n_pos)], 1)
-            cb = torch.cat([cb, cb.new_zeros(B, n_full - n_pos, 4)], 1)
+            ct = torch.cat([ct, ct.new_zeros(ct.shape[0], n_full - n_pos)], 1)
+            cb = torch.cat([cb, cb.new_zeros(cb.shape[0], n_full - n_pos, 4)], 1)
         return (m or model).stage1.decode_sequences(ct, cb, precision=dec_prec, clamp01=True)
 
-    def step(i, graph=True):
-        ct, cb = sample_codes(i, graph and not args.no_graph)
+    def step(i, graph=True, nb=None):
+        ct, cb = sample_codes(i, graph and not args.no_graph, nb)
         px = decode(ct, cb)
         if dist is not None and args.gather == 'pixels':
             dist.gather(px, gathered, dst=0)
@@ -331,24 +332,26 @@ def main():
 
     # ---- roofline: per-launch HIP-event timers inside libhqt, un-graphed pass, rank 0 only
     if rank == 0 and not args.no_roofline:
-        e2, e1 = model.stage2.engine(B, n_pos), model.stage1.engine(B)
+        # One pass of the timed region = `merge` steps = Bm rows: time the kernels of THAT pass (one lane, un-graphed, per-launch events).
+        Bm = merge * B
+        e2, e1 = model.stage2.engine(Bm, n_pos), model.stage1.engine(Bm)
         ar_ms_serial = ar_ms
-        if inflight > 1:
-            # the timed region ran the throughput-oriented GEMM tiles (hqt_set_policy): time THOSE kernels, first one graphed
-            # step for the graphed/un-graphed scale, then the un-graphed per-launch pass
-            e2.set_policy(1)
-            step(0)                                                     # capture under this policy
+        if inflight > 1 or merge > 1:
+            # the timed region ran the throughput-oriented GEMM tiles (hqt_set_policy) when several lanes were in flight: time THOSE
+            # kernels, first one graphed pass for the graphed/un-graphed scale, then the un-graphed per-launch pass
+            e2.set_policy(1 if inflight > 1 else 0)
+            step(0, nb=Bm)                                              # capture under this policy
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(dev)
             ea.record()
-            sample_codes(args.warmup, not args.no_graph)
+            sample_codes(args.warmup, not args.no_graph, Bm)
             eb.record()
             torch.cuda.synchronize(dev)
             ar_ms = ea.elapsed_time(eb)
         for e in (e2, e1):
             e.timing(True)
             e.timing_reset()
-        step(0, graph=False)
+        step(0, graph=False, nb=Bm)
         torch.cuda.synchronize(dev)
         if inflight > 1:
             e2.set_policy(0)
@@ -368,24 +371,26 @@ def main():
         ar_scale = (ar_ms / ar_eager_ms) if (ar_eager_ms > 0 and not args.no_graph) else 1.0
         gemm_ms = sum(v[1] for v in gemm.values()) * ar_scale
         conv_ms = sum(v[1] for v in conv.values())
-        wbytes = (2 if fast else 4) / 2 * work['ar_weight_bytes_per_pos'] * n_pos           # per batch, all AR GEMM launches
-        cflops = work['dec_flops'] * B
+        wbytes = (2 if fast else 4) / 2 * work['ar_weight_bytes_per_pos'] * n_pos           # per pass (Bm rows), all AR GEMM launches
+        cflops = work['dec_flops'] * Bm
+        passes = args.steps / merge                                                          # passes of the timed region
         fam = []
         if gemm_ms > 0:
             n_l = sum(v[0] for v in gemm.values())
             ach = wbytes / (gemm_ms * 1e-3) / 1e9
-            fam.append({'kernel': 'stream_gemm_kernel: AR weight-streaming GEMM family (qkv/proj/fc1/fc2/heads)', 'bound': 'hbm',
+            fam.append({'kernel': 'stream_gemm_kernel: AR weight-streaming GEMM family (qkv/proj/fc1/fc2/heads' + (f'; {Bm}-row passes: the 4 x {Bm}-row depth sub-step runs conv_glds_kernel)' if 4 * Bm > 256 else ')'), 'bound': 'hbm',
                         'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                         'traffic': pmc_traffic('stream_gemm'), 'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3),
                         'total_ms': round(gemm_ms, 3), 'algorithmic_bytes_per_launch': round(wbytes / n_l),
                         'eager_to_graph_scale': round(ar_scale, 4),
-                        'frac_timed_region': round(wbytes * args.steps / elapsed_lanes / 1e9 / HBM_PEAK_GBS, 4),
+                        'rows_per_pass': Bm,
+                        'frac_timed_region': round(wbytes * passes / elapsed_lanes / 1e9 / HBM_PEAK_GBS, 4),
                         'traffic_source': 'profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of a bounded run of this kernel family, '
                                           'committed with the repository; NOT collected by this invocation',
-                        'note': 'per-launch figure of the kernels the timed region runs (throughput policy when several steps are in flight), '
-                                'measured one lane at a time; with several lanes launches overlap',
-                        'ar_ms_one_lane_this_policy': round(ar_ms, 3), 'ar_ms_one_lane_latency_policy': round(ar_ms_serial, 3),
-                        'timed_region_weight_stream_GBps': round(wbytes * args.steps / elapsed_lanes / 1e9, 1)})
+                        'note': 'per-launch figure of the kernels the timed region runs (one pass = merge x batch rows; throughput policy when several lanes are '
+                                'in flight), measured one lane at a time; with several lanes launches overlap.  Algorithmic bytes = the weights, streamed once per pass',
+                        'ar_ms_one_pass_this_schedule': round(ar_ms, 3), 'ar_ms_serial_batch': round(ar_ms_serial, 3),
+                        'timed_region_weight_stream_GBps': round(wbytes * passes / elapsed_lanes / 1e9, 1)})
         if conv_ms > 0:
             n_l = sum(v[0] for v in conv.values())
             ach = cflops / (conv_ms * 1e-3) / 1e12
@@ -398,13 +403,15 @@ def main():
                         'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach * mfma_per_flop / peak, 4), 'traffic': pmc_traffic('decoder_conv'), 'launches': n_l,
                         'avg_launch_us': round(1000 * conv_ms / n_l, 3), 'total_ms': round(conv_ms, 3),
                         'algorithmic_flops_per_launch': round(cflops / n_l), 'matrix_flops_per_algorithmic_flop': mfma_per_flop,
-                        'achieved_algorithmic_tflops': round(ach, 2),
+                        'achieved_algorithmic_tflops': round(ach, 2), 'images_per_pass': Bm,
+                        'frac_timed_region': round(cflops * mfma_per_flop * passes / elapsed_lanes / 1e12 / peak, 4),
                         'note': 'achieved / peak count the MFMA work actually issued (3x the algorithmic FLOPs in SPLIT precision) against the dense f16/bf16 MFMA peak'})
         fam.sort(key=lambda f: -f['total_ms'])
         if fam:
             out['roofline'] = fam[0]
             out['roofline_other'] = fam[1:]
-        out['kernel_ms_per_batch'] = {k: [v[0], round(v[1], 3)] for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+        out['kernel_ms_per_pass'] = {k: [v[0], round(v[1], 3)] for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+        out['kernel_ms_per_pass_note'] = f'[launches, ms] per pass of {Bm} images ({merge} steps), un-graphed, one lane'
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, s2, s1, B)

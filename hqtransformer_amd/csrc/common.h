@@ -173,6 +173,7 @@ struct GemmArgs {
     // ---- SPLIT precision (split_kernels.h): A holds fp16 [row][hi K | lo K] planes, Bw the hi filters, Bw_lo the lo filters;
     //      C / resid are fp32.  gn_part_out_d: per-tile GroupNorm partials of the fp32 output as doubles (layout of gn_part_out).
     const void* Bw_lo;
+    const void* Bw_frag;     // optional: the same filters packed in MFMA fragment order (split_stream_conv.hip)
     double* gn_part_out_d;
 };
 

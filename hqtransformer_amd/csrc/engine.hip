@@ -65,6 +65,7 @@ struct Lin {            // one nn.Linear / conv filter bank in every layout the 
     bf16_t* w16 = nullptr;        // [N, K] bf16 row-major (FAST generic + conv MFMA)
     half_t* w16h = nullptr;       // [N, K] fp16 hi / lo planes of w32 (SPLIT convolutions: split_kernels.h)
     half_t* w16l = nullptr;
+    half_t* wfrag = nullptr;      // 3x3 filters, hi + lo, packed in MFMA fragment order (split_stream_conv.hip)
     bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)
     bf16_t* wpk_ln = nullptr;     // same packing of gamma o W (deferred LayerNorm), with its column sums and folded bias
     float* colsum = nullptr;
@@ -582,7 +583,12 @@ static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int k
         CHK(dev_alloc(h, (void**)&wt, (size_t)O * I * taps * 4, false));
         HIPCHK(launch_repack_conv(w, wt, O, I, taps, 0));
     }
-    return make_lin(h, l, wt, b, O, I * taps, false, true);
+    CHK(make_lin(h, l, wt, b, O, I * taps, false, true));
+    if (taps == 9 && I % 32 == 0) {              // fragment-packed copy for the streaming SPLIT kernel
+        CHK(dev_alloc(h, (void**)&l.wfrag, split_frag_elems(O, I) * sizeof(half_t), false));
+        HIPCHK(launch_pack_split_frag(wt, l.wfrag, O, I, 0));
+    }
+    return HQT_OK;
 }
 
 // the image enters conv_in as NHWC with its 3 channels zero-padded: 4 for the 4x4 stride-2 filter (K = 64), 16 for the 3x3 one (K = 144)
@@ -795,7 +801,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     if (g.lda == 0) g.lda = l.K;
     Timed t(h, tag, st);
     if (g.Bw_lo) {                              // SPLIT: the caller packed the operand planes (s1_operand) after checking the shape
-        g.Bw = l.w16h; g.Bw_lo = l.w16l;
+        g.Bw = l.w16h; g.Bw_lo = l.w16l; g.Bw_frag = l.wfrag;
         if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
         if (g.conv_taps == 9) {
             if (g.store == STORE_ROWS && h->gn_tiles && conv_halo_stats_ok(g.N, 32)) {   // every such output is normalised next
@@ -1355,7 +1361,7 @@ struct S1Ctx {
 static bool split_shape_ok(const hqt_handle* h, const GemmArgs& g, const Lin& l) {
     if (!l.w16h) return false;
     GemmArgs t = g;
-    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l;
+    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l; t.Bw_frag = l.wfrag;
     if (t.lda == 0) t.lda = l.K;
     return t.conv_taps == 9 ? split_conv3_ok(t) : split_gemm_ok(t);
 }

@@ -846,8 +846,9 @@ bool split_conv3_ok(const GemmArgs& g) {
     if (g.store == STORE_NCHW) return !g.resid && g.N <= 32;
     return g.store == STORE_ROWS && g.rows_per_group == 0 && g.ldc % 8 == 0 && g.N % 8 == 0;
 }
-int split_conv3_tiles_per_image(const GemmArgs& g) { return split_wide_shape(g) ? (g.H / W_T) * (g.W / W_T) : (g.H / S_TY) * (g.W / S_TX); }
+int split_conv3_tiles_per_image(const GemmArgs& g) { return split_stream_ok(g) ? split_stream_tiles_per_image(g) : split_wide_shape(g) ? (g.H / W_T) * (g.W / W_T) : (g.H / S_TY) * (g.W / S_TX); }
 hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st) {
+    if (split_stream_ok(g)) return launch_split_conv3_stream(g, st);
     if (split_wide_shape(g)) {
         if (g.store == STORE_NCHW) conv3x3_split_wide_kernel<true, 32><<<dim3(1, g.M / (W_T * W_T), 1), 512, split_wide_lds(32), st>>>(g);
         else conv3x3_split_wide_kernel<false, 128><<<dim3((g.N + 127) / 128, g.M / (W_T * W_T), 1), 512, split_wide_lds(128), st>>>(g);
@@ -1025,7 +1026,9 @@ hipError_t launch_split_gemm(const GemmArgs& g0, hipStream_t st) {
 }
 
 hipError_t split_kernels_configure() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_wide_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, split_wide_lds(128));
+    hipError_t e = split_stream_configure();
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_wide_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, split_wide_lds(128));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_wide_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, split_wide_lds(32));
     if (e != hipSuccess) return e;

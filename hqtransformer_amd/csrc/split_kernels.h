@@ -30,3 +30,12 @@ hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st);
 hipError_t launch_split_gemm(const GemmArgs& g, hipStream_t st);
 int split_conv3_tiles_per_image(const GemmArgs& g);
 hipError_t split_kernels_configure();             // raise the dynamic-LDS limits once (outside stream capture)
+
+// third-generation 3x3 kernel (split_stream_conv.hip): filters packed in MFMA fragment order (GemmArgs::Bw_frag) and streamed straight
+// into registers, one wave per SIMD
+size_t split_frag_elems(int N, int Cin);          // fp16 elements of the packed hi + lo fragments of an [N][9 Cin] filter bank (Cin % 32 == 0)
+hipError_t launch_pack_split_frag(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);
+bool split_stream_ok(const GemmArgs& g);          // g already passed split_conv3_ok
+int split_stream_tiles_per_image(const GemmArgs& g);
+hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st);
+hipError_t split_stream_configure();

@@ -1,0 +1,426 @@
+// SPLIT precision, third generation of the 3x3 convolution ("stream"): one wave per SIMD, everything software-pipelined
+// inside ONE instruction stream.
+//
+// What the two earlier kernels (split_conv.hip) taught, by in-kernel stamps and ablations (tools/micro/bench_split):
+//   * the two waves of a SIMD do not overlap vector / LDS / memory issue of one with matrix issue of the other: the ~100
+//     non-MFMA instructions a wave needs per k-tile (fragment reads, staging, address arithmetic, waits, the barrier) simply
+//     add to the 1536 matrix cycles of a step -- 62-68 % matrix-pipe occupancy at best;
+//   * a single wave, on the other hand, issues up to ~5 independent instructions in the shadow of each of its own 32-cycle
+//     MFMAs for free;
+//   * filters staged through LDS cost a ring, a ds_write pass, 8 fragment reads per k-tile and wave, and a barrier per k-tile.
+// Hence:
+//   * 4 waves per workgroup, 8 x 16 pixel tile x 128 channels, each wave 64 pixels x 64 channels (128 accumulator registers:
+//     256 -- a 16 x 16 tile -- would need the accumulators in AGPRs, and hipcc then shuffles them through v_accvgpr moves and
+//     spills), two workgroups per CU: 24 MFMAs per k-tile and wave against 8 fragment reads (the patch), 8 global loads (the
+//     filters) and <= 1 LDS-DMA piece, every wave self-contained between two chunk barriers;
+//   * the FILTERS never touch LDS: they are packed at finalize in MFMA A-operand fragment order (1-KiB chunks, [n-tile of 32]
+//     [chunk][tap][k-step][hi | lo]), and every wave streams the fragments of its own 64 channels straight into registers
+//     with coalesced global_load_dwordx4, one k-tile ahead (two waves share each fragment: L1 / L2 hits);
+//   * the PATCH ((8+2) x (16+2) pixels x 32 channels, both planes, 24 KiB) is double-buffered in LDS and filled by LDS-DMA,
+//     one piece per wave at each of the first six taps of the previous chunk: ONE workgroup barrier per chunk of nine k-tiles;
+//   * fragment reads run one k-step ahead; reads, loads, DMA pieces and waits are placed between the MFMAs in program
+//     order (asm statements keep their order; the MFMAs are pinned between them by their register dependencies).
+// Registers: 128 accumulators (main + cross) + 32 patch fragments (two sets) + 64 filter fragments (two k-tiles) + addresses < 256.
+#include "split_kernels.h"
+#include "gemm_generic.h"
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+namespace {
+constexpr float R_INV = 1.0f / 2048.0f;
+constexpr int R_TY = 8, R_TX = 16, R_PITCH = R_TX + 2;
+constexpr int R_ROWS = (R_TY + 2) * R_PITCH;                    // 180 patch rows (pixels) of 64 B per plane
+constexpr int R_PIECES = (R_ROWS + 15) / 16;                    // 12 DMA pieces of 16 rows per plane
+constexpr int R_PLANE = R_PIECES * 1024;
+constexpr int R_CPITCH = 128 * 4 + 16;                          // fp32 staging row of the epilogue (bytes)
+constexpr int R_LDS = 4 * R_PLANE;                              // two buffers x two planes = 48 KiB
+static_assert(64 * R_CPITCH <= R_LDS, "epilogue staging (64 pixels at a time) must fit in the patch buffers");
+
+__device__ __forceinline__ void r_xcd_tile(int& tile_m, int& tile_n) {
+    const int nx = gridDim.x, total = gridDim.x * gridDim.y;
+    int id = blockIdx.x + nx * blockIdx.y;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    tile_m = id / nx;
+    tile_n = id - tile_m * nx;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// finalize: tap-major fp32 filters [N][9 Cin] -> fragment-packed fp16 hi / lo.  Chunk index of (n-tile t, chunk c, tap, k-step ks,
+// plane p) = (((t NC + c) 9 + tap) 2 + ks) 2 + p; inside a chunk lane l holds W[32 t + (l & 31)][tap Cin + 32 c + 16 ks + 8 (l >> 5) + j].
+// Rows beyond N are zero.
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_split_frag_kernel(const float* __restrict__ w, half_t* __restrict__ out, int N, int Cin, size_t total) {
+    const int NC = Cin / 32;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t ch = i >> 9;
+        const int plane = (int)(ch & 1); ch >>= 1;
+        const int ks = (int)(ch & 1); ch >>= 1;
+        const int tap = (int)(ch % 9); ch /= 9;
+        const int c = (int)(ch % NC);
+        const int t = (int)(ch / NC);
+        const int n = t * 32 + (lane & 31), k = tap * Cin + c * 32 + ks * 16 + 8 * (lane >> 5) + j;
+        const float x = n < N ? w[(size_t)n * 9 * Cin + k] : 0.0f;
+        const half_t hi = (half_t)x;
+        out[i] = plane ? (half_t)((x - (float)hi) * 2048.0f) : hi;
+    }
+}
+// (+ one k-tile of padding: the kernel prefetches the filters of k-tile KT, one past the end of the last n-tile's stream, and drops them)
+size_t split_frag_elems(int N, int Cin) { return (size_t)((N + 31) / 32) * (Cin / 32) * 9 * 4 * 512 + 4 * 512; }
+hipError_t launch_pack_split_frag(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st) {
+    const size_t total = split_frag_elems(N, Cin) - 4 * 512;
+    pack_split_frag_kernel<<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, st>>>(w_tapmajor, out, N, Cin, total);
+    return hipGetLastError();
+}
+
+// ABL: ablation switches of tools/micro/bench_split (0 in the product): 1 no epilogue, 2 no patch DMA, 4 no fragment reads / loads
+template <bool NCHW, int BN, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_stream_kernel(GemmArgs g) {
+    static_assert(BN == 128 || (BN == 32 && NCHW), "the 32-channel variant exists for the NCHW conv_out store only");
+    constexpr int FI = BN == 128 ? 2 : 1, FJ = BN == 128 ? 2 : 1;   // BN = 32: 4 waves along the pixels, 32 pixels x 32 channels each
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
+    const int fr = lane & 31, fh = lane >> 5;
+    int tile_m, tile_n;
+    r_xcd_tile(tile_m, tile_n);
+    const int n0 = tile_n * BN;
+    const int tiles_x = g.W / R_TX, tiles_y = g.H / R_TY;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * R_TY, tx0 = (trem % tiles_x) * R_TX;
+    const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
+    const half_t* Abase = reinterpret_cast<const half_t*>(g.A);                 // [pixel][hi Cin | lo Cin]
+    const half_t* zero = reinterpret_cast<const half_t*>(g.zero_page);
+    const int NC = g.Cin / 32, KT = NC * 9;
+
+    // ---- patch DMA: 24 pieces of 16 rows x 64 B per chunk, piece id = wave + 4 u (u < 6): one piece per wave at each of taps 0..5.
+    //      lane -> (row = 16 piece + lane / 4, slot = lane & 3), source chunk = slot ^ ((row >> 2) & 3).
+    constexpr int PPW = 2 * R_PIECES / 4;
+    static_assert(PPW == 6, "one piece per wave and tap, taps 0..5");
+    const int npp = PPW;
+    // (the source offsets are recomputed per piece -- ~20 VALU instructions in the shadow of the MFMAs -- instead of being held in six
+    //  registers: at 256 registers they spilled, and a scratch reload in front of a DMA piece costs a vmcnt(0) that drains the filter loads)
+    auto patch_src = [&](int c, int u) -> const half_t* {
+        const int id = wave + 4 * u, plane = id / R_PIECES, piece = id - plane * R_PIECES;
+        int lq = lane >> 2;
+        asm volatile("" : "+v"(lq));                    // opaque: keeps hipcc from hoisting the six address computations out of the loop (and spilling them)
+        const int q = piece * 16 + lq;
+        const int qy = (q * 3641) >> 16, qx = q - qy * R_PITCH;                 // q / 18 for q < 192
+        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+        const int ch = ((lane & 3) ^ ((q >> 2) & 3)) * 8;
+        const bool in = q < R_ROWS && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        return in ? Abase + (((long long)img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * (2 * g.Cin) + ch + plane * g.Cin + c * 32 : zero;
+    };
+    auto issue_patch_piece = [&](int c, int s, int u) {             // prologue only: LDS-DMA (nothing competes with it there)
+        const int id = wave + 4 * u, plane = id / R_PIECES, piece = id - plane * R_PIECES;
+        char* dst = lds_raw + (size_t)(s * 2 + plane) * R_PLANE + piece * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)patch_src(c, u),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    // In the main loop the patch pieces travel through a register instead: an LDS-DMA piece cost the issuing wave 150+ cycles there
+    // (2753 vs 2236 us on the 512 -> 512 upsampling conv with / without them), a global_load_dwordx4 + ds_write_b128 pair does not block.
+    u32x4 pst;                                                      // one piece in flight: loaded at tap t, written to LDS at tap t + 1
+    auto load_patch_piece = [&](int c, int u) {
+        const half_t* sp = patch_src(c, u);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pst) : "v"(sp));
+    };
+    auto store_patch_piece = [&](int s, int u, int younger) {       // `younger` loads were issued after the piece's (static): vmcnt retires in order
+        const int id = wave + 4 * u, plane = id / R_PIECES, piece = id - plane * R_PIECES;
+        const unsigned a = lds_base + (s * 2 + plane) * R_PLANE + piece * 1024 + lane * 16;
+        if (younger == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pst));
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pst) : "n"(2 * (BN == 128 ? 2 : 1)));
+        asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(pst) : "memory");
+    };
+
+    // ---- filter fragments: two streams (j) of 4 KiB per k-tile, [ks][plane] chunks of 1 KiB
+    const half_t* bfrag[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) bfrag[j] = reinterpret_cast<const half_t*>(g.Bw_frag) + (size_t)((n0 + wn * 64 + j * 32) / 32) * KT * 2048 + lane * 8;
+
+    f32x16 accm[FI][FJ], accx[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.0f; accx[i][j][r] = 0.0f; }
+
+    int qbase[FI];                                                  // patch row of tap (0, 0) for this lane's pixel of fragment i
+#pragma unroll
+    for (int i = 0; i < FI; ++i) qbase[i] = (wm * (2 * FI) + i * 2 + (fr >> 4)) * R_PITCH + (fr & 15);
+
+    half8 ah[2][FI], al[2][FI];                                     // patch fragments, set = k-step parity
+    half8 wh[2][2][FJ], wl[2][2][FJ];                               // filter fragments [k-tile parity][ks][j]
+    auto read_a = [&](int ps, int tapoff, int ks, int set, int i) {
+        int q = qbase[i] + tapoff;
+        asm volatile("" : "+v"(q));                     // opaque: the 36 fragment addresses of an unrolled chunk are computed where they are used, not hoisted (and spilled)
+        const unsigned a = lds_base + ps * 2 * R_PLANE + ((q * 64 + ((fh ^ ((q >> 2) & 3)) << 4)) ^ (ks << 5));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ah[set][i]) : "v"(a));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[set][i]) : "v"(a), "n"(R_PLANE));
+    };
+    // Filter fragments are asm loads INSIDE a chunk (issued in k-tile t, retired by a counted wait in k-tile t + 1: straight-line code)
+    // and ORDINARY loads across a chunk boundary.  An asm load whose value crosses a branch is unsafe: hipcc copies the destination
+    // registers at the block boundary -- BEFORE the data has landed -- and the load later writes registers that hold something else by
+    // then (seen: a DMA source address -> memory fault).  Ordinary loads are counted by hipcc itself; its waits then are conservative
+    // about the asm loads it cannot see (vmcnt retires in issue order), never too weak.
+    auto load_b = [&](int kt, int par, int ks, int j, bool plain) {
+        const half_t* p = bfrag[j] + (size_t)kt * 2048 + ks * 1024;
+        if (plain) {
+            wh[par][ks][j] = *reinterpret_cast<const half8*>(p);
+            wl[par][ks][j] = *reinterpret_cast<const half8*>(p + 512);
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wh[par][ks][j]) : "v"(p));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(wl[par][ks][j]) : "v"(p));
+        }
+    };
+#define HQT_WAIT_B(par, ks, P)                                                                                                 \
+    do {                                                                                                                       \
+        if constexpr (FJ == 2)                                                                                                 \
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wh[par][ks][0]), "+v"(wl[par][ks][0]), "+v"(wh[par][ks][1]), "+v"(wl[par][ks][1]) : "n"(P)); \
+        else                                                                                                                   \
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wh[par][ks][0]), "+v"(wl[par][ks][0]) : "n"(P));                          \
+    } while (0)
+#define HQT_WAIT_A(set, P)                                                                                                     \
+    do {                                                                                                                       \
+        if constexpr (FI == 2)                                                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ah[set][0]), "+v"(al[set][0]), "+v"(ah[set][1]), "+v"(al[set][1]) : "n"(P)); \
+        else                                                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ah[set][0]), "+v"(al[set][0]) : "n"(P));                               \
+    } while (0)
+    constexpr int NBL = 2 * FJ;                                     // filter loads per k-step (hi + lo per j)
+
+    // one k-step: FI x FJ x 3 MFMAs with `between(slot)` called after each (i, j) group -- the slots carry the prefetches
+    auto mfma_step = [&](int aset, int par, int ks, auto&& between) {
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[par][ks][j], ah[aset][i], accm[i][j], 0, 0, 0);
+                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[par][ks][j], al[aset][i], accx[i][j], 0, 0, 0);
+                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[par][ks][j], ah[aset][i], accx[i][j], 0, 0, 0);
+                between(i * FJ + j);
+            }
+    };
+
+    // ---- prologue: the first patch, the filters of k-tile 0, the patch fragments of (k-tile 0, k-step 0)
+#pragma unroll
+    for (int u = 0; u < PPW; ++u)
+        if (u < npp) issue_patch_piece(0, 0, u);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) load_b(0, 0, ks, j, true);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NBL) : "memory");        // the DMA pieces are older than the filter loads (vmcnt is in issue order)
+
+    // ---- main loop: one iteration = TWO 32-channel chunks = 18 k-tiles, fully unrolled STRAIGHT-LINE code with static tap offsets, patch
+    //      buffers and filter register sets (k-tile parity; 18 is even, so ONE instantiation serves every iteration).  No branch inside:
+    //      an asm fragment load and the wait that retires it never have a block boundary between them (see load_b); the only values that
+    //      cross the loop's back edge are the accumulators and the filters of the next iteration's first k-tile (ordinary loads).
+    //      Issue order inside a k-tile: k-step 0: [A(kt, 1) reads] [one patch DMA piece, taps 0..5] [filters (kt+1, 0), last];
+    //      k-step 1: [A(kt+1, 0) reads] [filters (kt+1, 1)].  The patch of chunk c + 1 is fetched during chunk c (of chunk NC - 1 again
+    //      during the last one, into the buffer nobody reads any more); the filters of k-tile KT, one past the end, are loaded and
+    //      dropped (split_frag_elems pads the buffer).
+    constexpr int NS = FI * FJ;
+#pragma unroll 1
+    for (int c0 = 0; c0 < NC; c0 += 2) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = c0 + cc, kt0 = c * 9, cn = min(c + 1, NC - 1);
+            // the DMA pieces of this chunk's patch were issued by tap 5 of the previous chunk (the prologue for chunk 0) and are older than
+            // loads that have been waited for since; the barrier makes all four waves' pieces visible and closes the previous chunk's reads
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FI; ++i) read_a(cc, 0, 0, 0, i);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int PAR = (cc + tap) & 1;                     // static: kt = 9 c + tap, c = c0 + cc, c0 even
+                const bool last = cc == 1 && tap == 8;              // the filters loaded here are consumed behind the back edge
+                const int tapoff = (tap / 3) * R_PITCH + tap % 3, ntapoff = ((tap + 1) / 3) * R_PITCH + (tap + 1) % 3;
+                // k-step 0 needs A set 0 and the filters (PAR, k-step 0): all but the NBL youngest loads (k-step 1 of this k-tile) have landed
+                if (ABL != 4) { HQT_WAIT_A(0, 0); HQT_WAIT_B(PAR, 0, NBL); }
+                mfma_step(0, PAR, 0, [&](int slot) {
+                    if (ABL == 4) return;
+                    if (slot % FJ == 0) read_a(cc, tapoff, 1, 1, slot / FJ);                         // A of (this k-tile, k-step 1)
+                    if (slot == (FJ > 1 ? 1 : 0) && ABL != 2) {                                        // next chunk's patch: piece `tap` goes out, piece `tap - 1` comes in
+                        if (tap >= 1 && tap <= PPW) store_patch_piece(cc ^ 1, tap - 1, 1);          // behind it only the filters of (this k-tile, k-step 1) are in flight
+                        if (tap < PPW) load_patch_piece(cn, tap);
+                    }
+                    if (slot == NS - 1) {                                                            // filters of the next k-tile, k-step 0
+                        if (last) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < FJ; ++j) load_b(kt0 + tap + 1, PAR ^ 1, 0, j, last);
+                        if (last) __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                // k-step 1 needs A set 1 and the filters (PAR, k-step 1): older than the NBL loads issued during k-step 0 (the DMA piece is older still)
+                if (ABL != 4) { HQT_WAIT_A(1, 0); HQT_WAIT_B(PAR, 1, NBL); }
+                mfma_step(1, PAR, 1, [&](int slot) {
+                    if (ABL == 4) return;
+                    if (slot % FJ == 0 && tap < 8) read_a(cc, ntapoff, 0, 0, slot / FJ);             // A of (next k-tile, k-step 0): same patch buffer
+                    if (slot == NS - 1) {                                                            // filters of the next k-tile, k-step 1
+                        if (last) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < FJ; ++j) load_b(kt0 + tap + 1, PAR ^ 1, 1, j, last);
+                        if (last) __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            }
+        }
+    }
+#undef HQT_WAIT_A
+#undef HQT_WAIT_B
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // the patch buffers become the epilogue's staging area
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 1) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += accm[i][j][r] + accx[i][j][r];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
+        return;
+    }
+    // ---- epilogue.  D map: col = lane & 31 -> pixel fr of block i; row = (r & 3) + 8 (r >> 2) + 4 fh -> channel
+    if (NCHW) {                                        // conv_out: fp32 NCHW (+clamp); lanes = consecutive pixels of a row
+        float* Cb = reinterpret_cast<float*>(g.C);
+        const long long hw = (long long)g.H * g.W;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int py = wm * (2 * FI) + i * 2 + (fr >> 4);
+            const long long pix = (long long)(ty0 + py) * g.W + tx0 + (fr & 15);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = n0 + wn * 64 + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    if (n >= g.N) continue;
+                    float v = (accm[i][j][e] + accx[i][j][e] * R_INV) * g.alpha + (g.bias ? g.bias[n] : 0.0f);
+                    if (g.clamp01) v = fminf(fmaxf(0.5f * v + 0.5f, 0.0f), 1.0f);
+                    Cb[((long long)img * g.N + n) * hw + pix] = v;
+                }
+        }
+        return;
+    }
+    if constexpr (BN == 128) {
+        // Staged store, 64 pixels (the 4 tile rows of wave row wm = half) at a time: fp32 tile through the dead patch buffers,
+        // then whole NHWC rows, two 16-B stores per lane; 256 threads cover 16 pixels x 128 channels per pass.
+        const long long pix0 = ((long long)img * g.H + ty0) * g.W + tx0;
+        char* stage = lds_raw;
+        float* Cb = reinterpret_cast<float*>(g.C);
+        const float* Rb = reinterpret_cast<const float*>(g.resid);
+        const int c8 = (tid & 15) * 8, nn = n0 + c8;
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (g.bias && nn + e < g.N) ? g.bias[nn + e] : 0.0f;
+        float gs[8], gq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half > 0) __syncthreads();              // the previous half has been read back
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < FI; ++i) {
+                    const int r = i * 32 + fr;          // pixel within the staged 64
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const int nl = wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * R_INV;
+                            *reinterpret_cast<f32x4*>(stage + r * R_CPITCH + nl * 4) = v;
+                        }
+                }
+            }
+            __syncthreads();
+            if (nn < g.N) {                             // N % 8 == 0
+                long long moff[4];
+                f32x4 r0[4], r1[4];
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {        // the residual rows of the four passes are fetched together
+                    const int r = p4 * 16 + (tid >> 4);
+                    moff[p4] = (pix0 + (long long)(half * 4 + (r >> 4)) * g.W + (r & 15)) * g.ldc + nn;
+                    if (Rb) { r0[p4] = *reinterpret_cast<const f32x4*>(Rb + moff[p4]); r1[p4] = *reinterpret_cast<const f32x4*>(Rb + moff[p4] + 4); }
+                }
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int r = p4 * 16 + (tid >> 4);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * R_CPITCH + c8 * 4);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * R_CPITCH + c8 * 4 + 16);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
+                    if (Rb) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[p4][e]; v[4 + e] += r1[p4][e]; }
+                    }
+                    const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(Cb + moff[p4]) = o0;
+                    *reinterpret_cast<f32x4*>(Cb + moff[p4] + 4) = o1;
+                    if (g.gn_part_out_d) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+                    }
+                }
+            }
+        }
+        if (g.gn_part_out_d) {                              // uniform branch (kernel argument): barriers are safe here
+            __syncthreads();
+            float* redw = reinterpret_cast<float*>(lds_raw);                    // [16 pixel rows][128 channels][2]; zeros from idle threads
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
+                redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
+            }
+            __syncthreads();
+            const float* red = reinterpret_cast<const float*>(lds_raw);
+            if (tid < 128) {
+                double sa = 0.0, sq = 0.0;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) { sa += (double)red[((rg * 128) + tid) * 2]; sq += (double)red[((rg * 128) + tid) * 2 + 1]; }
+                const int cpg = g.N / g.gn_out_groups;
+                for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
+                const int ch = n0 + tid;
+                if (ch < g.N && (tid & (cpg - 1)) == 0) {
+                    double* pp = g.gn_part_out_d + (((long long)img * (tiles_x * tiles_y) + trem) * g.gn_out_groups + ch / cpg) * 2;
+                    pp[0] = sa; pp[1] = sq;
+                }
+            }
+        }
+    }
+}
+
+bool split_stream_ok(const GemmArgs& g) {
+    static const bool off = getenv("HQT_SPLIT_STREAM") && atoi(getenv("HQT_SPLIT_STREAM")) == 0;      // A/B switch
+    if (off || !g.Bw_frag) return false;
+    if (g.H % R_TY != 0 || g.W % R_TX != 0 || g.Cin % 64 != 0) return false;      // an even number of 32-channel chunks (static k-tile parity)
+    if (g.store == STORE_NCHW) return g.N <= 32;
+    return g.N % 128 == 0 && g.ldc % 8 == 0;              // whole 128-channel tiles (the packed fragments hold ceil(N / 32) n-tiles)
+}
+int split_stream_tiles_per_image(const GemmArgs& g) { return (g.H / R_TY) * (g.W / R_TX); }
+hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st) {
+    if (g.store == STORE_NCHW) conv3x3_split_stream_kernel<true, 32><<<dim3(1, g.M / (R_TY * R_TX), 1), 256, R_LDS, st>>>(g);
+    else conv3x3_split_stream_kernel<false, 128><<<dim3((g.N + 127) / 128, g.M / (R_TY * R_TX), 1), 256, R_LDS, st>>>(g);
+    return hipGetLastError();
+}
+hipError_t split_stream_configure() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_stream_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_stream_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+}

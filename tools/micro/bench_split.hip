@@ -2,6 +2,7 @@
 // (batch 64), with ablations that separate the epilogue, the DMA, the fragment reads and the bare MFMA stream.
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/micro/bench_split.hip -o tools/micro/bench_split
 #include "../../hqtransformer_amd/csrc/split_conv.hip"
+#include "../../hqtransformer_amd/csrc/split_stream_conv.hip"
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -36,6 +37,20 @@ static float run_wide(const GemmArgs& g, hipStream_t st, int reps) {
     return 1000.f * ms / reps;
 }
 
+template <int ABL>
+static float run_stream(const GemmArgs& g, hipStream_t st, int reps) {
+    const dim3 grid((g.N + 127) / 128, g.M / 128, 1);
+    void (*k)(GemmArgs) = conv3x3_split_stream_kernel<false, 128, ABL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS));
+    k<<<grid, 256, R_LDS, st>>>(g);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) k<<<grid, 256, R_LDS, st>>>(g);
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return 1000.f * ms / reps;
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64;
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -59,8 +74,16 @@ int main(int argc, char** argv) {
         }
     }
     CK(hipMemset(bias, 0, 512 * 4)); CK(hipMemset(zero, 0, 256));
+    half_t* Wfrag; float* W32;
+    CK(hipMalloc(&Wfrag, split_frag_elems(512, 512) * 2)); CK(hipMalloc(&W32, wmax * 4));
+    {
+        std::vector<float> wf(wmax);
+        unsigned x = 777u;
+        for (auto& v : wf) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 9) - (1 << 22)) * (1.0f / (1 << 24)); }
+        CK(hipMemcpy(W32, wf.data(), wmax * 4, hipMemcpyHostToDevice));
+    }
     printf("%-22s %8s | %7s %7s %7s | %7s %7s %7s %7s | %7s %7s\n", "layer (batch 64)", "GF x3", "pc1 us", "TF eq", "pc0 us", "no-epi", "no-dma", "dma", "mfma", "pc0nodma", "pc0 mfma");
-    double tot = 0, totf = 0;
+    double tot = 0, totf = 0, tot_stream = 0;
     for (const Shape& s : shapes) {
         GemmArgs g{};
         g.A = A; g.conv_taps = 9; g.H = s.res; g.W = s.res; g.Cin = s.cin; g.upsample = s.up;
@@ -74,6 +97,13 @@ int main(int argc, char** argv) {
         const float w0 = run_wide<0>(g, st, reps), w1 = run_wide<1>(g, st, reps), w2 = run_wide<2>(g, st, reps), w3 = run_wide<3>(g, st, reps), w4 = run_wide<4>(g, st, reps), w6 = run_wide<6>(g, st, reps), w5 = run_wide<5>(g, st, reps);
         printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7.1f %7.1f | contiguous-src %7.1f stagger %7.1f\n", "   wide tile 16x16", "", w0, fl / w0 * 1e-6, "", w1, w2, w3, w4, w6, w5);
         {
+            CK(launch_pack_split_frag(W32, Wfrag, s.cout, s.cin, st));
+            GemmArgs gs = g; gs.Bw_frag = Wfrag;
+            const float r0 = run_stream<0>(gs, st, reps), r1 = run_stream<1>(gs, st, reps), r2 = run_stream<2>(gs, st, reps), r4 = run_stream<4>(gs, st, reps);
+            printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f\n", "   stream (1 wave/simd)", "", r0, fl / r0 * 1e-6, "", r1, r2, "", r4);
+            tot_stream += r0;
+        }
+        {
             static long long* dbg = nullptr;
             if (!dbg) CK(hipMalloc(&dbg, 8 * 8 * 8));
             CK(hipMemset(dbg, 0, 8 * 8 * 8));
@@ -86,6 +116,6 @@ int main(int argc, char** argv) {
         }
         tot += std::min(t0, w0); totf += fl;
     }
-    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent\n", tot, totf / tot * 1e-6);
+    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent; stream kernel: %.1f us, %.1f\n", tot, totf / tot * 1e-6, tot_stream, totf / tot_stream * 1e-6);
     return 0;
 }
