@@ -380,9 +380,11 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), (void**)&h->codes_top, B * (size_t)c.max_steps * 8, true));
         CHK(dev_alloc(h.get(), (void**)&h->codes_bot, B * (size_t)c.max_steps * 4 * 8, true));
         if (c.code_levels == 3) CHK(dev_alloc(h.get(), (void**)&h->codes_l2, B * (size_t)c.max_steps * 16 * 8, true));
-        // packed_off() buffers are addressed with a row stride of 32 * packed_mb(M) (32 / 64 / 128 / 256 rows), which can
-        // exceed round32(M): size them for the widest padded block any M <= 256 pass can use
-        const size_t rows_pk = std::max<size_t>(rows, 256);
+        // packed_off() buffers are addressed with a row stride of 32 * packed_mb(M) (32 / 64 / ... / 4096 rows), which can
+        // exceed round32(M): size them for the widest padded block any M <= PACKED_MAX_ROWS pass can use
+        size_t rows_pk = 256;
+        while (rows_pk < rows && rows_pk < (size_t)PACKED_MAX_ROWS) rows_pk *= 2;
+        rows_pk = std::max(rows_pk, rows);
         CHK(dev_alloc(h.get(), (void**)&h->xpk, rows_pk * D * 2, true));
         CHK(dev_alloc(h.get(), (void**)&h->xdpk, rows_pk * D * 2, true));
         CHK(dev_alloc(h.get(), (void**)&h->parts, (D / 32 + 1) * rows_pk * 2 * 4, true));
@@ -916,7 +918,7 @@ static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float*
     const int D = h->cfg.embed_dim, M = c.B * Tq;
     const int adt = c.md.act_dt();
     // FAST: GEMM A operands travel in the MFMA-fragment-packed layout when the streaming GEMM serves them
-    const int pk = (c.md.fast && M <= 256 && bw.qkv.wpk && bw.proj.wpk && bw.fc1.wpk && bw.fc2.wpk) ? packed_mb(M) : 0;
+    const int pk = (c.md.fast && M <= PACKED_MAX_ROWS && bw.qkv.wpk && bw.proj.wpk && bw.fc1.wpk && bw.fc2.wpk) ? packed_mb(M) : 0;
     CHK(run_ln(h, c.st, x, bw.ln1_g, bw.ln1_b, nullptr, h->hbuf, M, D, 1, 0, adt, pk));
     GemmArgs g{};
     g.A = h->hbuf; g.M = M; g.batch = 1; g.a_packed_mb = pk;
@@ -949,7 +951,7 @@ static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float*
 static bool dln_ok(hqt_handle* h, const SampleCtx& c, const BlockW& bw, int M) {
     static const bool off = getenv("HQT_NO_DLN") != nullptr;      // debugging / A-B switch: classic LayerNorm kernels
     if (off) return false;
-    return c.md.fast && M <= 256 && bw.qkv.wpk_ln && bw.fc1.wpk_ln && bw.proj.wpk && bw.fc2.wpk && h->cfg.embed_dim % 32 == 0;
+    return c.md.fast && M <= PACKED_MAX_ROWS && bw.qkv.wpk_ln && bw.fc1.wpk_ln && bw.proj.wpk && bw.fc2.wpk && h->cfg.embed_dim % 32 == 0;
 }
 static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float* x32, bf16_t* xpk, float* parts, int* nparts,
                          int Tq, void* kc, void* vc, int Tcache, int t_base, const int* t_base_dev, int causal) {
@@ -1027,8 +1029,8 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
         h->npartsd = 1;
     }
     const size_t dkv_layer = (size_t)cf.max_batch * 5 * D * esz;
-    const int pk1 = (c.md.fast && B <= 256 && h->head_top.wpk) ? packed_mb(B) : 0;
-    const int pk4 = (c.md.fast && 4 * B <= 256 && h->head_bot.wpk) ? packed_mb(4 * B) : 0;
+    const int pk1 = (c.md.fast && B <= PACKED_MAX_ROWS && h->head_top.wpk) ? packed_mb(B) : 0;
+    const int pk4 = (c.md.fast && 4 * B <= PACKED_MAX_ROWS && h->head_bot.wpk) ? packed_mb(4 * B) : 0;
     // ---- depth sub-step 0: top code
     for (int l = 0; l < cf.n_layers_depth; ++l) {
         void* kc = (char*)h->dk + l * dkv_layer;
@@ -1117,7 +1119,7 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
     for (int lv = 0; lv < 3; ++lv) {
         const int Tq = Tqs[lv], M = B * Tq;
         const bool dln = dln_ok(h, c, h->depth[0], M) && heads[lv]->wpk_ln;
-        const int pk = (c.md.fast && M <= 256 && heads[lv]->wpk) ? packed_mb(M) : 0;
+        const int pk = (c.md.fast && M <= PACKED_MAX_ROWS && heads[lv]->wpk) ? packed_mb(M) : 0;
         if (lv == 0) {            // ln_f on the last token of each sample, + sos_depth -> depth input of level 0
             Timed t(h, "layernorm", c.st);
             LNArgs ln{h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, 1e-5f, DT_F32, 0,

@@ -105,7 +105,10 @@ constexpr size_t stream_gemm_lds(int MBW, int NT, int NW) { return (size_t)NW * 
 constexpr int stream_min_waves(int MBW, int NT, int NW, int U) {
     return (NW == 16 || (MBW * NT == 1 && NW == 8) || 16 * NT * MBW + 4 * U * (NT + MBW) + 40 <= 128) ? 4 : 1;
 }
-template <int MBW, int NT, int NW, int U, typename TC, int ABL = 0>   // ABL: ablation switches of tools/micro/bench_stream
+// PIPE: the wave's k-steps run as a software pipeline of depth U (k-step i + U is fetched into the registers k-step i just
+// released) instead of load-a-run / wait / multiply-a-run: the variants of the merged passes (M = 256 .. 1024), whose
+// per-wave K range is several runs long.  Needs cnt % U == 0 (the planner checks).
+template <int MBW, int NT, int NW, int U, typename TC, int ABL = 0, bool PIPE = false>   // ABL: ablation switches of tools/micro/bench_stream
 __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);                  // [NW][NT][MBW][m32][RP]: row m holds its 32 n, padded to 36 floats
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     // Variants with registers to spare (MBW >= 2: one workgroup per CU anyway) fetch their share of the partial row
     // statistics together with the first run's operands and hold it across the MFMA loop; the others fetch it after
     // the loop, when the operand registers are dead.  Unconditional loads (a valid dummy row when there is no LayerNorm).
-    constexpr bool EARLY_STATS = MBW >= 2 && U >= 12;
+    constexpr bool EARLY_STATS = MBW >= 2 && U >= 12 && !PIPE;
     constexpr int NPE = 6;
     float2 sv[NPE];
     bool sv_loaded = false;
@@ -200,7 +203,52 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
             }
     }
     };
-    if (g.w_nt) run_main(std::true_type{}); else run_main(std::false_type{});
+    auto run_pipe = [&](auto nt_tag) {
+    constexpr bool WNT = decltype(nt_tag)::value;
+    auto fetch_w = [&](int u, int k) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const u32x4* wsrc = wp + ((size_t)t * KS + k) * 64;
+            wbuf[u][t] = WNT ? __builtin_nontemporal_load(wsrc) : *wsrc;
+        }
+    };
+    auto fetch_x = [&](int u, int k) {
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) xbuf[u][mb] = xp[((size_t)k * MB + mb) * 64];
+    };
+    auto multiply = [&](int u) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, wbuf[u][t]);
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb)
+                acc[t][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, xbuf[u][mb]), acc[t][mb], 0, 0, 0);
+        }
+    };
+    if (cnt < U) return;                              // (planner: cnt % U == 0; anything else falls to the ragged tail below)
+#pragma unroll
+    for (int u = 0; u < U; ++u) fetch_w(u, u);
+    __builtin_amdgcn_sched_barrier(0);
+    chain_wait(g.chain, polled);                      // weights are in flight; the activations depend on the predecessor
+#pragma unroll
+    for (int u = 0; u < U; ++u) fetch_x(u, u);
+    first = false;
+    __builtin_amdgcn_sched_barrier(0);
+    for (; ks + 2 * U <= cnt; ks += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            multiply(u);
+            fetch_w(u, ks + U + u);
+            fetch_x(u, ks + U + u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { multiply(u); __builtin_amdgcn_sched_barrier(0); }
+    ks += U;
+    };
+    if (PIPE) { if (g.w_nt) run_pipe(std::true_type{}); else run_pipe(std::false_type{}); }
+    else if (g.w_nt) run_main(std::true_type{}); else run_main(std::false_type{});
     if (first) {                                      // K too short for a full run: nothing was prefetched
         chain_wait(g.chain, polled);
     }
@@ -516,15 +564,15 @@ hipError_t launch_fold_layernorm(const float* w32, const float* gamma, const flo
 
 bool stream_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
     (void)c_dt;
-    return g.a_packed_mb > 0 && a_dt == DT_BF16 && !g.conv_taps && g.M <= 256 && g.batch <= 1 && g.N % 32 == 0 &&
+    return g.a_packed_mb > 0 && a_dt == DT_BF16 && !g.conv_taps && g.M <= PACKED_MAX_ROWS && g.batch <= 1 && g.N % 32 == 0 &&
            g.K % 16 == 0 && g.a_packed_mb == packed_mb(g.M);
 }
 
-template <int MBW, int NT, int NW, int U, typename TC>
+template <int MBW, int NT, int NW, int U, typename TC, bool PIPE = false>
 static hipError_t launch_stream_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
     const size_t smem = stream_gemm_lds(MBW, NT, NW);
     const dim3 grid(g.N / (32 * NT), g.a_packed_mb / MBW, S);
-    stream_gemm_kernel<MBW, NT, NW, U, TC><<<grid, NW * 64, smem, st>>>(g, reinterpret_cast<const u32x4*>(wpk), slabs);
+    stream_gemm_kernel<MBW, NT, NW, U, TC, 0, PIPE><<<grid, NW * 64, smem, st>>>(g, reinterpret_cast<const u32x4*>(wpk), slabs);
     return hipGetLastError();
 }
 // configuration table (tools/micro/bench_stream on MI355X): per-CU L2->L1 bandwidth (~40 GB/s) bounds these
@@ -533,6 +581,8 @@ static hipError_t launch_stream_t(const GemmArgs& g, const bf16_t* wpk, int S, f
 #define STREAM_CASES(X, TC) \
     X(1, 1, 8, 12, TC) X(2, 1, 8, 12, TC) X(2, 1, 8, 6, TC) \
     X(2, 2, 4, 6, TC) X(2, 2, 8, 6, TC) X(2, 1, 4, 12, TC) X(1, 1, 4, 12, TC) X(1, 2, 4, 8, TC) X(4, 1, 4, 4, TC) X(4, 2, 4, 3, TC) X(2, 1, 4, 6, TC)
+// pipelined variants (512 .. 1024 activation rows: depth sub-step 1 of a merged pass, large merges)
+#define STREAM_PIPE_CASES(X, TC) X(2, 2, 4, 4, TC) X(2, 3, 4, 4, TC)
 int stream_gemm_splitk(const GemmArgs& g) {
     const int KS = g.K / 16;
     const int wgs = (g.N / 32) * g.a_packed_mb;            // with MBW = 1
@@ -612,6 +662,13 @@ static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, f
         if (g.a_packed_mb == 8 && g.N >= 3072 && (g.N / 32) % 2 == 0) return launch_stream_t<4, 2, 4, 3, TC>(g, wpk, 1, nullptr, st);
         if (g.a_packed_mb == 8 && (g.N / 32) % 2 == 0) return launch_stream_t<2, 2, 8, 6, TC>(g, wpk, 1, nullptr, st);
     }
+    if (S == 1 && g.a_packed_mb >= 16) {
+        // M = 512 .. 1024: bound by the L2 -> L1 traffic of the 64-row tiles (~20 TB/s over the chip), so the widest weight tile whose
+        // partial tiles still fit the LDS twice; tools/micro/bench_stream, M = 1024: qkv 29.7, proj 14.1, fc1 35.4, fc2 33.3 us
+        // (round 1 took these shapes through the generic LDS-DMA GEMM at 48 .. 86 us plus separate LayerNorm launches)
+        if (g.K > 2 * g.N && (g.N / 32) % 3 == 0) return launch_stream_t<2, 3, 4, 4, TC, true>(g, wpk, 1, nullptr, st);
+        if ((g.N / 32) % 2 == 0) return launch_stream_t<2, 2, 4, 4, TC, true>(g, wpk, 1, nullptr, st);
+    }
     const int wgs2 = (g.N / 32) * (g.a_packed_mb / 2);
     if (S == 1 && g.a_packed_mb == 2 && wgs2 >= 128) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);
     if (S == 1 && g.a_packed_mb >= 4) {                 // M = 128..256 (depth sub-step 1): 64-row activation tiles halve the weight re-reads
@@ -634,5 +691,12 @@ hipError_t stream_gemm_configure() {
     STREAM_CASES(CFG, bf16_t)
     STREAM_CASES(CFG, float)
 #undef CFG
+#define CFGP(MBW, NT, NW, U, TC)                                                                                   \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, TC, 0, true>),        \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_gemm_lds(MBW, NT, NW));      \
+    if (e != hipSuccess) return e;
+    STREAM_PIPE_CASES(CFGP, bf16_t)
+    STREAM_PIPE_CASES(CFGP, float)
+#undef CFGP
     return hipSuccess;
 }

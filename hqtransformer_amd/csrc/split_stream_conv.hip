@@ -72,10 +72,11 @@ __global__ void pack_split_frag_kernel(const float* __restrict__ w, half_t* __re
         out[i] = plane ? (half_t)((x - (float)hi) * 2048.0f) : hi;
     }
 }
-// (+ one k-tile of padding: the kernel prefetches the filters of k-tile KT, one past the end of the last n-tile's stream, and drops them)
-size_t split_frag_elems(int N, int Cin) { return (size_t)((N + 31) / 32) * (Cin / 32) * 9 * 4 * 512 + 4 * 512; }
+// (+ three k-tiles of padding: the kernels prefetch the filters of up to five k-steps past the end of the last n-tile's stream, and drop them)
+constexpr size_t R_FRAG_PAD = 3 * 4 * 512;
+size_t split_frag_elems(int N, int Cin) { return (size_t)((N + 31) / 32) * (Cin / 32) * 9 * 4 * 512 + R_FRAG_PAD; }
 hipError_t launch_pack_split_frag(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st) {
-    const size_t total = split_frag_elems(N, Cin) - 4 * 512;
+    const size_t total = split_frag_elems(N, Cin) - R_FRAG_PAD;
     pack_split_frag_kernel<<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, st>>>(w_tapmajor, out, N, Cin, total);
     return hipGetLastError();
 }
@@ -406,6 +407,292 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_stream_kernel(GemmArgs g
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fourth generation ("ring"): the same tile, patch and packed filters, but each wave owns 128 pixels x 32 channels (4 x 1 fragments
+// instead of 2 x 2).  What that buys, measured against the kernel above (512 -> 512 upsampling conv, tools/micro/bench_split):
+//   * vmcnt retires in issue order, so every counted wait for a filter fragment also waits for every older load -- the patch pieces
+//     included.  With filters one k-tile (0.6 us of this SIMD's matrix time) ahead, an L2 hit (~0.6 us) barely made it and a patch piece
+//     from HBM (1-2 us) stalled the wave at the next filter wait: ~550 us of fragment stalls + ~550 us of patch stalls on a 1740 us
+//     matrix stream.
+//   * One channel fragment per wave halves the filter registers per k-step (8 instead of 16), so a ring of SIX k-steps fits where two
+//     k-tiles did: filters are fetched five k-steps (2.5 k-tiles) ahead, a patch piece has three k-tiles to arrive before anything
+//     waits for it, and each filter fragment is fetched by one wave instead of two.
+//   * The patch fragments (LDS, ~150 cycles) are single-buffered instead: fragment i of the next k-step is read right after the three
+//     MFMAs that consume fragment i of this one were issued, nine MFMAs (288 cycles) before its first use.
+// Registers: 128 accumulators + 32 patch fragments + 48 filter fragments (ring of 6) + 12 patch pieces in flight + addresses.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int G_RING = 6, G_AHEAD = G_RING - 1, G_STEPS = 36;         // ring slots (k-steps), prefetch distance, k-steps per loop body (two chunks)
+static_assert(G_STEPS % G_RING == 0, "static ring slots");
+// Patch rows are 64 B of data on an 80-B pitch: 8 consecutive pixels then start in 8 different 16-B bank groups (5 q mod 8), so the
+// fragment reads need no XOR swizzle -- and without one a fragment address is  base(fragment) + constant(buffer, tap, k-step, plane),
+// i.e. an immediate offset: ZERO vector instructions per read (the swizzled layout cost ~7 each, 28+ per k-step, and vector
+// instructions are not hidden behind this wave's or its SIMD neighbour's MFMAs).
+constexpr int G_PITCH = 80, G_PLANE = 16 * R_PIECES * G_PITCH, G_LDS = 4 * G_PLANE;       // 15 KiB per plane, 60 KiB per workgroup
+static_assert(64 * R_CPITCH <= G_LDS, "epilogue staging (64 pixels at a time) must fit in the patch buffers");
+static_assert(3 * G_PLANE + 38 * G_PITCH + 32 < 65536, "ds_read immediate offsets");
+// patch piece loaded during body step u (k-step 1 of taps 0..5)?
+constexpr bool g_piece_at(int u) { u = ((u % G_STEPS) + G_STEPS) % G_STEPS; return (u & 1) && ((u % 18) >> 1) < 6; }
+// loads issued after the filters of body step s (fetched during step s - G_AHEAD, first hook) and before step s begins
+constexpr int g_younger(int s) {
+    int n = 2 * (G_AHEAD - 1);
+    for (int u = s - G_AHEAD; u < s; ++u) n += g_piece_at(u) ? 1 : 0;
+    return n;
+}
+}  // namespace
+
+// ABL: ablation switches of tools/micro/bench_split (0 in the product): 1 no epilogue, 2 no patch pieces, 4 MFMAs only, 5 patch fragment
+// reads only (no filter loads, no pieces), 6 filter loads only (no fragment reads, no pieces)
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_ring_kernel(GemmArgs g) {
+    constexpr int FI = 4;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    int tile_m, tile_n;
+    r_xcd_tile(tile_m, tile_n);
+    const int n0 = tile_n * 128;
+    const int tiles_x = g.W / R_TX, tiles_y = g.H / R_TY;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * R_TY, tx0 = (trem % tiles_x) * R_TX;
+    const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
+    const half_t* Abase = reinterpret_cast<const half_t*>(g.A);                 // [pixel][hi Cin | lo Cin]
+    const int NC = g.Cin / 32;
+
+    // ---- patch pieces: 24 pieces of 16 rows x 64 B per chunk (12 per plane), piece id = wave + 4 u (u < 6): plane u / 3, piece
+    //      wave + 4 (u % 3); lane -> (row = 16 piece + lane / 4, 16-B slot = lane & 3).  Fetched with buffer loads: a 32-bit byte offset
+    //      into THIS image's planes (<= 2 GiB) + the chunk's 64 B as the scalar offset, and the hardware's range check returns zeros for
+    //      the padding ring (offset 2^31 >= num_records): no address arithmetic in the loop, no select.
+    constexpr int PPW = 2 * R_PIECES / 4;
+    static_assert(PPW == 6, "one piece per wave at taps 0..5");
+    typedef int rsrc_t __attribute__((ext_vector_type(4)));
+    rsrc_t img_rsrc;
+    {
+        const unsigned long long ib = (unsigned long long)(size_t)(Abase + (long long)img * Hin * Win * (2 * g.Cin));
+        img_rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ib);
+        img_rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ib >> 32) & 0xffff);      // stride 0
+        img_rsrc[2] = __builtin_amdgcn_readfirstlane(Hin * Win * 2 * g.Cin * 2);               // bytes
+        img_rsrc[3] = 0x00020000;                                                              // raw buffer, 32-bit data format (gfx9)
+    }
+    unsigned poff[PPW];                                             // source byte offset of piece u at chunk 0
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        const int plane = u / 3, piece = wave + 4 * (u % 3);
+        const int q = piece * 16 + (lane >> 2);
+        const int qy = (q * 3641) >> 16, qx = q - qy * R_PITCH;                 // q / 18 for q < 192
+        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+        const bool in = (q < R_ROWS) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+        const unsigned off = (unsigned)((((iy >> g.upsample) * Win + (ix >> g.upsample)) * (2 * g.Cin) + (lane & 3) * 8 + plane * g.Cin) * 2);
+        poff[u] = in ? off : 0x80000000u;
+    }
+    u32x4 pst[3];                                                   // pieces in flight: loaded at tap t (k-step 1), written to LDS at tap t + 3
+    unsigned piece_base = lds_base + wave * (16 * G_PITCH) + (lane >> 2) * G_PITCH + (lane & 3) * 16;     // + (buffer, u) constant
+    auto load_piece = [&](int c, int u, int r) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pst[r]) : "v"(poff[u]), "s"(img_rsrc), "s"(c * 64));
+    };
+#define HQT_STORE_PIECE(buf, u, r)                                                                                             \
+    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(piece_base), "v"(pst[r]),                                            \
+                 "n"(((buf) * 2 + (u) / 3) * G_PLANE + 4 * ((u) % 3) * 16 * G_PITCH) : "memory")
+
+    // this wave's filter stream: a scalar base (+ 2 KiB per k-step) and one lane offset
+    const char* bfrag = reinterpret_cast<const char*>(reinterpret_cast<const half_t*>(g.Bw_frag) + (size_t)(n0 / 32 + wave) * ((size_t)NC * 9 * 2048));
+    unsigned lane16 = lane * 16;
+
+    f32x16 accm[FI], accx[FI];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accm[i][r] = 0.0f; accx[i][r] = 0.0f; }
+    unsigned abase[FI];                                             // LDS address of this lane's pixel of fragment i (tile rows 2 i, 2 i + 1) at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < FI; ++i) abase[i] = lds_base + ((i * 2 + (fr >> 4)) * R_PITCH + (fr & 15)) * G_PITCH + fh * 16;
+
+    half8 ah[FI], al[FI];                                           // patch fragments of the current k-step (refilled one by one)
+    half8 wh[G_RING], wl[G_RING];                                   // filter fragments, slot = k-step % 6
+#define HQT_READ_A(ps, tapoff, ks, i)                                                                                          \
+    do {                                                                                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[i]) : "v"(abase[i]), "n"((ps) * 2 * G_PLANE + (tapoff) * G_PITCH + (ks) * 32));            \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[i]) : "v"(abase[i]), "n"((ps) * 2 * G_PLANE + (tapoff) * G_PITCH + (ks) * 32 + G_PLANE));  \
+    } while (0)
+    // Every filter load is an asm load, also the ones consumed behind the loop's back edge: the body is ONE basic block and the ring
+    // registers are loop-carried in place (tools/micro/audit_ring.py checks both on the generated ISA -- an in-flight register that
+    // hipcc copied or reused would be garbage; tests/test_gpu_split.py would see it too).
+    auto load_b = [&](long long S, int slot) {
+        const char* p = bfrag + S * 2048;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wh[slot]) : "v"(lane16), "s"(p));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(wl[slot]) : "v"(lane16), "s"(p));
+    };
+
+    // ---- prologue: the first patch (two rounds of three pieces through the piece registers), the filters of k-steps 0 .. 4; everything
+    //      has landed before the loop starts, so the counted waits of the first body (which assume the steady-state issue pattern) can
+    //      only be too strict, never too weak
+#pragma unroll
+    for (int u = 0; u < 3; ++u) load_piece(0, u, u);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pst[0]), "+v"(pst[1]), "+v"(pst[2]));
+    HQT_STORE_PIECE(0, 0, 0); HQT_STORE_PIECE(0, 1, 1); HQT_STORE_PIECE(0, 2, 2);
+#pragma unroll
+    for (int u = 3; u < 6; ++u) load_piece(0, u, u - 3);
+#pragma unroll
+    for (int s = 0; s < G_AHEAD; ++s) load_b(s, s);
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(pst[0]), "+v"(pst[1]), "+v"(pst[2]) : "n"(2 * G_AHEAD));
+    HQT_STORE_PIECE(0, 3, 0); HQT_STORE_PIECE(0, 4, 1); HQT_STORE_PIECE(0, 5, 2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // ---- main loop: one iteration = two chunks = 36 k-steps of straight-line code with static taps, buffers, ring slots and wait counts
+#pragma unroll 1
+    for (int c0 = 0; c0 < NC; c0 += 2) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = c0 + cc, cn = min(c + 1, NC - 1);
+            __builtin_amdgcn_s_barrier();               // every wave's pieces of this chunk's patch are in LDS; the previous chunk's reads are done
+            __builtin_amdgcn_sched_barrier(0);
+            if (ABL != 4 && ABL != 6) {
+                HQT_READ_A(cc, 0, 0, 0); HQT_READ_A(cc, 0, 0, 1); HQT_READ_A(cc, 0, 0, 2); HQT_READ_A(cc, 0, 0, 3);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int s = cc * 18 + tap * 2 + ks, slot = s % G_RING, nslot = (s + G_AHEAD) % G_RING;
+                    const long long S = (long long)c0 * 18 + s;
+                    const bool refill = !(tap == 8 && ks == 1);         // the next chunk's first fragments are read after its barrier
+                    const int ntap = ks ? tap + 1 : tap;
+                    const int ntapoff = (ntap / 3) * R_PITCH + ntap % 3;
+                    if (ABL != 4 && ABL != 5) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wh[slot]), "+v"(wl[slot]) : "n"(g_younger(s)));
+#pragma unroll
+                    for (int i = 0; i < FI; ++i) {
+                        // fragment i: the 2 (3 - i) reads behind it belong to this k-step, the 2 i refills issued so far to the next
+                        if (ABL != 4 && ABL != 6) {
+                            if (refill || i == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ah[i]), "+v"(al[i]));
+                            else if (i == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[i]), "+v"(al[i]));
+                            else if (i == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[i]), "+v"(al[i]));
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
+                        }
+                        accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[slot], ah[i], accm[i], 0, 0, 0);
+                        accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[slot], al[i], accx[i], 0, 0, 0);
+                        accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[slot], ah[i], accx[i], 0, 0, 0);
+                        if (ABL == 4) continue;
+                        if (refill && ABL != 6) {
+                            if (i == 0) HQT_READ_A(cc, ntapoff, ks ^ 1, 0);
+                            else if (i == 1) HQT_READ_A(cc, ntapoff, ks ^ 1, 1);
+                            else if (i == 2) HQT_READ_A(cc, ntapoff, ks ^ 1, 2);
+                            else HQT_READ_A(cc, ntapoff, ks ^ 1, 3);
+                        }
+                        if (i == 0 && ABL != 5) load_b(S + G_AHEAD, nslot);         // the slot k-step s - 1 released takes the filters of k-step s + 5
+                        if (i == 1 && ks == 1 && ABL != 2 && ABL != 5 && ABL != 6) {
+                            // next chunk's patch: the piece of tap - 3 is older than the filters just waited for (it has landed) and goes to
+                            // LDS; the piece of this tap goes out into the register it frees
+                            if (tap >= 3 && tap - 3 < PPW) HQT_STORE_PIECE(cc ^ 1, tap - 3, tap % 3);
+                            if (tap < PPW) load_piece(cn, tap, tap % 3);
+                        }
+                    }
+                }
+        }
+    }
+#undef HQT_READ_A
+#undef HQT_STORE_PIECE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // the patch buffers become the epilogue's staging area
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 1) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += accm[i][r] + accx[i][r];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
+        return;
+    }
+    // ---- epilogue.  D map: col = lane & 31 -> pixel fr of fragment i; row = (r & 3) + 8 (r >> 2) + 4 fh -> channel within the wave's 32.
+    //      Staged store, 64 pixels (fragments 2 half, 2 half + 1) at a time: fp32 tile through the dead patch buffers, then whole NHWC
+    //      rows, two 16-B stores per lane; 256 threads cover 16 pixels x 128 channels per pass.
+    const long long pix0 = ((long long)img * g.H + ty0) * g.W + tx0;
+    char* stage = lds_raw;
+    float* Cb = reinterpret_cast<float*>(g.C);
+    const float* Rb = reinterpret_cast<const float*>(g.resid);
+    const int c8 = (tid & 15) * 8, nn = n0 + c8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (g.bias && nn + e < g.N) ? g.bias[nn + e] : 0.0f;
+    float gs[8], gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half > 0) __syncthreads();                  // the previous half has been read back
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = half * 2 + ii, r = ii * 32 + fr;      // pixel within the staged 64
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int nl = wave * 32 + 8 * q4 + 4 * fh;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = accm[i][4 * q4 + e] + accx[i][4 * q4 + e] * R_INV;
+                *reinterpret_cast<f32x4*>(stage + r * R_CPITCH + nl * 4) = v;
+            }
+        }
+        __syncthreads();
+        if (nn < g.N) {                                 // N % 8 == 0
+            long long moff[4];
+            f32x4 r0[4], r1[4];
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {            // the residual rows of the four passes are fetched together
+                const int r = p4 * 16 + (tid >> 4);
+                moff[p4] = (pix0 + (long long)(half * 4 + (r >> 4)) * g.W + (r & 15)) * g.ldc + nn;
+                if (Rb) { r0[p4] = *reinterpret_cast<const f32x4*>(Rb + moff[p4]); r1[p4] = *reinterpret_cast<const f32x4*>(Rb + moff[p4] + 4); }
+            }
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int r = p4 * 16 + (tid >> 4);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * R_CPITCH + c8 * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * R_CPITCH + c8 * 4 + 16);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
+                if (Rb) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[p4][e]; v[4 + e] += r1[p4][e]; }
+                }
+                const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(Cb + moff[p4]) = o0;
+                *reinterpret_cast<f32x4*>(Cb + moff[p4] + 4) = o1;
+                if (g.gn_part_out_d) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+                }
+            }
+        }
+    }
+    if (g.gn_part_out_d) {                              // uniform branch (kernel argument): barriers are safe here
+        __syncthreads();
+        float* redw = reinterpret_cast<float*>(lds_raw);                    // [16 pixel rows][128 channels][2]; zeros from idle threads
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
+            redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
+        }
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(lds_raw);
+        if (tid < 128) {
+            double sa = 0.0, sq = 0.0;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) { sa += (double)red[((rg * 128) + tid) * 2]; sq += (double)red[((rg * 128) + tid) * 2 + 1]; }
+            const int cpg = g.N / g.gn_out_groups;
+            for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
+            const int ch = n0 + tid;
+            if (ch < g.N && (tid & (cpg - 1)) == 0) {
+                double* pp = g.gn_part_out_d + (((long long)img * (tiles_x * tiles_y) + trem) * g.gn_out_groups + ch / cpg) * 2;
+                pp[0] = sa; pp[1] = sq;
+            }
+        }
+    }
+}
+
 bool split_stream_ok(const GemmArgs& g) {
     static const bool off = getenv("HQT_SPLIT_STREAM") && atoi(getenv("HQT_SPLIT_STREAM")) == 0;      // A/B switch
     if (off || !g.Bw_frag) return false;
@@ -416,11 +703,18 @@ bool split_stream_ok(const GemmArgs& g) {
 int split_stream_tiles_per_image(const GemmArgs& g) { return (g.H / R_TY) * (g.W / R_TX); }
 hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st) {
     if (g.store == STORE_NCHW) conv3x3_split_stream_kernel<true, 32><<<dim3(1, g.M / (R_TY * R_TX), 1), 256, R_LDS, st>>>(g);
-    else conv3x3_split_stream_kernel<false, 128><<<dim3((g.N + 127) / 128, g.M / (R_TY * R_TX), 1), 256, R_LDS, st>>>(g);
+    else {
+        static const bool ring = !(getenv("HQT_SPLIT_RING") && atoi(getenv("HQT_SPLIT_RING")) == 0);     // A/B switch: 0 = the stream kernel
+        const dim3 grid((g.N + 127) / 128, g.M / (R_TY * R_TX), 1);
+        if (ring) conv3x3_split_ring_kernel<0><<<grid, 256, G_LDS, st>>>(g);
+        else conv3x3_split_stream_kernel<false, 128><<<grid, 256, R_LDS, st>>>(g);
+    }
     return hipGetLastError();
 }
 hipError_t split_stream_configure() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_stream_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_ring_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_stream_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
 }

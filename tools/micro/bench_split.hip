@@ -51,6 +51,20 @@ static float run_stream(const GemmArgs& g, hipStream_t st, int reps) {
     return 1000.f * ms / reps;
 }
 
+template <int ABL>
+static float run_ring(const GemmArgs& g, hipStream_t st, int reps) {
+    const dim3 grid((g.N + 127) / 128, g.M / 128, 1);
+    void (*k)(GemmArgs) = conv3x3_split_ring_kernel<ABL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+    k<<<grid, 256, G_LDS, st>>>(g);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) k<<<grid, 256, G_LDS, st>>>(g);
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return 1000.f * ms / reps;
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64;
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -83,7 +97,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(W32, wf.data(), wmax * 4, hipMemcpyHostToDevice));
     }
     printf("%-22s %8s | %7s %7s %7s | %7s %7s %7s %7s | %7s %7s\n", "layer (batch 64)", "GF x3", "pc1 us", "TF eq", "pc0 us", "no-epi", "no-dma", "dma", "mfma", "pc0nodma", "pc0 mfma");
-    double tot = 0, totf = 0, tot_stream = 0;
+    double tot = 0, totf = 0, tot_stream = 0, tot_ring = 0;
     for (const Shape& s : shapes) {
         GemmArgs g{};
         g.A = A; g.conv_taps = 9; g.H = s.res; g.W = s.res; g.Cin = s.cin; g.upsample = s.up;
@@ -102,6 +116,10 @@ int main(int argc, char** argv) {
             const float r0 = run_stream<0>(gs, st, reps), r1 = run_stream<1>(gs, st, reps), r2 = run_stream<2>(gs, st, reps), r4 = run_stream<4>(gs, st, reps);
             printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f\n", "   stream (1 wave/simd)", "", r0, fl / r0 * 1e-6, "", r1, r2, "", r4);
             tot_stream += r0;
+            const float g0 = run_ring<0>(gs, st, reps), g1 = run_ring<1>(gs, st, reps), g2 = run_ring<2>(gs, st, reps), g4 = run_ring<4>(gs, st, reps);
+            const float g5 = run_ring<5>(gs, st, reps), g6 = run_ring<6>(gs, st, reps);
+            printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f | patch reads only %7.1f filter loads only %7.1f\n", "   ring (filters 5 k-steps ahead)", "", g0, fl / g0 * 1e-6, "", g1, g2, "", g4, g5, g6);
+            tot_ring += g0;
         }
         {
             static long long* dbg = nullptr;
@@ -116,6 +134,6 @@ int main(int argc, char** argv) {
         }
         tot += std::min(t0, w0); totf += fl;
     }
-    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent; stream kernel: %.1f us, %.1f\n", tot, totf / tot * 1e-6, tot_stream, totf / tot_stream * 1e-6);
+    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent; stream kernel: %.1f us, %.1f; ring kernel: %.1f us, %.1f\n", tot, totf / tot * 1e-6, tot_stream, totf / tot_stream * 1e-6, tot_ring, totf / tot_ring * 1e-6);
     return 0;
 }
