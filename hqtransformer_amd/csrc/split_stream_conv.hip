@@ -447,6 +447,7 @@ constexpr int g_younger(int s) {
 template <int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_ring_kernel(GemmArgs g) {
     constexpr int FI = 4;
+    constexpr bool A_ONLY = ABL == 5 || ABL == 7 || ABL == 8;       // 7: + no chunk barrier, 8: + hi-plane reads only (timing experiments)
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_raw;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring_kernel(GemmArgs g) 
 #define HQT_READ_A(ps, tapoff, ks, i)                                                                                          \
     do {                                                                                                                       \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[i]) : "v"(abase[i]), "n"((ps) * 2 * G_PLANE + (tapoff) * G_PITCH + (ks) * 32));            \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[i]) : "v"(abase[i]), "n"((ps) * 2 * G_PLANE + (tapoff) * G_PITCH + (ks) * 32 + G_PLANE));  \
+        if (ABL != 8) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[i]) : "v"(abase[i]), "n"((ps) * 2 * G_PLANE + (tapoff) * G_PITCH + (ks) * 32 + G_PLANE));  \
     } while (0)
     // Every filter load is an asm load, also the ones consumed behind the loop's back edge: the body is ONE basic block and the ring
     // registers are loop-carried in place (tools/micro/audit_ring.py checks both on the generated ISA -- an in-flight register that
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring_kernel(GemmArgs g) 
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int c = c0 + cc, cn = min(c + 1, NC - 1);
-            __builtin_amdgcn_s_barrier();               // every wave's pieces of this chunk's patch are in LDS; the previous chunk's reads are done
+            if (ABL != 7) __builtin_amdgcn_s_barrier(); // every wave's pieces of this chunk's patch are in LDS; the previous chunk's reads are done
             __builtin_amdgcn_sched_barrier(0);
             if (ABL != 4 && ABL != 6) {
                 HQT_READ_A(cc, 0, 0, 0); HQT_READ_A(cc, 0, 0, 1); HQT_READ_A(cc, 0, 0, 2); HQT_READ_A(cc, 0, 0, 3);
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring_kernel(GemmArgs g) 
                     const bool refill = !(tap == 8 && ks == 1);         // the next chunk's first fragments are read after its barrier
                     const int ntap = ks ? tap + 1 : tap;
                     const int ntapoff = (ntap / 3) * R_PITCH + ntap % 3;
-                    if (ABL != 4 && ABL != 5) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wh[slot]), "+v"(wl[slot]) : "n"(g_younger(s)));
+                    if (ABL != 4 && !A_ONLY) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wh[slot]), "+v"(wl[slot]) : "n"(g_younger(s)));
 #pragma unroll
                     for (int i = 0; i < FI; ++i) {
                         // fragment i: the 2 (3 - i) reads behind it belong to this k-step, the 2 i refills issued so far to the next
@@ -582,8 +583,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring_kernel(GemmArgs g) 
                             else if (i == 2) HQT_READ_A(cc, ntapoff, ks ^ 1, 2);
                             else HQT_READ_A(cc, ntapoff, ks ^ 1, 3);
                         }
-                        if (i == 0 && ABL != 5) load_b(S + G_AHEAD, nslot);         // the slot k-step s - 1 released takes the filters of k-step s + 5
-                        if (i == 1 && ks == 1 && ABL != 2 && ABL != 5 && ABL != 6) {
+                        if (i == 0 && !A_ONLY) load_b(S + G_AHEAD, nslot);         // the slot k-step s - 1 released takes the filters of k-step s + 5
+                        if (i == 1 && ks == 1 && ABL != 2 && !A_ONLY && ABL != 6) {
                             // next chunk's patch: the piece of tap - 3 is older than the filters just waited for (it has landed) and goes to
                             // LDS; the piece of this tap goes out into the register it frees
                             if (tap >= 3 && tap - 3 < PPW) HQT_STORE_PIECE(cc ^ 1, tap - 3, tap % 3);

@@ -117,8 +117,8 @@ int main(int argc, char** argv) {
             printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f\n", "   stream (1 wave/simd)", "", r0, fl / r0 * 1e-6, "", r1, r2, "", r4);
             tot_stream += r0;
             const float g0 = run_ring<0>(gs, st, reps), g1 = run_ring<1>(gs, st, reps), g2 = run_ring<2>(gs, st, reps), g4 = run_ring<4>(gs, st, reps);
-            const float g5 = run_ring<5>(gs, st, reps), g6 = run_ring<6>(gs, st, reps);
-            printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f | patch reads only %7.1f filter loads only %7.1f\n", "   ring (filters 5 k-steps ahead)", "", g0, fl / g0 * 1e-6, "", g1, g2, "", g4, g5, g6);
+            const float g5 = run_ring<5>(gs, st, reps), g6 = run_ring<6>(gs, st, reps), g7 = run_ring<7>(gs, st, reps), g8 = run_ring<8>(gs, st, reps);
+            printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f | patch reads only %7.1f (no barrier %7.1f, hi plane only %7.1f) filter loads only %7.1f\n", "   ring (filters 5 k-steps ahead)", "", g0, fl / g0 * 1e-6, "", g1, g2, "", g4, g5, g7, g8, g6);
             tot_ring += g0;
         }
         {
