@@ -564,27 +564,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring_kernel(GemmArgs g) 
                     const int ntap = ks ? tap + 1 : tap;
                     const int ntapoff = (ntap / 3) * R_PITCH + ntap % 3;
                     if (ABL != 4 && !A_ONLY) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wh[slot]), "+v"(wl[slot]) : "n"(g_younger(s)));
+                    // Fragments go in pairs: [m0 m1 x0 x1 x0' x1'] then [m2 m3 x2 x3 x2' x3'] (m = hi.hi, x = hi.lo, x' = lo.hi into the same cross
+                    // accumulator): no MFMA directly follows the one whose result it accumulates onto, so ONE wave keeps the matrix pipe busy
+                    // and a neighbour delayed by its memory instructions does not open bubbles.
 #pragma unroll
-                    for (int i = 0; i < FI; ++i) {
-                        // fragment i: the 2 (3 - i) reads behind it belong to this k-step, the 2 i refills issued so far to the next
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int i0 = 2 * pr, i1 = 2 * pr + 1;
+                        // reads in issue order: (s, 0) (s, 1) [mid of step s - 1], (s, 2) (s, 3) [end of step s - 1], (s + 1, 0) (s + 1, 1) [mid of s]
                         if (ABL != 4 && ABL != 6) {
-                            if (refill || i == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ah[i]), "+v"(al[i]));
-                            else if (i == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[i]), "+v"(al[i]));
-                            else if (i == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[i]), "+v"(al[i]));
-                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i]), "+v"(al[i]));
+                            if (pr == 0 || refill) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[i0]), "+v"(al[i0]), "+v"(ah[i1]), "+v"(al[i1]));
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i0]), "+v"(al[i0]), "+v"(ah[i1]), "+v"(al[i1]));
                         }
-                        accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[slot], ah[i], accm[i], 0, 0, 0);
-                        accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[slot], al[i], accx[i], 0, 0, 0);
-                        accx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[slot], ah[i], accx[i], 0, 0, 0);
+                        accm[i0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[slot], ah[i0], accm[i0], 0, 0, 0);
+                        accm[i1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[slot], ah[i1], accm[i1], 0, 0, 0);
+                        accx[i0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[slot], al[i0], accx[i0], 0, 0, 0);
+                        accx[i1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[slot], al[i1], accx[i1], 0, 0, 0);
+                        accx[i0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[slot], ah[i0], accx[i0], 0, 0, 0);
+                        accx[i1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[slot], ah[i1], accx[i1], 0, 0, 0);
                         if (ABL == 4) continue;
                         if (refill && ABL != 6) {
-                            if (i == 0) HQT_READ_A(cc, ntapoff, ks ^ 1, 0);
-                            else if (i == 1) HQT_READ_A(cc, ntapoff, ks ^ 1, 1);
-                            else if (i == 2) HQT_READ_A(cc, ntapoff, ks ^ 1, 2);
-                            else HQT_READ_A(cc, ntapoff, ks ^ 1, 3);
+                            if (pr == 0) { HQT_READ_A(cc, ntapoff, ks ^ 1, 0); HQT_READ_A(cc, ntapoff, ks ^ 1, 1); }
+                            else { HQT_READ_A(cc, ntapoff, ks ^ 1, 2); HQT_READ_A(cc, ntapoff, ks ^ 1, 3); }
                         }
-                        if (i == 0 && !A_ONLY) load_b(S + G_AHEAD, nslot);         // the slot k-step s - 1 released takes the filters of k-step s + 5
-                        if (i == 1 && ks == 1 && ABL != 2 && !A_ONLY && ABL != 6) {
+                        if (pr == 0 && !A_ONLY) load_b(S + G_AHEAD, nslot);         // the slot k-step s - 1 released takes the filters of k-step s + 5
+                        if (pr == 1 && ks == 1 && ABL != 2 && !A_ONLY && ABL != 6) {
                             // next chunk's patch: the piece of tap - 3 is older than the filters just waited for (it has landed) and goes to
                             // LDS; the piece of this tap goes out into the register it frees
                             if (tap >= 3 && tap - 3 < PPW) HQT_STORE_PIECE(cc ^ 1, tap - 3, tap % 3);
