@@ -44,7 +44,7 @@ F32_PEAK_TFLOPS = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=100, help='timed steps; the default keeps the timed region above 5 s')
+    p.add_argument('--steps', type=int, default=96, help='timed steps; the default keeps the timed region above 5 s (a multiple of --merge: whole passes)')
     p.add_argument('--warmup', type=int, default=6)
     p.add_argument('--sampler', choices=['harness', 'quality'], default='harness',
                    help='harness: top_k = top_p = None, T = [1, 1] (measure_throughput/__main__.py:93-101, the headline); quality: top_k = 2048, '
@@ -65,7 +65,7 @@ def parse():
     p.add_argument('--no-graph', action='store_true')
     p.add_argument('--inflight', type=int, default=3, help='batches in flight per GPU: consecutive steps are round-robined over this many '
                    'lanes (own HIP stream, KV cache and activations; shared weights).  1 = the serial order of the reference harness')
-    p.add_argument('--merge', type=int, default=4, help='execute this many queued steps as ONE pass of merge x batch rows (every step keeps its own class id, '
+    p.add_argument('--merge', type=int, default=8, help='execute this many queued steps as ONE pass of merge x batch rows (every step keeps its own class id, '
                    'Philox seed and global row indices: per step the same draws as unmerged; the weights are streamed once for all of them)')
     p.add_argument('--overlap', action='store_true', help='EXPERIMENT: run the decode of batch k on a second stream underneath the AR '
                    'loop of batch k+1 (measured slower on MI355X: the decoder starves the latency-bound AR kernels)')
@@ -233,8 +233,7 @@ def main():
     merge = max(1, args.merge)
     if txt_cond or three or args.positions:
         merge = 1                                  # merged steps: class-conditional / unconditional two-level sampling only
-    if args.steps % merge:
-        raise SystemExit(f'--steps must be divisible by --merge ({merge})')
+    rem = args.steps % merge                       # K need not be a multiple: the last pass of the timed region then holds `rem` steps
     pipe = InflightSampler(model, lanes=inflight, device=dev, merge=merge)
 
     def after(ct, cb, px):
@@ -247,6 +246,12 @@ def main():
     for li in range(0 if debug_short else max(inflight, args.warmup) * merge):  # every lane at least once: workspace, graph capture
         pipe.submit(B, cond_of(li), seed=1000 + li, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
                     use_graph=not args.no_graph, after=after, precision=dec_prec, **samp_kw)
+    pipe.flush()
+    for lane in range(0 if debug_short or not rem else inflight):  # ... and the shorter last pass once per lane too (its own workspace + graph)
+        for j in range(rem):
+            pipe.submit(B, cond_of(j), seed=2000 + lane * merge + j, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
+                        use_graph=not args.no_graph, after=after, precision=dec_prec, **samp_kw)
+        pipe.flush()
     pipe.drain()
     barrier()
     t0 = time.perf_counter()

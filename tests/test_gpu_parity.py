@@ -190,6 +190,24 @@ def test_fast_precision_teacher_forced(tiny_cls):
         gate(f'tiny_cls.fast_code_agreement(graph={graph})', agree, 0.96, '>=')
 
 
+def test_fast_wide_passes_up_to_4096_rows(tiny_cls):
+    """Merged passes reach the streaming GEMMs with 512 .. 4096 activation rows (depth sub-step 1 runs 4 rows per sample): the
+    packed-operand layout with 16 .. 128 row blocks and the pipelined 64-row-tile variants.  Same gates as the 2-row-block case."""
+    fx, spec, weights, _ = tiny_cls
+    for B in (160, 320, 1000):                               # 640 / 1280 / 4000 rows in depth sub-step 1; 1000 is ragged (not a multiple of 32)
+        eng = engine_s2(spec, weights, B)
+        n = 3
+        noise = torch.from_numpy(synth.exp_noise(11, n, B, spec.vocab_top))
+        cond = torch.from_numpy(synth.class_ids(6, B, spec.n_classes))
+        ct, cb, lg_e = eng.sample(B, cond, n, precision=PRECISION_EXACT, noise=noise, return_logits=True, use_graph=False)
+        for graph in (False, True):
+            ft, fb, lg_f = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, force_top=ct, force_bot=cb, return_logits=True, use_graph=graph)
+            gate(f'tiny_cls.wide{B}.fast_logits(graph={graph})', (lg_f - lg_e).abs().max().item(), 0.15)
+            agree = ((ft == ct).float().mean().item() + (fb == cb).float().mean().item()) / 2
+            gate(f'tiny_cls.wide{B}.fast_code_agreement(graph={graph})', agree, 0.96, '>=')
+        del eng
+
+
 def test_fast_single_key_shortcut_is_bit_identical(tiny_cls):
     """Depth sub-step 0 attends to exactly one key, so its attention output is the value row: the FAST path skips the
     query third of the fused GEMM and the attention launch.  softmax of one score is exactly 1.0, hence logits and
