@@ -326,10 +326,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
-    for (int j0 = 0; j0 < nkeys; j0 += rows_per_pass * PB) {
-        raw_t kbuf[PB][NRAW], vbuf[PB][NRAW];
+    // A group is up to PB passes fetched in one round trip; the last (often the only) group runs exactly the passes it has keys for --
+    // `np` is uniform over the launch, so the switch below picks a fully unrolled body.  Skipped passes contributed exp(-inf) = 0 and
+    // max(-inf) before: the results are bit-identical, and a step with few cached keys no longer pays the arithmetic of 64.
+    auto group = [&](int j0, auto np_tag) {
+        constexpr int NP = decltype(np_tag)::value;
+        raw_t kbuf[NP][NRAW], vbuf[NP][NRAW];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {                                  // unconditional (clamped) loads: all in flight at once
+        for (int p = 0; p < NP; ++p) {                                  // unconditional (clamped) loads: all in flight at once
             const long long j = min(j0 + p * rows_per_pass + slot, nkeys - 1);
             const raw_t* ks = reinterpret_cast<const raw_t*>(kc + j * D);
             const raw_t* vs = reinterpret_cast<const raw_t*>(vc + j * D);
@@ -338,10 +342,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (a.dbg && j0 == 0) { stamp[1] = clock64(); __builtin_amdgcn_sched_barrier(0); }
-        float sc[PB];
+        float sc[NP];
         float gmax = -INFINITY;
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
+        for (int p = 0; p < NP; ++p) {
             float kv[8];
             unpack(kbuf[p], kv);
             float s = 0.0f;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] *= rescale;
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const float e = expf(sc[p] - new_max);                      // 0 for masked rows
             gsum += e;
             float vv[8];
@@ -371,6 +375,20 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         run_sum = run_sum * rescale + gsum;
         run_max = new_max;
         if (a.dbg && j0 == 0) stamp[3] = clock64();
+    };
+    const int npass = (nkeys + rows_per_pass - 1) / rows_per_pass;
+    for (int p0 = 0; p0 < npass; p0 += PB) {
+        const int j0 = p0 * rows_per_pass;
+        switch (min(PB, npass - p0)) {
+        case 1: group(j0, std::integral_constant<int, 1>{}); break;
+        case 2: group(j0, std::integral_constant<int, 2>{}); break;
+        case 3: group(j0, std::integral_constant<int, 3>{}); break;
+        case 4: group(j0, std::integral_constant<int, 4>{}); break;
+        case 5: group(j0, std::integral_constant<int, 5>{}); break;
+        case 6: group(j0, std::integral_constant<int, 6>{}); break;
+        case 7: group(j0, std::integral_constant<int, 7>{}); break;
+        default: group(j0, std::integral_constant<int, 8>{}); break;
+        }
     }
     for (int off = chunks; off < 64; off <<= 1)
 #pragma unroll
