@@ -383,7 +383,7 @@ def main():
         if gemm_ms > 0:
             n_l = sum(v[0] for v in gemm.values())
             ach = wbytes / (gemm_ms * 1e-3) / 1e9
-            fam.append({'kernel': 'stream_gemm_kernel: AR weight-streaming GEMM family (qkv/proj/fc1/fc2/heads' + (f'; {Bm}-row passes: the 4 x {Bm}-row depth sub-step runs conv_glds_kernel)' if 4 * Bm > 256 else ')'), 'bound': 'hbm',
+            fam.append({'kernel': f'stream_gemm_kernel: AR weight-streaming GEMM family (qkv/proj/fc1/fc2/heads; {Bm}-row passes, {4 * Bm} rows in depth sub-step 1)', 'bound': 'hbm',
                         'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
                         'traffic': pmc_traffic('stream_gemm'), 'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3),
                         'total_ms': round(gemm_ms, 3), 'algorithmic_bytes_per_launch': round(wbytes / n_l),
@@ -393,7 +393,9 @@ def main():
                         'traffic_source': 'profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of a bounded run of this kernel family, '
                                           'committed with the repository; NOT collected by this invocation',
                         'note': 'per-launch figure of the kernels the timed region runs (one pass = merge x batch rows; throughput policy when several lanes are '
-                                'in flight), measured one lane at a time; with several lanes launches overlap.  Algorithmic bytes = the weights, streamed once per pass',
+                                'in flight), measured one lane at a time; with several lanes launches overlap.  Algorithmic bytes = the weights, streamed once per pass.  '
+                                'At 256+ rows per pass these launches are no longer bound by HBM but by the L2 -> L1 traffic of their 64-row tiles (DESIGN.md): '
+                                'the HBM fraction is quoted because HBM is still the roofline the weight stream has to respect',
                         'ar_ms_one_pass_this_schedule': round(ar_ms, 3), 'ar_ms_serial_batch': round(ar_ms_serial, 3),
                         'timed_region_weight_stream_GBps': round(wbytes * passes / elapsed_lanes / 1e9, 1)})
         if conv_ms > 0:
@@ -401,7 +403,8 @@ def main():
             ach = cflops / (conv_ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if dec_prec != 'exact' else F32_PEAK_TFLOPS
             mfma_per_flop = 3 if dec_prec == 'split' else 1           # SPLIT issues three fp16 MFMAs per product term
-            kname = {'split': 'conv3x3_split_wide_kernel (+ split_gemm_kernel for 1x1): HQ-VAE decoder conv family, fp16 hi/lo split operands',
+            kname = {'split': 'conv3x3_split_ring16_kernel (+ conv3x3_split_stream_kernel<32> for conv_out, split_gemm_kernel for the 1x1 convs and the attention GEMMs): '
+                              'HQ-VAE decoder conv family, fp16 hi/lo split operands',
                      'fast': 'conv3x3_halo_kernel (+ conv_glds_kernel for 1x1): HQ-VAE decoder conv family, bf16',
                      'exact': 'gemm_tile_kernel: HQ-VAE decoder conv family, fp32 vector ALUs'}[dec_prec]
             fam.append({'kernel': kname, 'bound': 'mfma', 'achieved': round(ach * mfma_per_flop, 2),

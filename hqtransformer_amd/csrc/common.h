@@ -175,6 +175,7 @@ struct GemmArgs {
     //      C / resid are fp32.  gn_part_out_d: per-tile GroupNorm partials of the fp32 output as doubles (layout of gn_part_out).
     const void* Bw_lo;
     const void* Bw_frag;     // optional: the same filters packed in MFMA fragment order (split_stream_conv.hip)
+    const void* Bw_frag16;   // optional: ... packed for v_mfma_f32_16x16x32_f16 (16-channel blocks; conv3x3_split_ring16_kernel)
     double* gn_part_out_d;
 };
 

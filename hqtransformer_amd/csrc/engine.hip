@@ -66,6 +66,7 @@ struct Lin {            // one nn.Linear / conv filter bank in every layout the 
     half_t* w16h = nullptr;       // [N, K] fp16 hi / lo planes of w32 (SPLIT convolutions: split_kernels.h)
     half_t* w16l = nullptr;
     half_t* wfrag = nullptr;      // 3x3 filters, hi + lo, packed in MFMA fragment order (split_stream_conv.hip)
+    half_t* wfrag16 = nullptr;    // ... in 16-channel blocks for the 16x16x32 MFMA shape
     bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)
     bf16_t* wpk_ln = nullptr;     // same packing of gamma o W (deferred LayerNorm), with its column sums and folded bias
     float* colsum = nullptr;
@@ -589,6 +590,10 @@ static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int k
     if (taps == 9 && I % 32 == 0) {              // fragment-packed copy for the streaming SPLIT kernel
         CHK(dev_alloc(h, (void**)&l.wfrag, split_frag_elems(O, I) * sizeof(half_t), false));
         HIPCHK(launch_pack_split_frag(wt, l.wfrag, O, I, 0));
+        if (O % 128 == 0) {
+            CHK(dev_alloc(h, (void**)&l.wfrag16, split_frag_elems(O, I) * sizeof(half_t), false));
+            HIPCHK(launch_pack_split_frag16(wt, l.wfrag16, O, I, 0));
+        }
     }
     return HQT_OK;
 }
@@ -803,7 +808,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     if (g.lda == 0) g.lda = l.K;
     Timed t(h, tag, st);
     if (g.Bw_lo) {                              // SPLIT: the caller packed the operand planes (s1_operand) after checking the shape
-        g.Bw = l.w16h; g.Bw_lo = l.w16l; g.Bw_frag = l.wfrag;
+        g.Bw = l.w16h; g.Bw_lo = l.w16l; g.Bw_frag = l.wfrag; g.Bw_frag16 = l.wfrag16;
         if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
         if (g.conv_taps == 9) {
             if (g.store == STORE_ROWS && h->gn_tiles && conv_halo_stats_ok(g.N, 32)) {   // every such output is normalised next
@@ -1363,7 +1368,7 @@ struct S1Ctx {
 static bool split_shape_ok(const hqt_handle* h, const GemmArgs& g, const Lin& l) {
     if (!l.w16h) return false;
     GemmArgs t = g;
-    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l; t.Bw_frag = l.wfrag;
+    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l; t.Bw_frag = l.wfrag; t.Bw_frag16 = l.wfrag16;
     if (t.lda == 0) t.lda = l.K;
     return t.conv_taps == 9 ? split_conv3_ok(t) : split_gemm_ok(t);
 }

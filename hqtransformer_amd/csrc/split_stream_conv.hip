@@ -697,6 +697,307 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring_kernel(GemmArgs g) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fifth generation ("ring16"): the ring kernel on v_mfma_f32_16x16x32_f16.  The ring kernel keeps the matrix pipe busy 85 % of the
+// time (profiles/r02_pmc_mfma_util_*.txt) -- but under that load the chip holds its clock near 1.5 GHz instead of 2.4
+// (GRBM_GUI_ACTIVE / 8 / duration), so what is left is the energy per MFMA, not the issue stream; MI355X_MICROARCH.md ('DVFS give-back',
+// item 7) measures the 16x16x32 shape ~1.12-1.15x faster by wall than 32x32x16 at equal cycles per FLOP with operands read from LDS.
+// Same tile, patch image, piece schedule and epilogue staging; per wave 8 pixel blocks (the 8 tile rows of 16 pixels) x 2 channel blocks
+// of 16; one MFMA covers a whole 32-channel chunk of a tap, so a "step" is a tap: 48 MFMAs of 16 cycles against 16 fragment reads,
+// 4 filter loads and <= 1 patch piece.  Filters are packed per 16-channel block ([32-channel group][chunk][tap][block][hi | lo],
+// 1 KiB each: lane l holds W[16 block + (l & 15)][tap Cin + 32 c + 8 (l >> 4) + j]), ring of 3 taps (48 registers).
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_split_frag16_kernel(const float* __restrict__ w, half_t* __restrict__ out, int N, int Cin, size_t total) {
+    const int NC = Cin / 32;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t ch = i >> 9;
+        const int plane = (int)(ch & 1); ch >>= 1;
+        const int blk = (int)(ch & 1); ch >>= 1;
+        const int tap = (int)(ch % 9); ch /= 9;
+        const int c = (int)(ch % NC);
+        const int t = (int)(ch / NC);
+        const int n = t * 32 + blk * 16 + (lane & 15), k = tap * Cin + c * 32 + 8 * (lane >> 4) + j;
+        const float x = n < N ? w[(size_t)n * 9 * Cin + k] : 0.0f;
+        const half_t hi = (half_t)x;
+        out[i] = plane ? (half_t)((x - (float)hi) * 2048.0f) : hi;
+    }
+}
+hipError_t launch_pack_split_frag16(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st) {
+    const size_t total = split_frag_elems(N, Cin) - R_FRAG_PAD;
+    pack_split_frag16_kernel<<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, st>>>(w_tapmajor, out, N, Cin, total);
+    return hipGetLastError();
+}
+
+namespace {
+constexpr int H_RING = 3, H_AHEAD = H_RING - 1, H_STEPS = 18;         // ring slots (taps), prefetch distance, taps per loop body (two chunks)
+static_assert(H_STEPS % H_RING == 0, "static ring slots");
+constexpr bool h_piece_at(int u) { u = ((u % H_STEPS) + H_STEPS) % H_STEPS; return (u % 9) < 6; }
+// loads issued after the filters of body step s (fetched during step s - 2, first hook) and before step s begins
+constexpr int h_younger(int s) {
+    int n = 4 * (H_AHEAD - 1);
+    for (int u = s - H_AHEAD; u < s; ++u) n += h_piece_at(u) ? 1 : 0;
+    return n;
+}
+}  // namespace
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_ring16_kernel(GemmArgs g) {
+    constexpr int NI = 8;                                           // pixel blocks = tile rows
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fx = lane & 15, fk = lane >> 4;
+    int tile_m, tile_n;
+    r_xcd_tile(tile_m, tile_n);
+    const int n0 = tile_n * 128;
+    const int tiles_x = g.W / R_TX, tiles_y = g.H / R_TY;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * R_TY, tx0 = (trem % tiles_x) * R_TX;
+    const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
+    const half_t* Abase = reinterpret_cast<const half_t*>(g.A);                 // [pixel][hi Cin | lo Cin]
+    const int NC = g.Cin / 32;
+
+    // ---- patch pieces: exactly as in the ring kernel
+    constexpr int PPW = 2 * R_PIECES / 4;
+    static_assert(PPW == 6, "one piece per wave at taps 0..5");
+    typedef int rsrc_t __attribute__((ext_vector_type(4)));
+    rsrc_t img_rsrc;
+    {
+        const unsigned long long ib = (unsigned long long)(size_t)(Abase + (long long)img * Hin * Win * (2 * g.Cin));
+        img_rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ib);
+        img_rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ib >> 32) & 0xffff);      // stride 0
+        img_rsrc[2] = __builtin_amdgcn_readfirstlane(Hin * Win * 2 * g.Cin * 2);               // bytes
+        img_rsrc[3] = 0x00020000;                                                              // raw buffer, 32-bit data format (gfx9)
+    }
+    unsigned poff[3];                                               // hi-plane source offset of pieces wave + 4 (u % 3); the lo plane is + Cin halves (scalar offset)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int plane = 0, piece = wave + 4 * u;
+        const int q = piece * 16 + (lane >> 2);
+        const int qy = (q * 3641) >> 16, qx = q - qy * R_PITCH;                 // q / 18 for q < 192
+        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+        const bool in = (q < R_ROWS) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+        const unsigned off = (unsigned)((((iy >> g.upsample) * Win + (ix >> g.upsample)) * (2 * g.Cin) + (lane & 3) * 8 + plane * g.Cin) * 2);
+        poff[u] = in ? off : 0x80000000u;
+    }
+    u32x4 pst[2];                                                   // pieces in flight: loaded at tap t, written to LDS at tap t + 2
+    unsigned piece_base = lds_base + wave * (16 * G_PITCH) + (lane >> 2) * G_PITCH + (lane & 3) * 16;
+    auto load_piece = [&](int c, int u, int r) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pst[r]) : "v"(poff[u % 3]), "s"(img_rsrc), "s"(c * 64 + (u / 3) * g.Cin * 2));
+    };
+#define HQT_STORE_PIECE(buf, u, r)                                                                                             \
+    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(piece_base), "v"(pst[r]),                                            \
+                 "n"(((buf) * 2 + (u) / 3) * G_PLANE + 4 * ((u) % 3) * 16 * G_PITCH) : "memory")
+
+    // this wave's filter stream: 4 KiB per tap ([block 0 hi][block 0 lo][block 1 hi][block 1 lo])
+    const char* bfrag = reinterpret_cast<const char*>(reinterpret_cast<const half_t*>(g.Bw_frag16) + (size_t)(n0 / 32 + wave) * ((size_t)NC * 9 * 2048));
+    unsigned lane16 = lane * 16;
+
+    f32x4 accm[NI][2], accx[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accm[i][j][r] = 0.0f; accx[i][j][r] = 0.0f; }
+    // fragment of pixel block i at tap (dy, dx): patch row (i + dy) * 18 + fx + dx, 16-B group fk -- one base + immediates
+    const unsigned abase = lds_base + fx * G_PITCH + fk * 16;
+    half8 ah[4], al[4];                                             // pixel blocks in flight: slot = block % 4
+    half8 wh[H_RING][2], wl[H_RING][2];                             // filter fragments [tap % 3][channel block]
+#define HQT_READ_A16(ps, tapoff, i)                                                                                            \
+    do {                                                                                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[(i) % 4]) : "v"(abase), "n"((ps) * 2 * G_PLANE + ((i) * R_PITCH + (tapoff)) * G_PITCH));            \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[(i) % 4]) : "v"(abase), "n"((ps) * 2 * G_PLANE + ((i) * R_PITCH + (tapoff)) * G_PITCH + G_PLANE));  \
+    } while (0)
+    auto load_b = [&](long long S, int slot) {
+        const char* p = bfrag + S * 4096;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wh[slot][0]) : "v"(lane16), "s"(p));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(wl[slot][0]) : "v"(lane16), "s"(p));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wh[slot][1]) : "v"(lane16), "s"(p));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(wl[slot][1]) : "v"(lane16), "s"(p));
+    };
+
+    // ---- prologue (as the ring kernel): first patch through the piece registers, filters of taps 0 and 1; everything lands first
+#pragma unroll
+    for (int rnd = 0; rnd < 3; ++rnd) {
+        load_piece(0, 2 * rnd, 0); load_piece(0, 2 * rnd + 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pst[0]), "+v"(pst[1]));
+        if (rnd == 0) { HQT_STORE_PIECE(0, 0, 0); HQT_STORE_PIECE(0, 1, 1); }
+        else if (rnd == 1) { HQT_STORE_PIECE(0, 2, 0); HQT_STORE_PIECE(0, 3, 1); }
+        else { HQT_STORE_PIECE(0, 4, 0); HQT_STORE_PIECE(0, 5, 1); }
+    }
+#pragma unroll
+    for (int s = 0; s < H_AHEAD; ++s) load_b(s, s);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // ---- main loop: one iteration = two chunks = 18 taps of straight-line code
+#pragma unroll 1
+    for (int c0 = 0; c0 < NC; c0 += 2) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = c0 + cc, cn = min(c + 1, NC - 1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (ABL != 4) { HQT_READ_A16(cc, 0, 0); HQT_READ_A16(cc, 0, 1); HQT_READ_A16(cc, 0, 2); HQT_READ_A16(cc, 0, 3); }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int s = cc * 9 + tap, slot = s % H_RING, nslot = (s + H_AHEAD) % H_RING;
+                const long long S = (long long)c0 * 9 + s;
+                const int tapoff = (tap / 3) * R_PITCH + tap % 3, ntapoff = ((tap + 1) / 3) * R_PITCH + (tap + 1) % 3;
+                if (ABL != 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wh[slot][0]), "+v"(wl[slot][0]), "+v"(wh[slot][1]), "+v"(wl[slot][1]) : "n"(h_younger(s)));
+                // pixel blocks in pairs [m m m m x x x x x' x' x' x']: no MFMA directly follows the one it accumulates onto
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int i0 = 2 * pr, i1 = 2 * pr + 1;
+                    // reads in issue order: blocks (2 pr, 2 pr + 1) of this tap were issued two pairs ago; behind them: the next pair (4 reads)
+                    if (ABL != 4) {
+                        const bool more = !(tap == 8 && pr == 3);       // the last pair of a chunk has nothing behind it
+                        if (more) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[i0 % 4]), "+v"(al[i0 % 4]), "+v"(ah[i1 % 4]), "+v"(al[i1 % 4]));
+                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i0 % 4]), "+v"(al[i0 % 4]), "+v"(ah[i1 % 4]), "+v"(al[i1 % 4]));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            accm[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][j], ah[(i0 + ii) % 4], accm[i0 + ii][j], 0, 0, 0);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            accx[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][j], al[(i0 + ii) % 4], accx[i0 + ii][j], 0, 0, 0);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            accx[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot][j], ah[(i0 + ii) % 4], accx[i0 + ii][j], 0, 0, 0);
+                    if (ABL == 4) continue;
+                    // refill the two slots: blocks (i0 + 4, i1 + 4) of this tap, or blocks (i0 - 4, i1 - 4) of the next tap
+                    if (pr < 2) {
+                        if (pr == 0) { HQT_READ_A16(cc, tapoff, 4); HQT_READ_A16(cc, tapoff, 5); }
+                        else { HQT_READ_A16(cc, tapoff, 6); HQT_READ_A16(cc, tapoff, 7); }
+                    } else if (tap < 8) {
+                        if (pr == 2) { HQT_READ_A16(cc, ntapoff, 0); HQT_READ_A16(cc, ntapoff, 1); }
+                        else { HQT_READ_A16(cc, ntapoff, 2); HQT_READ_A16(cc, ntapoff, 3); }
+                    }
+                    if (pr == 0) load_b(S + H_AHEAD, nslot);            // the slot tap s - 1 released takes the filters of tap s + 2
+                    if (pr == 1 && ABL != 2) {
+                        // the piece of tap - 2: behind it were issued the filters of tap + 1 (4), the piece of tap - 1 and the filters of tap + 2 (4)
+                        if (tap >= 2 && tap - 2 < PPW) {
+                            if (tap - 1 < PPW) asm volatile("s_waitcnt vmcnt(9)" : "+v"(pst[tap % 2]));
+                            else asm volatile("s_waitcnt vmcnt(8)" : "+v"(pst[tap % 2]));
+                            HQT_STORE_PIECE(cc ^ 1, tap - 2, tap % 2);
+                        }
+                        if (tap < PPW) load_piece(cn, tap, tap % 2);
+                    }
+                }
+            }
+        }
+    }
+#undef HQT_READ_A16
+#undef HQT_STORE_PIECE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // the patch buffers become the epilogue's staging area
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 1) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc += accm[i][j][r] + accx[i][j][r];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
+        return;
+    }
+    // ---- epilogue.  D map: col = lane & 15 -> pixel fx of tile row i; row = 4 (lane >> 4) + r -> channel 16 j + 4 fk + r of the wave's 32.
+    //      Staged store, 64 pixels (tile rows 4 half .. 4 half + 3) at a time, then as the ring kernel.
+    const long long pix0 = ((long long)img * g.H + ty0) * g.W + tx0;
+    char* stage = lds_raw;
+    float* Cb = reinterpret_cast<float*>(g.C);
+    const float* Rb = reinterpret_cast<const float*>(g.resid);
+    const int c8 = (tid & 15) * 8, nn = n0 + c8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (g.bias && nn + e < g.N) ? g.bias[nn + e] : 0.0f;
+    float gs[8], gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half > 0) __syncthreads();                  // the previous half has been read back
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = half * 4 + ii, r = ii * 16 + fx;      // pixel within the staged 64
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nl = wave * 32 + j * 16 + 4 * fk;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = accm[i][j][e] + accx[i][j][e] * R_INV;
+                *reinterpret_cast<f32x4*>(stage + r * R_CPITCH + nl * 4) = v;
+            }
+        }
+        __syncthreads();
+        if (nn < g.N) {                                 // N % 8 == 0
+            long long moff[4];
+            f32x4 r0[4], r1[4];
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {            // the residual rows of the four passes are fetched together
+                const int r = p4 * 16 + (tid >> 4);
+                moff[p4] = (pix0 + (long long)(half * 4 + (r >> 4)) * g.W + (r & 15)) * g.ldc + nn;
+                if (Rb) { r0[p4] = *reinterpret_cast<const f32x4*>(Rb + moff[p4]); r1[p4] = *reinterpret_cast<const f32x4*>(Rb + moff[p4] + 4); }
+            }
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int r = p4 * 16 + (tid >> 4);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * R_CPITCH + c8 * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * R_CPITCH + c8 * 4 + 16);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
+                if (Rb) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[p4][e]; v[4 + e] += r1[p4][e]; }
+                }
+                const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(Cb + moff[p4]) = o0;
+                *reinterpret_cast<f32x4*>(Cb + moff[p4] + 4) = o1;
+                if (g.gn_part_out_d) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+                }
+            }
+        }
+    }
+    if (g.gn_part_out_d) {                              // uniform branch (kernel argument): barriers are safe here
+        __syncthreads();
+        float* redw = reinterpret_cast<float*>(lds_raw);                    // [16 pixel rows][128 channels][2]; zeros from idle threads
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
+            redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
+        }
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(lds_raw);
+        if (tid < 128) {
+            double sa = 0.0, sq = 0.0;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) { sa += (double)red[((rg * 128) + tid) * 2]; sq += (double)red[((rg * 128) + tid) * 2 + 1]; }
+            const int cpg = g.N / g.gn_out_groups;
+            for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
+            const int ch = n0 + tid;
+            if (ch < g.N && (tid & (cpg - 1)) == 0) {
+                double* pp = g.gn_part_out_d + (((long long)img * (tiles_x * tiles_y) + trem) * g.gn_out_groups + ch / cpg) * 2;
+                pp[0] = sa; pp[1] = sq;
+            }
+        }
+    }
+}
+
 bool split_stream_ok(const GemmArgs& g) {
     static const bool off = getenv("HQT_SPLIT_STREAM") && atoi(getenv("HQT_SPLIT_STREAM")) == 0;      // A/B switch
     if (off || !g.Bw_frag) return false;
@@ -710,7 +1011,9 @@ hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st) {
     else {
         static const bool ring = !(getenv("HQT_SPLIT_RING") && atoi(getenv("HQT_SPLIT_RING")) == 0);     // A/B switch: 0 = the stream kernel
         const dim3 grid((g.N + 127) / 128, g.M / (R_TY * R_TX), 1);
-        if (ring) conv3x3_split_ring_kernel<0><<<grid, 256, G_LDS, st>>>(g);
+        static const bool ring16 = !(getenv("HQT_SPLIT_RING16") && atoi(getenv("HQT_SPLIT_RING16")) == 0);   // A/B switch: 0 = the 32x32x16 ring kernel
+        if (ring && ring16 && g.Bw_frag16) conv3x3_split_ring16_kernel<0><<<grid, 256, G_LDS, st>>>(g);
+        else if (ring) conv3x3_split_ring_kernel<0><<<grid, 256, G_LDS, st>>>(g);
         else conv3x3_split_stream_kernel<false, 128><<<grid, 256, R_LDS, st>>>(g);
     }
     return hipGetLastError();
@@ -719,6 +1022,8 @@ hipError_t split_stream_configure() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_stream_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_ring_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_ring16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_stream_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
 }

@@ -65,6 +65,20 @@ static float run_ring(const GemmArgs& g, hipStream_t st, int reps) {
     return 1000.f * ms / reps;
 }
 
+template <int ABL>
+static float run_ring16(const GemmArgs& g, hipStream_t st, int reps) {
+    const dim3 grid((g.N + 127) / 128, g.M / 128, 1);
+    void (*k)(GemmArgs) = conv3x3_split_ring16_kernel<ABL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+    k<<<grid, 256, G_LDS, st>>>(g);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) k<<<grid, 256, G_LDS, st>>>(g);
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return 1000.f * ms / reps;
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64;
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -88,8 +102,8 @@ int main(int argc, char** argv) {
         }
     }
     CK(hipMemset(bias, 0, 512 * 4)); CK(hipMemset(zero, 0, 256));
-    half_t* Wfrag; float* W32;
-    CK(hipMalloc(&Wfrag, split_frag_elems(512, 512) * 2)); CK(hipMalloc(&W32, wmax * 4));
+    half_t *Wfrag, *Wfrag16; float* W32;
+    CK(hipMalloc(&Wfrag, split_frag_elems(512, 512) * 2)); CK(hipMalloc(&Wfrag16, split_frag_elems(512, 512) * 2)); CK(hipMalloc(&W32, wmax * 4));
     {
         std::vector<float> wf(wmax);
         unsigned x = 777u;
@@ -97,7 +111,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(W32, wf.data(), wmax * 4, hipMemcpyHostToDevice));
     }
     printf("%-22s %8s | %7s %7s %7s | %7s %7s %7s %7s | %7s %7s\n", "layer (batch 64)", "GF x3", "pc1 us", "TF eq", "pc0 us", "no-epi", "no-dma", "dma", "mfma", "pc0nodma", "pc0 mfma");
-    double tot = 0, totf = 0, tot_stream = 0, tot_ring = 0;
+    double tot = 0, totf = 0, tot_stream = 0, tot_ring = 0, tot_ring16 = 0;
     for (const Shape& s : shapes) {
         GemmArgs g{};
         g.A = A; g.conv_taps = 9; g.H = s.res; g.W = s.res; g.Cin = s.cin; g.upsample = s.up;
@@ -120,6 +134,11 @@ int main(int argc, char** argv) {
             const float g5 = run_ring<5>(gs, st, reps), g6 = run_ring<6>(gs, st, reps), g7 = run_ring<7>(gs, st, reps), g8 = run_ring<8>(gs, st, reps);
             printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f | patch reads only %7.1f (no barrier %7.1f, hi plane only %7.1f) filter loads only %7.1f\n", "   ring (filters 5 k-steps ahead)", "", g0, fl / g0 * 1e-6, "", g1, g2, "", g4, g5, g7, g8, g6);
             tot_ring += g0;
+            CK(launch_pack_split_frag16(W32, Wfrag16, s.cout, s.cin, st));
+            GemmArgs gh = gs; gh.Bw_frag16 = Wfrag16;
+            const float h0 = run_ring16<0>(gh, st, reps), h1 = run_ring16<1>(gh, st, reps), h2 = run_ring16<2>(gh, st, reps), h4 = run_ring16<4>(gh, st, reps);
+            printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f\n", "   ring16 (16x16x32 MFMA)", "", h0, fl / h0 * 1e-6, "", h1, h2, "", h4);
+            tot_ring16 += h0;
         }
         {
             static long long* dbg = nullptr;
@@ -134,6 +153,6 @@ int main(int argc, char** argv) {
         }
         tot += std::min(t0, w0); totf += fl;
     }
-    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent; stream kernel: %.1f us, %.1f; ring kernel: %.1f us, %.1f\n", tot, totf / tot * 1e-6, tot_stream, totf / tot_stream * 1e-6, tot_ring, totf / tot_ring * 1e-6);
+    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent; stream kernel: %.1f us, %.1f; ring kernel: %.1f us, %.1f; ring16: %.1f us, %.1f\n", tot, totf / tot * 1e-6, tot_stream, totf / tot_stream * 1e-6, tot_ring, totf / tot_ring * 1e-6, tot_ring16, totf / tot_ring16 * 1e-6);
     return 0;
 }
