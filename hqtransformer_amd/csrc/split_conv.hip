@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
             float t = f[i];
             if (GN) {
                 t = (t - mu[i]) * rs[i] * gm[i] + bt[i];
-                if (swish) t = t / (1.0f + expf(-t));
+                if (swish) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));     // v_exp_f32 / v_rcp_f32 (1 ulp each): the pass is close to VALU-bound with IEEE division
             }
             split2(t, hi[i], lo[i]);
         }
