@@ -666,7 +666,7 @@ static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, f
         // M = 512 .. 1024: bound by the L2 -> L1 traffic of the 64-row tiles (~20 TB/s over the chip), so the widest weight tile whose
         // partial tiles still fit the LDS twice; tools/micro/bench_stream, M = 1024: qkv 29.7, proj 14.1, fc1 35.4, fc2 33.3 us
         // (round 1 took these shapes through the generic LDS-DMA GEMM at 48 .. 86 us plus separate LayerNorm launches)
-        if (g.K > 2 * g.N && (g.N / 32) % 3 == 0) return launch_stream_t<2, 3, 4, 4, TC, true>(g, wpk, 1, nullptr, st);
+        if (g.a_packed_mb >= 32 && g.K > 2 * g.N && (g.N / 32) % 3 == 0) return launch_stream_t<2, 3, 4, 4, TC, true>(g, wpk, 1, nullptr, st);   // fc2 from 1024 rows (at 512: 33 vs 26 us)
         if ((g.N / 32) % 2 == 0) return launch_stream_t<2, 2, 4, 4, TC, true>(g, wpk, 1, nullptr, st);
     }
     const int wgs2 = (g.N / 32) * (g.a_packed_mb / 2);

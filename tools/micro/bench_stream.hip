@@ -68,21 +68,21 @@ int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
     const Shape shapes[] = {{"qkv", 4608, 1536}, {"proj", 1536, 1536}, {"fc1", 6144, 1536}, {"fc2", 1536, 6144}, {"head", 8192, 1536}};
     bf16_t* x; float *y, *slabs;
-    CK(hipMalloc(&x, 1024 * 6144 * 2)); CK(hipMemset(x, 0x3c, 1024 * 6144 * 2));
-    CK(hipMalloc(&y, 1024 * 8192 * 4)); CK(hipMalloc(&slabs, 4ull * 1024 * 8192 * 4));
+    CK(hipMalloc(&x, 2048 * 6144 * 2)); CK(hipMemset(x, 0x3c, 2048 * 6144 * 2));
+    CK(hipMalloc(&y, 2048ull * 8192 * 4)); CK(hipMalloc(&slabs, 4ull * 2048 * 8192 * 4));
     for (const Shape& sh : shapes) {
         const size_t bytes = (size_t)sh.N * sh.K * 2;
         const int nbuf = (int)(((size_t)600 << 20) / bytes) + 1;
         std::vector<bf16_t*> w(nbuf);
         for (auto& p : w) { CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0x3c, bytes)); }
-        for (int M : {64, 256, 1024}) {
+        for (int M : {64, 256, 512, 1024, 2048}) {
             printf("== %s N=%d K=%d M=%d  (%.1f MB weights; HBM floor %.2f us @6.3TB/s)\n", sh.name, sh.N, sh.K, M, bytes / 1e6, bytes / 6.3e6);
 #define V(MBW, NT, NW, U, S) { float t = run<MBW, NT, NW, U>(sh, M, S, w, x, y, slabs, st); if (t > 0) printf("   MBW=%d NT=%d NW=%d U=%2d S=%d : %7.2f us  (%.2f TB/s)\n", MBW, NT, NW, U, S, t, bytes / t / 1e6); }
             if (M == 64 && false) {} if (M == 64) { V(2, 1, 8, 12, 1) V(1, 1, 8, 12, 1) V(1, 1, 16, 12, 1) V(1, 1, 16, 6, 1) V(2, 1, 16, 6, 1) V(2, 1, 16, 4, 1) V(1, 1, 8, 6, 1) V(2, 1, 8, 4, 1) }
             if (M == 64 && false) { stamps<2, 1, 8, 12>(sh, M, 1, w[0], x, y, slabs, st); stamps<1, 1, 8, 12>(sh, M, 1, w[1], x, y, slabs, st); }
 #define P(MBW, NT, NW, U, S) { float t = run<MBW, NT, NW, U, 0, true>(sh, M, S, w, x, y, slabs, st); if (t > 0) printf("   MBW=%d NT=%d NW=%d D=%2d S=%d pipelined : %7.2f us  (%.2f TB/s, %.0f TFLOP/s)\n", MBW, NT, NW, U, S, t, bytes / t / 1e6, 2.0 * M * sh.N * sh.K / t / 1e6); }
-            if (M >= 256) { P(2, 2, 8, 4, 1) P(2, 2, 8, 3, 1) P(2, 2, 8, 6, 1) P(2, 2, 4, 4, 1) P(2, 2, 4, 6, 1) P(2, 3, 4, 4, 1) P(2, 3, 4, 6, 1) P(2, 1, 8, 6, 1) P(2, 1, 8, 4, 1) P(4, 2, 4, 3, 1) P(4, 2, 4, 4, 1) P(4, 1, 8, 4, 1) P(4, 1, 4, 6, 1) P(2, 2, 8, 4, 2) P(2, 2, 8, 4, 4) P(2, 2, 4, 4, 2) P(4, 2, 4, 3, 2) P(4, 2, 4, 3, 4) }
-            if (M == 1024) { V(2, 2, 8, 6, 1) V(4, 2, 4, 3, 1) V(2, 1, 8, 6, 1) }
+            if (M >= 256) { P(2, 2, 8, 4, 1) P(2, 2, 8, 3, 1) P(2, 2, 8, 6, 1) P(2, 2, 4, 4, 1) P(2, 2, 4, 6, 1) P(2, 3, 4, 4, 1) P(2, 3, 4, 6, 1) P(2, 1, 8, 6, 1) P(2, 1, 8, 4, 1) P(4, 2, 4, 3, 1) P(4, 2, 4, 4, 1) P(4, 1, 8, 4, 1) P(4, 1, 4, 6, 1) P(2, 3, 8, 4, 1) P(2, 2, 4, 4, 2) P(2, 2, 8, 4, 2) }
+            if (M >= 512) { V(2, 2, 8, 6, 1) V(4, 2, 4, 3, 1) V(2, 1, 8, 6, 1) V(2, 1, 8, 12, 1) V(2, 2, 4, 6, 1) }
             else if (M == 256) { V(1, 1, 8, 12, 1) V(2, 1, 8, 12, 1) V(2, 1, 8, 4, 1) V(2, 1, 8, 6, 1) V(2, 1, 16, 4, 1) V(4, 1, 8, 3, 1) V(4, 1, 8, 4, 1) V(4, 1, 4, 4, 1) V(4, 1, 16, 2, 1) V(2, 2, 8, 4, 1) }
         }
         for (auto& p : w) CK(hipFree(p));
