@@ -231,8 +231,8 @@ def main():
     from hqtransformer_amd.pipeline import InflightSampler
     inflight = max(1, args.inflight)
     merge = max(1, args.merge)
-    if txt_cond or three or args.positions:
-        merge = 1                                  # merged steps: class-conditional / unconditional two-level sampling only
+    if args.positions:
+        merge = 1                                  # debug runs (counter collection) sample a few positions of one pass
     rem = args.steps % merge                       # K need not be a multiple: the last pass of the timed region then holds `rem` steps
     pipe = InflightSampler(model, lanes=inflight, device=dev, merge=merge)
 

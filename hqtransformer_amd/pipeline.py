@@ -7,8 +7,8 @@ therefore round-robins consecutive batches over N *lanes*: every lane has its ow
 (``hqt_clone``) and shares the weights, every batch is still one complete ``sampling_ihqgpt`` + ``decode_code`` pass
 of the configured batch size, and results do not depend on the lane (bit-identical, tests/test_gpu_surface.py).
 
-``merge=k`` additionally executes k queued steps as ONE pass of k x B rows: the steps stay independent -- every row keeps the class
-id, the Philox seed and the global row index of its own step (``hqt_sample_opts.row_seeds`` / ``row_offsets``), so in EXACT
+``merge=k`` additionally executes k queued steps as ONE pass of k x B rows (class-conditional, unconditional, text-conditional; two or
+three code levels): the steps stay independent -- every row keeps the class id / prompt, the Philox seed and the global row index of its own step (``hqt_sample_opts.row_seeds`` / ``row_offsets``), so in EXACT
 arithmetic each step's codes are bit-identical to the unmerged call (tests/test_gpu_surface.py) -- but the weights are streamed
 once for all of them instead of once per step.
 """
@@ -54,8 +54,8 @@ class InflightSampler:
         The tensors are valid once ``done_event`` has completed (or after ``drain()``).  ``phase_events``: three timing
         events recorded on the lane's stream at AR start / AR end / decode end (lane time: phases of different lanes overlap)."""
         if self.merge > 1:
-            if decode is False or phase_events is not None or sample_kw.get('noise') is not None or getattr(self.model.stage2, 'use_txt_cond', False):
-                raise ValueError('merged steps support the plain class-conditional / unconditional sample + decode step only')
+            if decode is False or phase_events is not None or sample_kw.get('noise') is not None:
+                raise ValueError('merged steps support the plain sample + decode step only (no explicit noise, no phase events)')
             p = Pending()
             self._queue.append((p, num_candidates, cond, seed, max_seq_len, use_fp16, precision, clamp01, use_graph, after, order_after_current, sample_kw))
             if len(self._queue) >= self.merge:
@@ -83,7 +83,9 @@ class InflightSampler:
         kw.pop('sample_offset', None)
         cls = getattr(self.model.stage2, 'use_cls_cond', False)
         cond = None
-        if cls:
+        if getattr(self.model.stage2, 'use_txt_cond', False):           # [n, ctx_len_txt] token ids per step
+            cond = torch.cat([torch.as_tensor(e[2]).reshape(n, -1).to('cpu', torch.int64) for e, n in zip(q, sizes)])
+        elif cls:
             parts = []
             for e, n in zip(q, sizes):
                 c = torch.as_tensor(e[2]).reshape(-1).to('cpu', torch.int64)
