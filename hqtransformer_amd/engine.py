@@ -5,6 +5,7 @@ PyTorch is plumbing here (device memory, streams); all arithmetic happens inside
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -50,7 +51,7 @@ def make_config(s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], max_batch: i
 
 # (data_ptr, numel) -> tensor version of device tensors whose indices are known to be in range: produced by a sampler of this
 # process (any engine: the stage-2 engine's codes go to the stage-1 engine's decode) or already validated once
-_TRUSTED: Dict[Tuple[int, int], int] = {}
+_TRUSTED: Dict[Tuple[int, int], tuple] = {}       # (data_ptr, numel) -> (tensor version, weakref to its storage)
 
 
 class Engine:
@@ -135,7 +136,9 @@ class Engine:
     def _trust(self, *tensors) -> None:
         for t in tensors:
             if t is not None:
-                _TRUSTED[(t.data_ptr(), t.numel())] = t._version
+                # (address, size) alone is not an identity: the caching allocator hands a freed block to the next tensor of that size.
+                # The storage object is: torch keeps one Python wrapper per live storage, and a weak reference to it dies with the storage.
+                _TRUSTED[(t.data_ptr(), t.numel())] = (t._version, weakref.ref(t.untyped_storage()))
                 if len(_TRUSTED) > 256:
                     _TRUSTED.pop(next(iter(_TRUSTED)))
 
@@ -143,7 +146,8 @@ class Engine:
         if t is None or t.numel() == 0:
             return
         key = (t.data_ptr(), t.numel())
-        if t.is_cuda and _TRUSTED.get(key) == t._version:
+        seen = _TRUSTED.get(key) if t.is_cuda else None
+        if seen is not None and seen[0] == t._version and seen[1]() is t.untyped_storage():
             return
         lo, hi = (int(v) for v in torch.stack([t.min(), t.max()]).tolist())
         if lo < 0 or hi >= n:

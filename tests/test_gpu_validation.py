@@ -92,3 +92,24 @@ def test_kernels_clamp_indices_that_bypass_the_python_surface(engines):
     wild = run(torch.tensor([10 ** 9, -7], device=DEV), torch.tensor([[5, 10 ** 12, 1], [-3, 2, 7]], device=DEV))
     tame = run(torch.tensor([s2.n_classes - 1, 0], device=DEV), torch.tensor([[5, s2.vocab_top - 1, 1], [0, 2, 7]], device=DEV))
     assert torch.equal(wild[0], tame[0]) and torch.equal(wild[1], tame[1])
+
+
+def test_index_trust_dies_with_the_tensor(engines):
+    """Index tensors that passed the range check are remembered (no second device round trip when sample()'s codes go into decode());
+    the memory must not stay trusted once the tensor is gone: the caching allocator hands the block to the next tensor of that size
+    (seen in the full suite: a bad code grid landed on a block an earlier test had validated, and decode() did not raise)."""
+    import weakref
+    from hqtransformer_amd import engine as E
+    s2, e2, s1, e1, fx1 = engines
+    cb = torch.from_numpy(fx1['code_b']).to(DEV)
+    ct = torch.from_numpy(fx1['code_t']).to(DEV)
+    e1.decode(ct, cb, precision=PRECISION_EXACT)                # checked once ...
+    key = (ct.data_ptr(), ct.numel())
+    assert key in E._TRUSTED and E._TRUSTED[key][1]() is ct.untyped_storage()      # ... and trusted while it lives
+    bad_host = torch.from_numpy(fx1['code_t']).clone()
+    bad_host[0, 0, 0] = s1.n_embed + 7
+    bad = bad_host.to(DEV)
+    # what a freed-and-reused block leaves behind: an entry for this address, size and version whose storage is another one
+    E._TRUSTED[(bad.data_ptr(), bad.numel())] = (bad._version, weakref.ref(ct.untyped_storage()))
+    with pytest.raises(IndexError):
+        e1.decode(bad, cb, precision=PRECISION_EXACT)

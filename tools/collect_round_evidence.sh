@@ -27,8 +27,8 @@ timeout 600 python bench.py --merge 4 --inflight 3 --no-cpu-baseline --no-roofli
 timeout 600 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline --no-roofline > $O/bench_serial.json 2>/dev/null
 timeout 600 python bench.py --batch 256 --merge 1 --inflight 1 --steps 24 --no-cpu-baseline --no-roofline > $O/bench_batch256_inflight1.json 2>/dev/null
 timeout 600 python bench.py --decode-precision fast --no-cpu-baseline --no-roofline > $O/bench_decode_fast.json 2>/dev/null
-timeout 600 python bench.py --config configs/imagenet-12l-level3.yaml --steps 12 --no-cpu-baseline --no-roofline > $O/bench_level3.json 2>/dev/null
-timeout 600 python bench.py --config configs/cc15m-12l-txt.yaml --steps 12 --no-cpu-baseline --no-roofline > $O/bench_text_cond.json 2>/dev/null
+timeout 600 python bench.py --config configs/imagenet-12l-level3.yaml --steps 48 --no-cpu-baseline --no-roofline > $O/bench_level3.json 2>/dev/null
+timeout 600 python bench.py --config configs/cc15m-12l-txt.yaml --steps 48 --no-cpu-baseline --no-roofline > $O/bench_text_cond.json 2>/dev/null
 timeout 300 python tools/bench_decode.py --precision split > $O/decode_split_batch64.json 2>/dev/null
 timeout 300 python tools/bench_decode.py --precision fast > $O/decode_fast_batch64.json 2>/dev/null
 timeout 300 python tools/diag_overlap.py --rows 512 > $O/diag_overlap_rows512.json 2>/dev/null
