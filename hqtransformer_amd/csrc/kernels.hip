@@ -487,26 +487,54 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
     if (a.top_k > 0 && a.top_k < V) {
         uint32_t prefix = 0;
         int remaining = a.top_k;
+        const int lane = tid & 63, wave = tid >> 6;
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
+            if (tid == 0) sel[0] = 0;
             __syncthreads();
             const uint32_t himask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
-            for (int i = tid; i < V; i += NT) {
-                const uint32_t o = f2ord(lp[i]);
-                if ((o & himask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int cum = 0, bin = 255;
-                for (; bin > 0; --bin) {
-                    if (cum + (int)hist[bin] >= remaining) break;
-                    cum += (int)hist[bin];
+            // Histogram of the current byte.  Logits share their leading bytes, so most of a wave hits ONE bin: a plain atomicAdd per
+            // element serialises on that LDS address (1.1 ms per launch at 2048 rows, V = 8192).  Each wave therefore counts its own
+            // elements per distinct bin with ballots and issues one atomic per (wave, bin).
+            for (int i0 = 0; i0 < V; i0 += NT) {
+                const int i = i0 + tid;
+                const uint32_t o = i < V ? f2ord(lp[i]) : 0u;
+                const bool act = i < V && (o & himask) == prefix;
+                const unsigned bin = (o >> shift) & 255u;
+                unsigned long long todo = __ballot(act);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const unsigned b = (unsigned)__shfl((int)bin, leader, 64);
+                    const unsigned long long same = __ballot(act && bin == b);
+                    if (lane == leader) atomicAdd(&hist[b], (unsigned)__popcll(same));
+                    todo &= ~same;
                 }
-                sel[0] = bin;
-                sel[1] = remaining - cum;
             }
             __syncthreads();
-            prefix |= ((uint32_t)sel[0]) << shift;
+            // The bin that holds the k-th largest: the highest bin b >= 1 with (elements in bins above b) + hist[b] >= remaining, else
+            // bin 0 -- what a scan from bin 255 downwards finds; here by a suffix sum over the 256 bins (4 waves) instead of 256
+            // dependent LDS reads on one thread.
+            unsigned h = 0, incl = 0, above = 0;
+            if (tid < 256) {
+                h = hist[tid];
+                incl = h;                                           // sum over this wave's bins >= this one
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned v = (unsigned)__shfl_down((int)incl, off, 64);
+                    if (lane + off < 64) incl += v;
+                }
+                if (lane == 0) redi[wave] = (int)incl;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                above = incl - h;
+                for (int w = wave + 1; w < 4; ++w) above += (unsigned)redi[w];
+                if (tid >= 1 && above + h >= (unsigned)remaining) atomicMax(&sel[0], tid);
+            }
+            __syncthreads();
+            const int bin_sel = sel[0];
+            if (tid == bin_sel) sel[1] = remaining - (int)above;
+            __syncthreads();
+            prefix |= ((uint32_t)bin_sel) << shift;
             remaining = sel[1];
             __syncthreads();
         }
@@ -530,14 +558,30 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
     float renorm = 1.0f;
     const bool use_p = a.top_p > 0.0f;
     if (use_p) {
-        for (int i = tid; i < n2; i += NT) {
-            skey[i] = i < V ? lp[i] : -1.0f;
-            sidx[i] = (unsigned short)i;
-        }
+        // Only entries with p > 0 can matter (zeros -- everything top-k masked -- sort last, add nothing to the prefix sums and stay zero
+        // whether kept or not), so they alone are compacted, sorted and scanned: with top_k = 2048 of V = 8192 the bitonic network
+        // shrinks from 91 passes x 8 elements per thread to 66 x 2 (1.1 ms -> see profiles/ per launch at 2048 rows).  Same results bit
+        // for bit: the network orders (probability desc, index asc) pairs, a total order that does not depend on where they start.
+        const int per = (V + NT - 1) / NT, lane_ = tid & 63, wave_ = tid >> 6;
+        int c_local = 0;
+        for (int c = 0; c < per; ++c) { const int j = tid * per + c; if (j < V && lp[j] > 0.0f) ++c_local; }
+        int incl = c_local;
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane_ >= off) incl += v; }
+        if (lane_ == 63) redi[wave_] = incl;
         __syncthreads();
-        for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+        int pos = incl - c_local, cnt = 0;
+        for (int w = 0; w < NT / 64; ++w) { const int t = redi[w]; if (w < wave_) pos += t; cnt += t; }
+        for (int c = 0; c < per; ++c) {
+            const int j = tid * per + c;
+            if (j < V && lp[j] > 0.0f) { skey[pos] = lp[j]; sidx[pos] = (unsigned short)j; ++pos; }
+        }
+        int n2e = 256;
+        while (n2e < cnt) n2e <<= 1;                                 // <= n2 (cnt <= V)
+        for (int i = cnt + tid; i < n2e; i += NT) { skey[i] = -1.0f; sidx[i] = (unsigned short)i; }
+        __syncthreads();
+        for (int k2 = 2; k2 <= n2e; k2 <<= 1) {
             for (int j = k2 >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < n2; i += NT) {
+                for (int i = tid; i < n2e; i += NT) {
                     const int ixj = i ^ j;
                     if (ixj > i) {
                         const float ka = skey[i], kb = skey[ixj];
@@ -550,9 +594,9 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
                 __syncthreads();
             }
         }
-        const int chunk = (n2 + NT - 1) / NT;
+        const int chunk = (n2e + NT - 1) / NT;
         double local = 0.0;
-        for (int c = 0; c < chunk; ++c) { const int j = tid * chunk + c; if (j < V) local += (double)skey[j]; }
+        for (int c = 0; c < chunk; ++c) { const int j = tid * chunk + c; if (j < cnt) local += (double)skey[j]; }
         dsum[tid] = local;
         __syncthreads();
         if (tid == 0) {
@@ -564,7 +608,7 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
         int first = V;                                   // first sorted position whose prefix >= p
         for (int c = 0; c < chunk; ++c) {
             const int j = tid * chunk + c;
-            if (j < V) {
+            if (j < cnt) {
                 run += (double)skey[j];
                 if ((float)run >= a.top_p && j < first) first = j;
             }
@@ -572,7 +616,7 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
         first = block_reduce(first, OpMin(), redi);
         for (int i = tid; i < V; i += NT) keep[i] = 0;
         __syncthreads();
-        for (int j = tid; j < V; j += NT)
+        for (int j = tid; j < cnt; j += NT)
             if (j <= first) keep[sidx[j]] = 1;           // position `first` itself is kept (shifted mask)
         __syncthreads();
         float ks = 0.0f;
