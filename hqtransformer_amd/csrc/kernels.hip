@@ -418,9 +418,117 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         d[0] = wall_clock64(); d[1] = stamp[1] - stamp[0]; d[2] = stamp[2] - stamp[0]; d[3] = stamp[3] - stamp[0]; d[4] = stamp[4] - stamp[0];
     }
 }
+// Few queries over a short shared cache (depth sub-step 1: 4 queries x <= 5 keys; sub-steps of the three-level head): one wave per
+// (sample, head) fetches the K / V rows ONCE and loops over the queries -- a quarter of the waves of the kernel above, whose cost at
+// these sizes is the wave count (49 k waves at 512 samples: 50 us per launch for a few kilobytes of arithmetic).  Per query the same
+// operations in the same order as attention_kernel with one group: bit-identical results.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void attention_fewq_kernel(AttnArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gid = blockIdx.x * 4 + wave;
+    if (gid >= a.B * a.n_heads) return;
+    const int h = gid % a.n_heads, b = gid / a.n_heads;
+    const int hs = a.head_dim, D = a.n_heads * hs;
+    const int chunks = hs >> 3, rows_per_pass = 64 / chunks;
+    const int c = lane % chunks, slot = lane / chunks;
+    const T* kc = reinterpret_cast<const T*>(a.kcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
+    const T* vc = reinterpret_cast<const T*>(a.vcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
+    const int tb = a.t_base + (a.t_base_dev ? *a.t_base_dev : 0);
+    const int nall = tb + a.Tq;                                       // keys any query of this call can see
+    const float scale = 1.0f / sqrtf((float)hs);
+    typedef typename std::conditional<sizeof(T) == 2, uint4, float4>::type raw_t;
+    constexpr int NRAW = sizeof(T) == 2 ? 1 : 2;
+    raw_t kbuf[NP][NRAW], vbuf[NP][NRAW];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const long long j = min(p * rows_per_pass + slot, nall - 1);
+        const raw_t* ks = reinterpret_cast<const raw_t*>(kc + j * D);
+        const raw_t* vs = reinterpret_cast<const raw_t*>(vc + j * D);
+#pragma unroll
+        for (int e = 0; e < NRAW; ++e) { kbuf[p][e] = ks[e]; vbuf[p][e] = vs[e]; }
+    }
+    auto unpack = [](const raw_t* r, float (&f)[8]) {
+        if (sizeof(T) == 2) {
+            const uint4 t = *reinterpret_cast<const uint4*>(r);
+            const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); f[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
+        } else {
+            const float4 a0 = *reinterpret_cast<const float4*>(r), a1 = *reinterpret_cast<const float4*>(r + 1);
+            f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
+        }
+    };
+    for (int qi = 0; qi < a.Tq; ++qi) {
+        const int nkeys = a.causal ? tb + qi + 1 : nall;
+        float qv[8];
+        ld8<T>(reinterpret_cast<const T*>(a.q) + ((long long)(b * a.Tq + qi)) * D + h * hs + c * 8, qv);
+        float sc[NP], gmax = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float kv[8];
+            unpack(kbuf[p], kv);
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kv[i] * scale, s);            // scale on K, as layers.py:102
+            for (int off = chunks >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            sc[p] = (p * rows_per_pass + slot < nkeys) ? s : -INFINITY;
+            gmax = fmaxf(gmax, sc[p]);
+        }
+        for (int off = chunks; off < 64; off <<= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+        const float new_max = fmaxf(-INFINITY, gmax);
+        const float rescale = expf(-INFINITY - new_max);                // 0: one group, as the first group of attention_kernel
+        float gsum = 0.0f, acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0f * rescale;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float e = expf(sc[p] - new_max);
+            gsum += e;
+            float vv[8];
+            unpack(vbuf[p], vv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(e, vv[i], acc[i]);
+        }
+        for (int off = chunks; off < 64; off <<= 1) gsum += __shfl_xor(gsum, off, 64);
+        const float run_sum = 0.0f * rescale + gsum;
+        for (int off = chunks; off < 64; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off, 64);
+        const float inv = 1.0f / run_sum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] *= inv;
+        if (slot == 0) {
+            const int row = b * a.Tq + qi, col = h * hs + c * 8;
+            T* o = a.out_packed_mb ? reinterpret_cast<T*>(a.out) + packed_off(row, col, a.out_packed_mb)
+                                   : reinterpret_cast<T*>(a.out) + (long long)row * D + col;
+            if (sizeof(T) == 2) {
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16(acc[4]) | ((unsigned)f32_to_bf16(acc[5]) << 16);
+                pk.w = (unsigned)f32_to_bf16(acc[6]) | ((unsigned)f32_to_bf16(acc[7]) << 16);
+                *reinterpret_cast<uint4*>(o) = pk;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st1<T>(o + i, acc[i]);
+            }
+        }
+    }
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
     const int chunks = a.head_dim / 8;
     if (a.head_dim % 8 != 0 || chunks > 64 || (chunks & (chunks - 1)) != 0) return hipErrorInvalidValue;
+    // few queries over a cache known on the host to fit one pass (depth sub-steps): one wave per (sample, head), see attention_fewq_kernel
+    if (a.Tq > 1 && a.Tq <= 16 && !a.t_base_dev && !a.dbg && a.t_base + a.Tq <= 2 * (64 / chunks)) {
+        static const bool off = getenv("HQT_NO_FEWQ_ATTN") != nullptr;          // A/B switch
+        if (!off) {
+            const int g2 = (a.B * a.n_heads + 3) / 4, one = a.t_base + a.Tq <= 64 / chunks;
+            if (a.dtype == DT_BF16) { if (one) attention_fewq_kernel<bf16_t, 1><<<g2, 256, 0, st>>>(a); else attention_fewq_kernel<bf16_t, 2><<<g2, 256, 0, st>>>(a); }
+            else { if (one) attention_fewq_kernel<float, 1><<<g2, 256, 0, st>>>(a); else attention_fewq_kernel<float, 2><<<g2, 256, 0, st>>>(a); }
+            return hipGetLastError();
+        }
+    }
     const int grid = (a.B * a.n_heads * a.Tq + 3) / 4;
     if (a.dtype == DT_BF16) attention_kernel<bf16_t><<<grid, 256, 0, st>>>(a);
     else attention_kernel<float><<<grid, 256, 0, st>>>(a);

@@ -118,6 +118,13 @@ int main() {
             printf("B=%3d keys=%2d (%.1f MB K+V): product %.2f us (%.2f TB/s) | copy %.2f | head-major %.2f us (%.2f TB/s) | head-major PB=4 %.2f\n",
                    B, keys, mb, t0, mb / t0 / 1e6 * 1e6 / 1e6 * 1e0, t1, t2, mb / t2, t3);
         }
+        {   // depth sub-step 1: 4 queries per sample over a 5-key cache (1 key cached by sub-step 0), causal
+            bf16_t *q4, *o4; CK(hipMalloc(&q4, (size_t)B * 4 * D * 2)); CK(hipMalloc(&o4, (size_t)B * 4 * D * 2)); CK(hipMemset(q4, 0, (size_t)B * 4 * D * 2));
+            AttnArgs at{q4, nullptr, nullptr, o4, B, 4, nh, hs, 5, 1, nullptr, 1, DT_BF16, 0, nullptr};
+            const float t0 = graph_time(st, 5, [&] { for (int l = 0; l < L; ++l) { AttnArgs a = at; a.kcache = kc[l]; a.vcache = vc[l]; CK(launch_attention(a, st)); } }) / L;
+            printf("B=%3d depth sub-step 1 (4 queries x <= 5 keys, %d waves): %.2f us\n", B, B * nh * 4, t0);
+            CK(hipFree(q4)); CK(hipFree(o4));
+        }
         for (int l = 0; l < L; ++l) { CK(hipFree(kc[l])); CK(hipFree(vc[l])); }
         CK(hipFree(q)); CK(hipFree(o));
     }
