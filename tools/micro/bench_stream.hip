@@ -35,18 +35,18 @@ static float run(const Shape& sh, int M, int S, const std::vector<bf16_t*>& wbuf
     return 1000.f * ms / (3 * iters);
 }
 
-template <int MBW, int NT, int NW, int U>
+template <int MBW, int NT, int NW, int U, bool PIPE = false>
 static void stamps(const Shape& sh, int M, int S, bf16_t* w, bf16_t* x, float* y, float* slabs, hipStream_t st) {
     const int MB = packed_mb(M);
     const size_t smem = stream_gemm_lds(MBW, NT, NW);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, float, 9>),
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, float, 9, PIPE>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     GemmArgs g{};
     g.A = x; g.a_packed_mb = MB; g.M = M; g.N = sh.N; g.K = sh.K; g.batch = 1; g.C = y; g.ldc = sh.N; g.alpha = 1.f; g.store = STORE_ROWS;
     const dim3 grid(sh.N / (32 * NT), MB / MBW, S);
     const int nwg = grid.x * grid.y * grid.z;
     for (int rep = 0; rep < 2; ++rep) {
-        stream_gemm_kernel<MBW, NT, NW, U, float, 9><<<grid, NW * 64, smem, st>>>(g, reinterpret_cast<const u32x4*>(w), slabs);
+        stream_gemm_kernel<MBW, NT, NW, U, float, 9, PIPE><<<grid, NW * 64, smem, st>>>(g, reinterpret_cast<const u32x4*>(w), slabs);
         CK(hipStreamSynchronize(st));
     }
     std::vector<long long> h((size_t)nwg * NW * 8);
@@ -80,6 +80,11 @@ int main() {
 #define V(MBW, NT, NW, U, S) { float t = run<MBW, NT, NW, U>(sh, M, S, w, x, y, slabs, st); if (t > 0) printf("   MBW=%d NT=%d NW=%d U=%2d S=%d : %7.2f us  (%.2f TB/s)\n", MBW, NT, NW, U, S, t, bytes / t / 1e6); }
             if (M == 64 && false) {} if (M == 64) { V(2, 1, 8, 12, 1) V(1, 1, 8, 12, 1) V(1, 1, 16, 12, 1) V(1, 1, 16, 6, 1) V(2, 1, 16, 6, 1) V(2, 1, 16, 4, 1) V(1, 1, 8, 6, 1) V(2, 1, 8, 4, 1) }
             if (M == 64 && false) { stamps<2, 1, 8, 12>(sh, M, 1, w[0], x, y, slabs, st); stamps<1, 1, 8, 12>(sh, M, 1, w[1], x, y, slabs, st); }
+            if (M == 512 || M == 2048) {
+                const float e0 = run<2, 2, 4, 4, 0, true>(sh, M, 1, w, x, y, slabs, st), e3 = run<2, 2, 4, 4, 3, true>(sh, M, 1, w, x, y, slabs, st);
+                printf("   <2,2,4,4> pipelined: full %.2f us, without the epilogue (ABL 3) %.2f us\n", e0, e3);
+            }
+            if (M == 512 || M == 2048) { stamps<2, 2, 4, 4, true>(sh, M, 1, w[0], x, y, slabs, st); stamps<2, 2, 8, 6, false>(sh, M, 1, w[1], x, y, slabs, st); }
 #define P(MBW, NT, NW, U, S) { float t = run<MBW, NT, NW, U, 0, true>(sh, M, S, w, x, y, slabs, st); if (t > 0) printf("   MBW=%d NT=%d NW=%d D=%2d S=%d pipelined : %7.2f us  (%.2f TB/s, %.0f TFLOP/s)\n", MBW, NT, NW, U, S, t, bytes / t / 1e6, 2.0 * M * sh.N * sh.K / t / 1e6); }
             if (M >= 256) { P(2, 2, 8, 4, 1) P(2, 2, 8, 3, 1) P(2, 2, 8, 6, 1) P(2, 2, 4, 4, 1) P(2, 2, 4, 6, 1) P(2, 3, 4, 4, 1) P(2, 3, 4, 6, 1) P(2, 1, 8, 6, 1) P(2, 1, 8, 4, 1) P(4, 2, 4, 3, 1) P(4, 2, 4, 4, 1) P(4, 1, 8, 4, 1) P(4, 1, 4, 6, 1) P(2, 3, 8, 4, 1) P(2, 2, 4, 4, 2) P(2, 2, 8, 4, 2) }
             if (M >= 512) { V(2, 2, 8, 6, 1) V(4, 2, 4, 3, 1) V(2, 1, 8, 6, 1) V(2, 1, 8, 12, 1) V(2, 2, 4, 6, 1) }
