@@ -124,8 +124,8 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     // Variants with registers to spare (MBW >= 2: one workgroup per CU anyway) fetch their share of the partial row
     // statistics together with the first run's operands and hold it across the MFMA loop; the others fetch it after
     // the loop, when the operand registers are dead.  Unconditional loads (a valid dummy row when there is no LayerNorm).
-    constexpr bool EARLY_STATS = MBW >= 2 && U >= 12 && !PIPE;
-    constexpr int NPE = 6;
+    constexpr bool EARLY_STATS = MBW >= 2 && (U >= 12 || PIPE);
+    constexpr int NPE = PIPE ? 12 : 6;                 // pipelined variants hold every partial of D <= 1536 (48 parts over 4 thread groups)
     float2 sv[NPE];
     bool sv_loaded = false;
     const float2* sbase = reinterpret_cast<const float2*>(g.ln_parts ? (const void*)g.ln_parts : g.A) + (blockIdx.y * ROWS + threadIdx.x % ROWS);
@@ -160,6 +160,32 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     int ks = 0;
     bool first = true;
     const unsigned polled = chain_poll(g.chain);
+    // ---- vector epilogue (the AR loop's store modes): a thread finishes 4 consecutive columns of one row.  Its bias, column sums and
+    //      residual row are fetched under the end of the K loop (pipelined variants) or under the reduction, never as dependent loads after it.
+    const bool xs = S > 1 && g.xs_ctr != nullptr;                    // in-kernel split-K: the last arriver of a tile finishes it
+    const bool vec_epi = (S == 1 || xs) && (ABL == 0 || ABL == 9) && g.N % 4 == 0 && g.ldc % 4 == 0 &&
+                         (g.store == STORE_RESID || g.store == STORE_PACKED || (g.store == STORE_QKV && g.qkv_D % (32 * NT) == 0) ||
+                          (g.store == STORE_ROWS && g.rows_per_group == 0 && !g.resid && g.batch <= 1));
+    constexpr int VGROUPS = TILE / 4;                                 // 4-column groups per workgroup
+    constexpr int VPT = (VGROUPS + NW * 64 - 1) / (NW * 64);          // groups per thread (1 for the instantiated variants)
+    f32x4 e_bias[VPT], e_cs[VPT], e_res[VPT];
+    bool epi_prefetched = false;
+    auto prefetch_epilogue = [&]() {
+        epi_prefetched = true;
+        if (!vec_epi) return;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int o4 = min((int)(threadIdx.x + j * NW * 64), VGROUPS - 1) * 4;
+            const int n = o4 & 31, ml = (o4 >> 5) & 31, blk = o4 >> 10;
+            const int mb = blk % MBW, t = blk / MBW;
+            const int m = min((mb0 + mb) * 32 + ml, g.M - 1);
+            const int ncol = (ntile0 + t) * 32 + n;
+            const float* zsrc = reinterpret_cast<const float*>(g.A);          // any valid 16 bytes: unconditional loads
+            e_bias[j] = *reinterpret_cast<const f32x4*>(g.bias ? g.bias + ncol : zsrc);
+            e_cs[j] = *reinterpret_cast<const f32x4*>(g.ln_parts ? g.ln_colsum + ncol : zsrc);
+            e_res[j] = *reinterpret_cast<const f32x4*>(g.store == STORE_RESID ? reinterpret_cast<const float*>(g.C) + (size_t)m * g.ldc + ncol : zsrc);
+        }
+    };
     // Two copies of the run loop: weights fetched with the non-temporal hint (streamed once: the body's 340 MB per position) or as
     // ordinary loads (re-read soon: the depth blocks run twice per position, and steps in flight on other lanes re-read what
     // this one just pulled through the 256 MB Infinity Cache).  GemmArgs.w_nt picks; a runtime select per load would put the
@@ -232,6 +258,11 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     chain_wait(g.chain, polled);                      // weights are in flight; the activations depend on the predecessor
 #pragma unroll
     for (int u = 0; u < U; ++u) fetch_x(u, u);
+    if (EARLY_STATS) {                                // the partial row statistics travel with the first operands (consumed after the loop)
+        sv_loaded = true;
+#pragma unroll
+        for (int i = 0; i < NPE; ++i) sv[i] = sbase[(size_t)min((int)(threadIdx.x / ROWS) + i * PGROUPS, snp - 1) * (g.a_packed_mb * 32)];
+    }
     first = false;
     __builtin_amdgcn_sched_barrier(0);
     for (; ks + 2 * U <= cnt; ks += U) {
@@ -243,6 +274,8 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    prefetch_epilogue();                              // bias / column sums / residual rows: in flight under the last U k-steps and the reduction
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u) { multiply(u); __builtin_amdgcn_sched_barrier(0); }
     ks += U;
@@ -286,29 +319,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
             ln_partial_stats<ROWS, PGROUPS>(g, ln_s, ln_q);
         }
     }
-    // ---- vector epilogue (the AR loop's store modes): a thread finishes 4 consecutive columns of one row.  Its bias,
-    //      column sums and residual row are fetched here, under the reduction, instead of as dependent loads afterwards.
-    const bool xs = S > 1 && g.xs_ctr != nullptr;                    // in-kernel split-K: the last arriver of a tile finishes it
-    const bool vec_epi = (S == 1 || xs) && (ABL == 0 || ABL == 9) && g.N % 4 == 0 && g.ldc % 4 == 0 &&
-                         (g.store == STORE_RESID || g.store == STORE_PACKED || (g.store == STORE_QKV && g.qkv_D % (32 * NT) == 0) ||
-                          (g.store == STORE_ROWS && g.rows_per_group == 0 && !g.resid && g.batch <= 1));
-    constexpr int VGROUPS = TILE / 4;                                 // 4-column groups per workgroup
-    constexpr int VPT = (VGROUPS + NW * 64 - 1) / (NW * 64);          // groups per thread (1 for the instantiated variants)
-    f32x4 e_bias[VPT], e_cs[VPT], e_res[VPT];
-    if (vec_epi) {
-#pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            const int o4 = min((int)(threadIdx.x + j * NW * 64), VGROUPS - 1) * 4;
-            const int n = o4 & 31, ml = (o4 >> 5) & 31, blk = o4 >> 10;
-            const int mb = blk % MBW, t = blk / MBW;
-            const int m = min((mb0 + mb) * 32 + ml, g.M - 1);
-            const int ncol = (ntile0 + t) * 32 + n;
-            const float* zsrc = reinterpret_cast<const float*>(g.A);          // any valid 16 bytes: unconditional loads
-            e_bias[j] = *reinterpret_cast<const f32x4*>(g.bias ? g.bias + ncol : zsrc);
-            e_cs[j] = *reinterpret_cast<const f32x4*>(g.ln_parts ? g.ln_colsum + ncol : zsrc);
-            e_res[j] = *reinterpret_cast<const f32x4*>(g.store == STORE_RESID ? reinterpret_cast<const float*>(g.C) + (size_t)m * g.ldc + ncol : zsrc);
-        }
-    }
+    if (!epi_prefetched) prefetch_epilogue();
     // ---- cross-wave reduction through LDS; C/D map: col = lane & 31 -> m, row = (r&3) + 8 (r>>2) + 4 (lane>>5) -> n
     {
         float* my = red + (size_t)wave * TILE_P;
