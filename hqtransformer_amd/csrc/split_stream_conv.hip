@@ -1002,6 +1002,8 @@ bool split_stream_ok(const GemmArgs& g) {
     static const bool off = getenv("HQT_SPLIT_STREAM") && atoi(getenv("HQT_SPLIT_STREAM")) == 0;      // A/B switch
     if (off || !g.Bw_frag) return false;
     if (g.H % R_TY != 0 || g.W % R_TX != 0 || g.Cin % 64 != 0) return false;      // an even number of 32-channel chunks (static k-tile parity)
+    // the ring kernels address one image's operand planes with 32-bit byte offsets below 2^31 (buffer loads; 2^31 marks the padding ring)
+    if ((long long)(g.H >> g.upsample) * (g.W >> g.upsample) * g.Cin * 4 >= (1ll << 31)) return false;
     if (g.store == STORE_NCHW) return g.N <= 32;
     return g.N % 128 == 0 && g.ldc % 8 == 0;              // whole 128-channel tiles (the packed fragments hold ceil(N / 32) n-tiles)
 }
