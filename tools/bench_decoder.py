@@ -4,7 +4,7 @@ config (its FFHQ model is 256 x 256), so SURVEY.md 8(d) defines one with the ref
 Decoder(resolution=1024, ch=128, ch_mult=[1, 2, 4, 4, 4], num_res_blocks=2, attn_resolutions=[32], use_init_downsample=True,
 z_channels=256) fed by random code grids top [B, 16, 16] / bottom [B, 32, 32]: 2.80 TFLOP per image.  GPU box only.
 
-    python tools/bench_decoder.py [--batch 8] [--iters 3] [--precision fast|exact]
+    python tools/bench_decoder.py [--batch 8] [--iters 3] [--precision split|fast|exact]
 """
 import argparse
 import json
@@ -17,7 +17,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hqtransformer_amd import synth  # noqa: E402
-from hqtransformer_amd._lib import PRECISION_EXACT, PRECISION_FAST  # noqa: E402
+from hqtransformer_amd._lib import PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT  # noqa: E402
 from hqtransformer_amd.engine import Engine  # noqa: E402
 from hqtransformer_amd.spec import Stage1Spec, decoder_plan  # noqa: E402
 
@@ -52,7 +52,7 @@ def main():
     eng = Engine(None, s1, dev, a.batch)
     eng.load(stage1=synth.stage1_weights(s1, 1, 'bench'))
     eng.finalize()
-    prec = PRECISION_FAST if a.precision == 'fast' else PRECISION_EXACT
+    prec = {'fast': PRECISION_FAST, 'split': PRECISION_SPLIT}.get(a.precision, PRECISION_EXACT)
     r = np.random.default_rng(0)
     ct = torch.from_numpy(r.integers(0, s1.n_embed, (a.batch, s1.z_res // 2, s1.z_res // 2))).to(dev)
     cb = torch.from_numpy(r.integers(0, s1.n_embed, (a.batch, s1.z_res, s1.z_res))).to(dev)
