@@ -590,7 +590,7 @@ static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int k
     if (taps == 9 && I % 32 == 0) {              // fragment-packed copy for the streaming SPLIT kernel
         CHK(dev_alloc(h, (void**)&l.wfrag, split_frag_elems(O, I) * sizeof(half_t), false));
         HIPCHK(launch_pack_split_frag(wt, l.wfrag, O, I, 0));
-        if (O % 128 == 0) {
+        if (O % 128 == 0 || O <= 16) {           // 16-channel-block packing: the ring16 kernel (whole 128-channel tiles) and conv_out
             CHK(dev_alloc(h, (void**)&l.wfrag16, split_frag_elems(O, I) * sizeof(half_t), false));
             HIPCHK(launch_pack_split_frag16(wt, l.wfrag16, O, I, 0));
         }

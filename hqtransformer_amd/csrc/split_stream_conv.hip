@@ -998,6 +998,156 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring16_kernel(GemmArgs g
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// conv_out (C_in -> 3 channels, NCHW fp32 + clamp) on the ring16 structure: the output channels are padded to ONE 16-channel MFMA block
+// (32 in the stream kernel's variant: 10x the matrix work the 3 channels need, 36 % pipe utilisation), so the four waves of a tile split
+// its PIXELS: wave w owns tile rows 2 w and 2 w + 1 (2 pixel blocks x 1 channel block: 6 MFMAs per tap) and all of them fetch the same
+// filter fragments (L1 hits).  Patch image, piece schedule and waits as in conv3x3_split_ring16_kernel; the fragments of the next tap are
+// read one tap ahead (4 register slots: tap parity x pixel block).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3x3_split_out16_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fx = lane & 15, fk = lane >> 4;
+    const int tile_m = blockIdx.y;
+    const int tiles_x = g.W / R_TX, tiles_y = g.H / R_TY;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * R_TY, tx0 = (trem % tiles_x) * R_TX;
+    const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
+    const half_t* Abase = reinterpret_cast<const half_t*>(g.A);
+    const int NC = g.Cin / 32;
+
+    constexpr int PPW = 2 * R_PIECES / 4;
+    typedef int rsrc_t __attribute__((ext_vector_type(4)));
+    rsrc_t img_rsrc;
+    {
+        const unsigned long long ib = (unsigned long long)(size_t)(Abase + (long long)img * Hin * Win * (2 * g.Cin));
+        img_rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ib);
+        img_rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ib >> 32) & 0xffff);
+        img_rsrc[2] = __builtin_amdgcn_readfirstlane(Hin * Win * 2 * g.Cin * 2);
+        img_rsrc[3] = 0x00020000;
+    }
+    unsigned poff[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int piece = wave + 4 * u;
+        const int q = piece * 16 + (lane >> 2);
+        const int qy = (q * 3641) >> 16, qx = q - qy * R_PITCH;
+        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+        const bool in = (q < R_ROWS) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+        const unsigned off = (unsigned)((((iy >> g.upsample) * Win + (ix >> g.upsample)) * (2 * g.Cin) + (lane & 3) * 8) * 2);
+        poff[u] = in ? off : 0x80000000u;
+    }
+    u32x4 pst[2];
+    unsigned piece_base = lds_base + wave * (16 * G_PITCH) + (lane >> 2) * G_PITCH + (lane & 3) * 16;
+    auto load_piece = [&](int c, int u, int r) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pst[r]) : "v"(poff[u % 3]), "s"(img_rsrc), "s"(c * 64 + (u / 3) * g.Cin * 2));
+    };
+#define HQT_STORE_PIECE(buf, u, r)                                                                                             \
+    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(piece_base), "v"(pst[r]),                                            \
+                 "n"(((buf) * 2 + (u) / 3) * G_PLANE + 4 * ((u) % 3) * 16 * G_PITCH) : "memory")
+
+    // one filter stream for the whole tile: 4 KiB per tap in the 16-channel-block packing, block 0 only ([hi][lo])
+    const char* bfrag = reinterpret_cast<const char*>(g.Bw_frag16);
+    unsigned lane16 = lane * 16;
+
+    f32x4 accm[2], accx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { accm[i][r] = 0.0f; accx[i][r] = 0.0f; }
+    // this wave's pixel blocks = tile rows 2 wave, 2 wave + 1
+    const unsigned abase = lds_base + (2 * wave * R_PITCH + fx) * G_PITCH + fk * 16;
+    half8 ah[4], al[4];                                             // [tap parity * 2 + block]
+    half8 wh[H_RING], wl[H_RING];
+#define HQT_READ_A16(ps, tapoff, i, slot)                                                                                      \
+    do {                                                                                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[slot]) : "v"(abase), "n"((ps) * 2 * G_PLANE + ((i) * R_PITCH + (tapoff)) * G_PITCH));            \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[slot]) : "v"(abase), "n"((ps) * 2 * G_PLANE + ((i) * R_PITCH + (tapoff)) * G_PITCH + G_PLANE));  \
+    } while (0)
+    auto load_b = [&](long long S, int slot) {
+        const char* p = bfrag + S * 4096;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wh[slot]) : "v"(lane16), "s"(p));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(wl[slot]) : "v"(lane16), "s"(p));
+    };
+    // loads issued after the filters of body step s (2 loads, fetched during step s - 2) and before step s begins
+#define HQT_YOUNGER(s) (2 * (H_AHEAD - 1) + (h_piece_at((s) - 2) ? 1 : 0) + (h_piece_at((s) - 1) ? 1 : 0))
+
+#pragma unroll
+    for (int rnd = 0; rnd < 3; ++rnd) {
+        load_piece(0, 2 * rnd, 0); load_piece(0, 2 * rnd + 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pst[0]), "+v"(pst[1]));
+        if (rnd == 0) { HQT_STORE_PIECE(0, 0, 0); HQT_STORE_PIECE(0, 1, 1); }
+        else if (rnd == 1) { HQT_STORE_PIECE(0, 2, 0); HQT_STORE_PIECE(0, 3, 1); }
+        else { HQT_STORE_PIECE(0, 4, 0); HQT_STORE_PIECE(0, 5, 1); }
+    }
+#pragma unroll
+    for (int s = 0; s < H_AHEAD; ++s) load_b(s, s);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+#pragma unroll 1
+    for (int c0 = 0; c0 < NC; c0 += 2) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = c0 + cc, cn = min(c + 1, NC - 1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            HQT_READ_A16(cc, 0, 0, 0); HQT_READ_A16(cc, 0, 1, 1);       // tap 0 -> parity 0
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int s = cc * 9 + tap, slot = s % H_RING, nslot = (s + H_AHEAD) % H_RING;
+                const long long S = (long long)c0 * 9 + s;
+                const int par = tap & 1;
+                const int ntapoff = ((tap + 1) / 3) * R_PITCH + (tap + 1) % 3;
+                // the next tap's fragments first (read one tap ahead into the other parity's slots), then this tap's MFMAs
+                if (tap < 8) {
+                    if (par == 0) { HQT_READ_A16(cc, ntapoff, 0, 2); HQT_READ_A16(cc, ntapoff, 1, 3); }
+                    else { HQT_READ_A16(cc, ntapoff, 0, 0); HQT_READ_A16(cc, ntapoff, 1, 1); }
+                }
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wh[slot]), "+v"(wl[slot]) : "n"(HQT_YOUNGER(s)));
+                if (tap < 8) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[2 * par]), "+v"(al[2 * par]), "+v"(ah[2 * par + 1]), "+v"(al[2 * par + 1]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[2 * par]), "+v"(al[2 * par]), "+v"(ah[2 * par + 1]), "+v"(al[2 * par + 1]));
+                accm[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot], ah[2 * par], accm[0], 0, 0, 0);
+                accm[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot], ah[2 * par + 1], accm[1], 0, 0, 0);
+                accx[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot], al[2 * par], accx[0], 0, 0, 0);
+                accx[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot], al[2 * par + 1], accx[1], 0, 0, 0);
+                accx[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot], ah[2 * par], accx[0], 0, 0, 0);
+                accx[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot], ah[2 * par + 1], accx[1], 0, 0, 0);
+                load_b(S + H_AHEAD, nslot);
+                if (tap >= 2 && tap - 2 < PPW) {
+                    if (tap - 1 < PPW) asm volatile("s_waitcnt vmcnt(5)" : "+v"(pst[tap % 2]));     // behind the piece: filters of tap + 1 (2), piece of tap - 1, filters of tap + 2 (2)
+                    else asm volatile("s_waitcnt vmcnt(4)" : "+v"(pst[tap % 2]));
+                    HQT_STORE_PIECE(cc ^ 1, tap - 2, tap % 2);
+                }
+                if (tap < PPW) load_piece(cn, tap, tap % 2);
+            }
+        }
+    }
+#undef HQT_READ_A16
+#undef HQT_STORE_PIECE
+#undef HQT_YOUNGER
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // ---- epilogue: D col = lane & 15 -> pixel fx of tile row 2 wave + i; row = 4 fk + r -> channel (< N <= 16)
+    float* Cb = reinterpret_cast<float*>(g.C);
+    const long long hw = (long long)g.H * g.W;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long pix = (long long)(ty0 + 2 * wave + i) * g.W + tx0 + fx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 4 * fk + r;
+            if (n >= g.N) continue;
+            float v = (accm[i][r] + accx[i][r] * R_INV) * g.alpha + (g.bias ? g.bias[n] : 0.0f);
+            if (g.clamp01) v = fminf(fmaxf(0.5f * v + 0.5f, 0.0f), 1.0f);
+            Cb[((long long)img * g.N + n) * hw + pix] = v;
+        }
+    }
+}
+
 bool split_stream_ok(const GemmArgs& g) {
     static const bool off = getenv("HQT_SPLIT_STREAM") && atoi(getenv("HQT_SPLIT_STREAM")) == 0;      // A/B switch
     if (off || !g.Bw_frag) return false;
@@ -1009,7 +1159,11 @@ bool split_stream_ok(const GemmArgs& g) {
 }
 int split_stream_tiles_per_image(const GemmArgs& g) { return (g.H / R_TY) * (g.W / R_TX); }
 hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st) {
-    if (g.store == STORE_NCHW) conv3x3_split_stream_kernel<true, 32><<<dim3(1, g.M / (R_TY * R_TX), 1), 256, R_LDS, st>>>(g);
+    if (g.store == STORE_NCHW) {
+        static const bool out16 = !(getenv("HQT_SPLIT_OUT16") && atoi(getenv("HQT_SPLIT_OUT16")) == 0);     // A/B switch: 0 = the 32-channel stream variant
+        if (out16 && g.Bw_frag16 && g.N <= 16) conv3x3_split_out16_kernel<<<dim3(1, g.M / (R_TY * R_TX), 1), 256, G_LDS, st>>>(g);
+        else conv3x3_split_stream_kernel<true, 32><<<dim3(1, g.M / (R_TY * R_TX), 1), 256, R_LDS, st>>>(g);
+    }
     else {
         static const bool ring = !(getenv("HQT_SPLIT_RING") && atoi(getenv("HQT_SPLIT_RING")) == 0);     // A/B switch: 0 = the stream kernel
         const dim3 grid((g.N + 127) / 128, g.M / (R_TY * R_TX), 1);
@@ -1026,6 +1180,8 @@ hipError_t split_stream_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_ring_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_ring16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_out16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_stream_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
 }
