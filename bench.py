@@ -403,7 +403,7 @@ def main():
             ach = cflops / (conv_ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if dec_prec != 'exact' else F32_PEAK_TFLOPS
             mfma_per_flop = 3 if dec_prec == 'split' else 1           # SPLIT issues three fp16 MFMAs per product term
-            kname = {'split': 'conv3x3_split_ring16_kernel (+ conv3x3_split_stream_kernel<32> for conv_out, split_gemm_kernel for the 1x1 convs and the attention GEMMs): '
+            kname = {'split': 'conv3x3_split_ring16_kernel (+ conv3x3_split_out16_kernel for conv_out, split_gemm_kernel for the 1x1 convs and the attention GEMMs): '
                               'HQ-VAE decoder conv family, fp16 hi/lo split operands',
                      'fast': 'conv3x3_halo_kernel (+ conv_glds_kernel for 1x1): HQ-VAE decoder conv family, bf16',
                      'exact': 'gemm_tile_kernel: HQ-VAE decoder conv family, fp32 vector ALUs'}[dec_prec]

@@ -10,7 +10,7 @@ import re
 import sys
 
 FAMILIES = {'stream_gemm': ('stream_gemm_kernel',),
-            'decoder_conv': ('conv3x3_split_ring16_kernel', 'conv3x3_split_ring_kernel', 'conv3x3_split_stream_kernel', 'split_gemm_kernel'),       # SPLIT (the default decode)
+            'decoder_conv': ('conv3x3_split_ring16_kernel', 'conv3x3_split_out16_kernel', 'conv3x3_split_ring_kernel', 'conv3x3_split_stream_kernel', 'split_gemm_kernel'),       # SPLIT (the default decode)
             'decoder_conv_fast': ('conv3x3_halo_kernel', 'conv_glds_kernel')}
 
 
