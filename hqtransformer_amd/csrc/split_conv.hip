@@ -894,19 +894,26 @@ __global__ __launch_bounds__(256, 1) void split_gemm_kernel(GemmArgs g, int a_lo
         aoff[i] = (m0 + row < g.M) ? (long long)(m0 + row) * g.lda + ch : -1;
         boff[i] = (n0 + row < g.N) ? (long long)(n0 + row) * g.ldb + ch : -1;
     }
-    auto issue = [&](int kt, int buf) {
+    // Staging goes through registers (global_load_dwordx4, then ds_write_b128 after the k-tile's MFMAs): the 16 LDS-DMA pieces a wave
+    // issued per k-tile cost it 150-300 cycles EACH next to MFMAs (2x the k-tile's matrix time; split_stream_conv.hip), while a whole
+    // k-tile of ordinary loads stays in flight for free in the 512 registers a one-wave-per-SIMD kernel has.
+    u32x4 stg[4][4];
+    auto fetch = [&](int kt) {
         const int k0 = kt * BKG;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const half_t* s[4] = {aoff[i] >= 0 ? Abase + aoff[i] + k0 : zero, aoff[i] >= 0 ? Abase + aoff[i] + a_lo_off + k0 : zero,
                                   boff[i] >= 0 ? Bhi + boff[i] + k0 : zero, boff[i] >= 0 ? Blo + boff[i] + k0 : zero};
 #pragma unroll
-            for (int op = 0; op < 4; ++op) {
-                char* dst = LDS(buf, op) + (wave * 4 + i) * 8 * ROWB;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s[op],
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
+            for (int op = 0; op < 4; ++op) stg[i][op] = *reinterpret_cast<const u32x4*>(s[op]);
         }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int op = 0; op < 4; ++op)
+                *reinterpret_cast<u32x4*>(LDS(buf, op) + (wave * 4 + i) * 8 * ROWB + lane * 16) = stg[i][op];
     };
     f32x16 accm[2][2], accx[2][2];
 #pragma unroll
@@ -947,12 +954,14 @@ __global__ __launch_bounds__(256, 1) void split_gemm_kernel(GemmArgs g, int a_lo
                 }
         }
     };
-    issue(0, 0);
-    __syncthreads();                                   // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    fetch(0);
+    stash(0);
+    __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) issue(kt + 1, buf ^ 1);
+        if (kt + 1 < KT) fetch(kt + 1);                // in flight under this k-tile's MFMAs
         compute(buf);
+        if (kt + 1 < KT) stash(buf ^ 1);               // the other stage: its readers passed the barrier below one k-tile ago
         __syncthreads();
     }
     // epilogue: a lane owns 4 consecutive columns of one row per register quad
