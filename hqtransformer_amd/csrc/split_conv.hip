@@ -868,13 +868,14 @@ hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1x1 convolutions / plain GEMMs: C[m][n] = alpha sum_k A[m][k] W[n][k] (+bias) (+resid), 128 x 128 x 64 tiles, both
-// operands (two planes each) staged by LDS-DMA into two LDS stages (128 KiB, one workgroup per CU), 4 waves x (64 x 64).
+// 1x1 convolutions / plain GEMMs: C[m][n] = alpha sum_k A[m][k] W[n][k] (+bias) (+resid), 128 x 128 x 32 tiles, both
+// operands (two planes each) staged through registers into two LDS stages (64 KiB, two workgroups per CU: with K = 256 .. 512
+// a workgroup is mostly prologue and epilogue, which the second one covers), 4 waves x (64 x 64).
 // A rows are [m][hi K | lo K] (lda elements per row, lo at +a_lo_off); same source-side bank swizzle as conv_glds_kernel.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void split_gemm_kernel(GemmArgs g, int a_lo_off) {
-    constexpr int BM = 128, BN = 128, BKG = 64, ROWB = 128, OPB = 128 * ROWB;       // bytes per operand plane and stage
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];                   // [2 stages][A hi, A lo, B hi, B lo][128 * 128 B]
+__global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo_off) {
+    constexpr int BM = 128, BN = 128, BKG = 32, ROWB = 64, OPB = 128 * ROWB;        // 32-wide k-tiles: 64 KiB of LDS, two workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];                   // [2 stages][A hi, A lo, B hi, B lo][128 rows of 64 B]
     auto LDS = [&](int stage, int op) -> char* { return lds_raw + (size_t)(stage * 4 + op) * OPB; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -886,22 +887,24 @@ __global__ __launch_bounds__(256, 1) void split_gemm_kernel(GemmArgs g, int a_lo
     const half_t* Bhi = reinterpret_cast<const half_t*>(g.Bw) + (long long)bz * g.b_batch_stride;
     const half_t* Blo = reinterpret_cast<const half_t*>(g.Bw_lo) + (long long)bz * g.b_batch_stride;
     const half_t* zero = reinterpret_cast<const half_t*>(g.zero_page);
-    long long aoff[4], boff[4];
+    // a 1-KiB piece = 16 rows x 4 chunks of 16 B; chunk c of row r lives at position c ^ ((r >> 2) & 3): the 16 rows a ds_read_b128
+    // lane group covers (lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) then fall on 16 different 16-B slots of the 256-B LDS row
+    long long aoff[2], boff[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        const int ch = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
         aoff[i] = (m0 + row < g.M) ? (long long)(m0 + row) * g.lda + ch : -1;
         boff[i] = (n0 + row < g.N) ? (long long)(n0 + row) * g.ldb + ch : -1;
     }
     // Staging goes through registers (global_load_dwordx4, then ds_write_b128 after the k-tile's MFMAs): the 16 LDS-DMA pieces a wave
     // issued per k-tile cost it 150-300 cycles EACH next to MFMAs (2x the k-tile's matrix time; split_stream_conv.hip), while a whole
     // k-tile of ordinary loads stays in flight for free in the 512 registers a one-wave-per-SIMD kernel has.
-    u32x4 stg[4][4];
+    u32x4 stg[2][4];
     auto fetch = [&](int kt) {
         const int k0 = kt * BKG;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const half_t* s[4] = {aoff[i] >= 0 ? Abase + aoff[i] + k0 : zero, aoff[i] >= 0 ? Abase + aoff[i] + a_lo_off + k0 : zero,
                                   boff[i] >= 0 ? Bhi + boff[i] + k0 : zero, boff[i] >= 0 ? Blo + boff[i] + k0 : zero};
 #pragma unroll
@@ -910,10 +913,10 @@ __global__ __launch_bounds__(256, 1) void split_gemm_kernel(GemmArgs g, int a_lo
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int op = 0; op < 4; ++op)
-                *reinterpret_cast<u32x4*>(LDS(buf, op) + (wave * 4 + i) * 8 * ROWB + lane * 16) = stg[i][op];
+                *reinterpret_cast<u32x4*>(LDS(buf, op) + (wave * 2 + i) * 16 * ROWB + lane * 16) = stg[i][op];
     };
     f32x16 accm[2][2], accx[2][2];
 #pragma unroll
@@ -927,20 +930,20 @@ __global__ __launch_bounds__(256, 1) void split_gemm_kernel(GemmArgs g, int a_lo
     auto compute = [&](int buf) {
         const char *Ah = LDS(buf, 0), *Al = LDS(buf, 1), *Wh = LDS(buf, 2), *Wl = LDS(buf, 3);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 2 + fh;
             half8 ah[2], al[2], wh[2], wl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = wm * 64 + i * 32 + fr;
-                const int o = r * ROWB + ((c ^ ((r >> 1) & 7)) << 4);
+                const int o = r * ROWB + ((c ^ ((r >> 2) & 3)) << 4);
                 ah[i] = *reinterpret_cast<const half8*>(Ah + o);
                 al[i] = *reinterpret_cast<const half8*>(Al + o);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = wn * 64 + j * 32 + fr;
-                const int o = r * ROWB + ((c ^ ((r >> 1) & 7)) << 4);
+                const int o = r * ROWB + ((c ^ ((r >> 2) & 3)) << 4);
                 wh[j] = *reinterpret_cast<const half8*>(Wh + o);
                 wl[j] = *reinterpret_cast<const half8*>(Wl + o);
             }
@@ -1030,7 +1033,7 @@ hipError_t launch_split_gemm(const GemmArgs& g0, hipStream_t st) {
     if (g.conv_taps == 1) { g.lda = 2 * g.Cin; g.conv_taps = 0; }        // a 1x1 conv over [pixel][hi C | lo C] is a plain GEMM with lda = 2 C
     const int a_lo_off = g.lda / 2;
     const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
-    split_gemm_kernel<<<grid, 256, 2 * 4 * 128 * 128, st>>>(g, a_lo_off);
+    split_gemm_kernel<<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
     return hipGetLastError();
 }
 
@@ -1049,5 +1052,5 @@ hipError_t split_kernels_configure() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<true, 32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(32));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 128);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
 }
