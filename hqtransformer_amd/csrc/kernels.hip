@@ -595,47 +595,34 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
     if (a.top_k > 0 && a.top_k < V) {
         uint32_t prefix = 0;
         int remaining = a.top_k;
-        const int lane = tid & 63, wave = tid >> 6;
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
-            if (tid == 0) sel[0] = 0;
             __syncthreads();
             const uint32_t himask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
-            // Histogram of the current byte.  Logits share their leading bytes, so most of a wave hits ONE bin: a plain atomicAdd per
-            // element serialises on that LDS address (1.1 ms per launch at 2048 rows, V = 8192).  Each wave therefore counts its own
-            // elements per distinct bin with ballots and issues one atomic per (wave, bin).
-            for (int i0 = 0; i0 < V; i0 += NT) {
-                const int i = i0 + tid;
-                const uint32_t o = i < V ? f2ord(lp[i]) : 0u;
-                const bool act = i < V && (o & himask) == prefix;
-                const unsigned bin = (o >> shift) & 255u;
-                unsigned long long todo = __ballot(act);
-                while (todo) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const unsigned b = (unsigned)__shfl((int)bin, leader, 64);
-                    const unsigned long long same = __ballot(act && bin == b);
-                    if (lane == leader) atomicAdd(&hist[b], (unsigned)__popcll(same));
-                    todo &= ~same;
-                }
+            for (int i = tid; i < V; i += NT) {
+                const uint32_t o = f2ord(lp[i]);
+                if ((o & himask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
             }
             __syncthreads();
-            // The bin that holds the k-th largest: the highest bin b >= 1 with (elements in bins above b) + hist[b] >= remaining, else
-            // bin 0 -- what a scan from bin 255 downwards finds; here by a suffix sum over the 256 bins (4 waves) instead of 256
-            // dependent LDS reads on one thread.
+            // the bin that holds the k-th largest = the highest bin b >= 1 with (elements in bins above b) + hist[b] >= remaining, else
+            // bin 0 (what a scan from bin 255 downwards finds): suffix sums over the 256 bins by 4 waves instead of 256 dependent LDS
+            // reads on one thread
+            if (tid == 0) sel[0] = 0;
             unsigned h = 0, incl = 0, above = 0;
+            const int lane_k = tid & 63, wave_k = tid >> 6;
             if (tid < 256) {
                 h = hist[tid];
-                incl = h;                                           // sum over this wave's bins >= this one
+                incl = h;
                 for (int off = 1; off < 64; off <<= 1) {
                     const unsigned v = (unsigned)__shfl_down((int)incl, off, 64);
-                    if (lane + off < 64) incl += v;
+                    if (lane_k + off < 64) incl += v;
                 }
-                if (lane == 0) redi[wave] = (int)incl;
+                if (lane_k == 0) redi[wave_k] = (int)incl;
             }
             __syncthreads();
             if (tid < 256) {
                 above = incl - h;
-                for (int w = wave + 1; w < 4; ++w) above += (unsigned)redi[w];
+                for (int w = wave_k + 1; w < 4; ++w) above += (unsigned)redi[w];
                 if (tid >= 1 && above + h >= (unsigned)remaining) atomicMax(&sel[0], tid);
             }
             __syncthreads();
