@@ -561,7 +561,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // NT threads per logits row: 1024 (16 waves, 4 per SIMD) hides the latency of the exp / log / divide / Philox chains that a
 // lone 4-wave workgroup per CU exposes (25 -> ~10 us per launch at V = 8192); 256 for small vocabularies.
 template <int NT>
-__global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
+__global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {   // 8 waves per SIMD = two 1024-thread rows per CU: the plain path is 30 % slower at 7 (tools/micro/bench_sampler)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // layout: double dsum[NT]; float redf[16]; int redi[16]; unsigned hist[256]; int sel[4]; float lp[V];
     //         (top-p only) float skey[n2]; unsigned short sidx[n2]; unsigned char keep[V]
@@ -692,14 +692,15 @@ __global__ __launch_bounds__(NT) void sampler_kernel(SamplerArgs a, int n2) {
         const int chunk = (n2e + NT - 1) / NT;
         double local = 0.0;
         for (int c = 0; c < chunk; ++c) { const int j = tid * chunk + c; if (j < cnt) local += (double)skey[j]; }
-        dsum[tid] = local;
+        // exclusive prefix of the per-thread sums: shuffle scan inside each wave, then the totals of the waves in front (a 1024-step
+        // serial loop on one thread before: ~9 us per row).  Everything is accumulated in double, as torch.cumsum does for an fp32 row;
+        // the association differs from a strictly sequential sum only below 2^-53 relative.
+        double scan = local;
+        for (int off = 1; off < 64; off <<= 1) { const double v = __shfl_up(scan, off, 64); if (lane_ >= off) scan += v; }
+        if (lane_ == 63) dsum[wave_] = scan;
         __syncthreads();
-        if (tid == 0) {
-            double run = 0.0;
-            for (int t = 0; t < NT; ++t) { const double v = dsum[t]; dsum[t] = run; run += v; }
-        }
-        __syncthreads();
-        double run = dsum[tid];
+        double run = scan - local;
+        for (int w = 0; w < wave_; ++w) run += dsum[w];
         int first = V;                                   // first sorted position whose prefix >= p
         for (int c = 0; c < chunk; ++c) {
             const int j = tid * chunk + c;
