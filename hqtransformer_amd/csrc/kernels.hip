@@ -674,7 +674,61 @@ __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {
         while (n2e < cnt) n2e <<= 1;                                 // <= n2 (cnt <= V)
         for (int i = cnt + tid; i < n2e; i += NT) { skey[i] = -1.0f; sidx[i] = (unsigned short)i; }
         __syncthreads();
-        for (int k2 = 2; k2 <= n2e; k2 <<= 1) {
+        // The bitonic network with the elements in registers: element e of thread t is position e NT + t, so a partner at distance
+        // j >= NT is another register of the same thread, at j < 64 a lane of the same wave (one shuffle each for key and index), and
+        // only 64 <= j < NT goes through LDS with barriers: 14 of the 66 steps at 2048 entries on 1024 threads.
+        constexpr int EMAX = 2;
+        const int E = n2e > NT ? n2e / NT : 1;
+        const bool in_regs = E <= EMAX;
+        if (in_regs) {
+            float kv[EMAX];
+            int iv[EMAX];
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                const int i = e * NT + tid;
+                kv[e] = (e < E && i < n2e) ? skey[i] : -2.0f;
+                iv[e] = (e < E && i < n2e) ? (int)sidx[i] : 0xFFFF;
+            }
+            auto first = [](float ka, int ia, float kb, int ib) { return ka > kb || (ka == kb && ia < ib); };      // a before b: prob desc, index asc
+            for (int k2 = 2; k2 <= n2e; k2 <<= 1) {
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    if (j >= NT) {                                    // (E == 2, j == NT) partner = the thread's other register
+                        const bool up = (tid & k2) == 0;              // position of register 0; bit j is clear in it
+                        const bool a_first = first(kv[0], iv[0], kv[1], iv[1]);
+                        if (up ? !a_first : a_first) { const float tk = kv[0]; kv[0] = kv[1]; kv[1] = tk; const int ti = iv[0]; iv[0] = iv[1]; iv[1] = ti; }
+                    } else if (j >= 64) {                             // partner in another wave: through LDS
+                        __syncthreads();
+#pragma unroll
+                        for (int e = 0; e < EMAX; ++e) { const int i = e * NT + tid; if (e < E && i < n2e) { skey[i] = kv[e]; sidx[i] = (unsigned short)iv[e]; } }
+                        __syncthreads();
+#pragma unroll
+                        for (int e = 0; e < EMAX; ++e) {
+                            const int i = e * NT + tid;
+                            if (e < E && i < n2e) {
+                                const float kb = skey[i ^ j]; const int ib = sidx[i ^ j];
+                                const bool lower = (i & j) == 0, up = (i & k2) == 0;
+                                const bool me_first = first(kv[e], iv[e], kb, ib);
+                                if ((lower == up) ? !me_first : me_first) { kv[e] = kb; iv[e] = ib; }      // lower & up (or upper & down) keeps the first
+                            }
+                        }
+                    } else {                                          // partner = lane ^ j of this wave
+#pragma unroll
+                        for (int e = 0; e < EMAX; ++e) {
+                            const int i = e * NT + tid;
+                            const float kb = __shfl_xor(kv[e], j, 64); const int ib = __shfl_xor(iv[e], j, 64);
+                            const bool lower = (i & j) == 0, up = (i & k2) == 0;
+                            const bool me_first = first(kv[e], iv[e], kb, ib);
+                            if ((lower == up) ? !me_first : me_first) { kv[e] = kb; iv[e] = ib; }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) { const int i = e * NT + tid; if (e < E && i < n2e) { skey[i] = kv[e]; sidx[i] = (unsigned short)iv[e]; } }
+            __syncthreads();
+        }
+        for (int k2 = 2; !in_regs && k2 <= n2e; k2 <<= 1) {
             for (int j = k2 >> 1; j > 0; j >>= 1) {
                 for (int i = tid; i < n2e; i += NT) {
                     const int ixj = i ^ j;
