@@ -36,3 +36,6 @@ timeout 200 tools/micro/bench_split > $O/micro_split_conv_variants.txt 2>&1
 timeout 300 tools/micro/bench_stream > $O/micro_stream_gemm_variants.txt 2>&1
 timeout 200 tools/micro/bench_attn > $O/micro_attention.txt 2>&1
 ls -la $O
+timeout 100 tools/micro/bench_sampler > $O/micro_sampler.txt 2>&1
+timeout 200 tools/micro/bench_panel > $O/micro_panel_gemm_experiment.txt 2>&1
+ls $O | wc -l
