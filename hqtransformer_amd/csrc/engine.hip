@@ -401,7 +401,7 @@ static int alloc_workspace(hqt_handle* hp) {
             const size_t out_e = out_r * out_r * (size_t)(l.kind == 4 ? 0 : l.cout);
             per_img = std::max(per_img, std::max(in_e, out_e));
         }
-        h->dec_chunk = std::min<int>(c.max_batch, getenv("HQT_DEC_CHUNK") ? atoi(getenv("HQT_DEC_CHUNK")) : 128);    // images per decode pass: 64 -> 128 -> 256 = 2047 -> 2090 -> 2102 images/s (SPLIT); 128 keeps the workspace at 17 GB per lane
+        h->dec_chunk = std::min<int>(c.max_batch, getenv("HQT_DEC_CHUNK") ? atoi(getenv("HQT_DEC_CHUNK")) : 64);     // images per decode pass.  Decoder alone 64 -> 128 -> 256: 2047 -> 2090 -> 2102 images/s (SPLIT), but in the pipeline 128 measured 0.4 % slower (1275 vs 1280 images/s, same box)
         h->act_elems = per_img * h->dec_chunk;
         for (int i = 0; i < 3; ++i) CHK(dev_alloc(h.get(), &h->act[i], h->act_elems * 4, true));
         CHK(dev_alloc(h.get(), &h->act[3], h->act_elems * 4, true));     // bf16 copy (FAST) or fp16 hi / lo planes (SPLIT)
