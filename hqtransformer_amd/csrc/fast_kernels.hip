@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     // ---- vector epilogue (the AR loop's store modes): a thread finishes 4 consecutive columns of one row.  Its bias, column sums and
     //      residual row are fetched under the end of the K loop (pipelined variants) or under the reduction, never as dependent loads after it.
     const bool xs = S > 1 && g.xs_ctr != nullptr;                    // in-kernel split-K: the last arriver of a tile finishes it
-    const bool vec_epi = (S == 1 || xs) && (ABL == 0 || ABL == 9) && g.N % 4 == 0 && g.ldc % 4 == 0 &&
+    const bool vec_epi = (S == 1 || xs) && (ABL == 0 || ABL == 9 || ABL == 6 || ABL == 7) && g.N % 4 == 0 && g.ldc % 4 == 0 &&
                          (g.store == STORE_RESID || g.store == STORE_PACKED || (g.store == STORE_QKV && g.qkv_D % (32 * NT) == 0) ||
                           (g.store == STORE_ROWS && g.rows_per_group == 0 && !g.resid && g.batch <= 1));
     constexpr int VGROUPS = TILE / 4;                                 // 4-column groups per workgroup
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
             const float* rp = red + ((o4 >> 10) * 32 + ((o4 >> 5) & 31)) * RP + (o4 & 31);
             f32x4 sv = *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
-            for (int w = 1; w < NW; ++w) sv += *reinterpret_cast<const f32x4*>(rp + (size_t)w * TILE_P);
+            for (int w = 1; w < (ABL == 7 ? 1 : NW); ++w) sv += *reinterpret_cast<const f32x4*>(rp + (size_t)w * TILE_P);   // ABL 7 (bench_stream): no cross-wave sum
             part[j] = sv;
         }
         if (xs) {
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], g.act);
             if (g.store == STORE_PACKED) st4<TC>(reinterpret_cast<TC*>(g.C) + packed_off(m, ncol, g.c_packed_mb), v);
-            else st4<TC>(reinterpret_cast<TC*>(g.C) + (long long)m * g.ldc + ncol, v);
+            else if (ABL != 6 || v[0] == 12345.678f) st4<TC>(reinterpret_cast<TC*>(g.C) + (long long)m * g.ldc + ncol, v);      // ABL 6 (bench_stream): no output stores
         }
     } else
     for (int o = threadIdx.x; o < TILE; o += NW * 64) {

@@ -82,7 +82,8 @@ int main() {
             if (M == 64 && false) { stamps<2, 1, 8, 12>(sh, M, 1, w[0], x, y, slabs, st); stamps<1, 1, 8, 12>(sh, M, 1, w[1], x, y, slabs, st); }
             if (M == 512 || M == 2048) {
                 const float e0 = run<2, 2, 4, 4, 0, true>(sh, M, 1, w, x, y, slabs, st), e3 = run<2, 2, 4, 4, 3, true>(sh, M, 1, w, x, y, slabs, st);
-                printf("   <2,2,4,4> pipelined: full %.2f us, without the epilogue (ABL 3) %.2f us\n", e0, e3);
+                const float e6 = run<2, 2, 4, 4, 6, true>(sh, M, 1, w, x, y, slabs, st), e7 = run<2, 2, 4, 4, 7, true>(sh, M, 1, w, x, y, slabs, st);
+                printf("   <2,2,4,4> pipelined: full %.2f us, without the epilogue (ABL 3) %.2f us, without the output stores %.2f, without the cross-wave sum reads %.2f\n", e0, e3, e6, e7);
             }
             if (M == 512 || M == 2048) { stamps<2, 2, 4, 4, true>(sh, M, 1, w[0], x, y, slabs, st); stamps<2, 2, 8, 6, false>(sh, M, 1, w[1], x, y, slabs, st); }
 #define P(MBW, NT, NW, U, S) { float t = run<MBW, NT, NW, U, 0, true>(sh, M, S, w, x, y, slabs, st); if (t > 0) printf("   MBW=%d NT=%d NW=%d D=%2d S=%d pipelined : %7.2f us  (%.2f TB/s, %.0f TFLOP/s)\n", MBW, NT, NW, U, S, t, bytes / t / 1e6, 2.0 * M * sh.N * sh.K / t / 1e6); }
