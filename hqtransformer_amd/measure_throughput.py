@@ -12,7 +12,9 @@ Differences, stated: the whole batch is decoded in one call instead of ``batch_s
 default ``decode_precision=split`` is fp32-accurate on the matrix cores (pixels within 1e-4 of the fp32 result), ``exact`` runs
 fp32 FMA chains on the vector ALUs, ``fast`` bf16 MFMA (faster, 0.04 max pixel error).  ``inflight=N`` (default 1 = the reference's order) keeps N
 iterations in flight on N lanes (``hqtransformer_amd.pipeline``): same iterations, same accounting of the loop's wall
-time; the per-phase figures then are lane times, which overlap.
+time; the per-phase figures then are lane times, which overlap.  ``merge=k`` executes k consecutive iterations as one pass of
+k x batch_size rows (every iteration keeps its own class id and seed; ``bench.py``'s default schedule is ``inflight=3 merge=8``);
+the per-phase figures are then measured per pass.
 """
 from __future__ import annotations
 
@@ -28,7 +30,7 @@ from .models import ImageGPT2
 from .sampling import rearrange_codes, rearrange_codes3, sampling_hqtransformer, sampling_ihqgpt
 
 EXPERIMENT_DEFAULTS = dict(f=32, model='huge', d=4, c=16384, batch_size=50, n_loop=6, warmup=1, model_path='',
-                           top_resolution=8, code_levels=2, decode_batch=0, decode_precision='split', seed=0, inflight=1)
+                           top_resolution=8, code_levels=2, decode_batch=0, decode_precision='split', seed=0, inflight=1, merge=1)
 
 
 def iterations_per_loop(batch_size: int) -> int:
@@ -60,11 +62,10 @@ def main(args) -> dict:
     n_loop = args.n_loop
 
     pipe = None
-    if int(args.inflight) > 1:
-        if args.code_levels == 3:
-            raise NotImplementedError('inflight > 1 with code_levels=3')
+    merge = max(1, int(args.merge))
+    if int(args.inflight) > 1 or merge > 1:
         from .pipeline import InflightSampler
-        pipe = InflightSampler(model_ar, lanes=int(args.inflight), device=device)
+        pipe = InflightSampler(model_ar, lanes=int(args.inflight), device=device, merge=merge, record_phases=merge > 1)
 
     def loop(loop_idx: int):
         starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
@@ -75,7 +76,7 @@ def main(args) -> dict:
         for i in range(n_iter_per_loop if pipe is not None else 0):
             pipe.submit(batch_size, random.randint(0, 999), max_seq_len=args.top_resolution * args.top_resolution, use_fp16=True,
                         precision=args.decode_precision, clamp01=True, softmax_temperature=[1.0 for _ in range(args.code_levels)],
-                        phase_events=(starts[i], middles[i], ends[i]))
+                        phase_events=None if merge > 1 else (starts[i], middles[i], ends[i]))
         if pipe is not None:
             pipe.drain()
         for i in range(n_iter_per_loop if (pipe is None and args.code_levels == 3) else 0):     # measure_throughput/__main__.py:116-138
@@ -111,8 +112,13 @@ def main(args) -> dict:
         torch.cuda.synchronize(device)
         toc = time.time()
         elapsed_time = toc - tic
-        elapsed_time_ar = sum(starts[i].elapsed_time(middles[i]) for i in range(n_iter_per_loop)) / 1000
-        elapsed_time_decode = sum(middles[i].elapsed_time(ends[i]) for i in range(n_iter_per_loop)) / 1000
+        if pipe is not None and merge > 1:                 # per pass: (AR start, AR end, decode end) on the pass's lane
+            log, pipe.phase_log = pipe.phase_log, []
+            elapsed_time_ar = sum(ev[0].elapsed_time(ev[1]) for ev, _ in log) / 1000
+            elapsed_time_decode = sum(ev[1].elapsed_time(ev[2]) for ev, _ in log) / 1000
+        else:
+            elapsed_time_ar = sum(starts[i].elapsed_time(middles[i]) for i in range(n_iter_per_loop)) / 1000
+            elapsed_time_decode = sum(middles[i].elapsed_time(ends[i]) for i in range(n_iter_per_loop)) / 1000
         print(f'{loop_idx + 1}/{n_loop} | {elapsed_time:.1f} s/loop (ar: {elapsed_time_ar:.1f}, decode: {elapsed_time_decode:.1f})')
         n = n_iter_per_loop * batch_size
         speed, speed_ar, speed_decode = (elapsed_time / n * 1000, elapsed_time_ar / n * 1000, elapsed_time_decode / n * 1000)

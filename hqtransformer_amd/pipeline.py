@@ -36,11 +36,13 @@ class Pending:
 
 
 class InflightSampler:
-    def __init__(self, model, lanes: int = 3, device: Optional[torch.device] = None, merge: int = 1):
+    def __init__(self, model, lanes: int = 3, device: Optional[torch.device] = None, merge: int = 1, record_phases: bool = False):
         if lanes < 1 or merge < 1:
             raise ValueError('lanes and merge must be >= 1')
         self.model = model
         self.merge = int(merge)
+        self.record_phases = bool(record_phases)     # merged passes: (AR start, AR end, decode end) events per pass, appended to phase_log
+        self.phase_log: list = []
         self._queue: list = []
         self.n = int(lanes)
         self.device = device if device is not None else model.stage2._device
@@ -102,8 +104,12 @@ class InflightSampler:
                 if a is not None:
                     a(ct[lo:lo + n], [c[lo:lo + n] for c in cb] if isinstance(cb, (list, tuple)) else cb[lo:lo + n], None if px is None else px[lo:lo + n])
                 lo += n
+        phases = None
+        if self.record_phases:
+            phases = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+            self.phase_log.append((phases, sum(sizes)))
         ct, cb, px, ev = self._launch(sum(sizes), cond, seed=seeds[0], max_seq_len=ref[4], use_fp16=ref[5], decode=True, precision=ref[6], clamp01=ref[7],
-                                      use_graph=ref[8], after=split_after if any(a is not None for a in afters) else None,
+                                      use_graph=ref[8], after=split_after if any(a is not None for a in afters) else None, phase_events=phases,
                                       order_after_current=any(e[10] for e in q), row_seeds=row_seeds, row_offsets=row_offsets, **kw)
         lo = 0
         for e, n in zip(q, sizes):

@@ -71,6 +71,10 @@ def test_measure_throughput_counterpart(capsys):
     args = parse_dotlist([f'model_path={TINY}', 'batch_size=250', 'n_loop=2', 'warmup=1', 'inflight=3'], mt.EXPERIMENT_DEFAULTS)
     out3 = mt.main(args)
     assert 'bs250, sampling loops 2-2' in capsys.readouterr().out and out3['ms_per_sample'] > 0
+    # ... and merged into passes of 4 x 50 rows on 2 lanes (20 iterations per loop: 5 passes), phases measured per pass
+    args = parse_dotlist([f'model_path={TINY}', 'batch_size=50', 'n_loop=2', 'warmup=1', 'inflight=2', 'merge=4'], mt.EXPERIMENT_DEFAULTS)
+    outm = mt.main(args)
+    assert 'bs50, sampling loops 2-2' in capsys.readouterr().out and outm['ms_per_sample'] > 0 and outm['ms_ar'] > 0 and outm['ms_decode'] > 0
 
 
 def test_sampling_hqmodel_counterpart_writes_reference_formats(tmp_path):
