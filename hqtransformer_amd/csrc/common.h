@@ -42,8 +42,13 @@ __device__ __host__ inline uint32_t float_order_key(float f) {
 __device__ __host__ inline long long packed_off(int m, int k, int MB) {
     return ((long long)(k >> 4) * MB + (m >> 5)) * 512 + ((((k >> 3) & 1) << 5) + (m & 31)) * 8 + (k & 7);
 }
-constexpr int PACKED_MAX_ROWS = 4096;      // most rows of a packed_off() activation (a merged pass: 4 depth tokens x up to 1024 samples)
-__device__ __host__ inline int packed_mb(int M) { return M <= 32 ? 1 : (M <= 64 ? 2 : (M <= 128 ? 4 : (M <= 256 ? 8 : (M <= 512 ? 16 : (M <= 1024 ? 32 : (M <= 2048 ? 64 : (M <= 4096 ? 128 : 0))))))); }
+constexpr int PACKED_MAX_ROWS = 16384;     // most rows of a packed_off() activation (a merged pass: 4 depth tokens x up to 4096 samples)
+__device__ __host__ inline int packed_mb(int M) {          // 32-row blocks of the packed layout for M rows: the next power of two (1 .. 512)
+    if (M > PACKED_MAX_ROWS) return 0;
+    int mb = 1;
+    while (mb * 32 < M) mb <<= 1;
+    return mb;
+}
 
 // One NT GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]  (+bias, act, +residual) with
 //   * an optional implicit-GEMM A operand: 1x1 / 3x3 'same' convolution over an NHWC tensor, with

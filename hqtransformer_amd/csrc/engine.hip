@@ -115,6 +115,8 @@ struct hqt_handle {
     float *parts = nullptr, *partsd = nullptr; // their partial row statistics [D/32][Mpad][2]
     int nparts = 0, npartsd = 0;
     float* fold_tmp = nullptr;
+    int resid_nparts = 0;                     // partial row statistics the last STORE_RESID GEMM left per row (run_linear)
+    bool tile_gemm = true;                    // merged passes through the LDS-tiled MFMA kernels (HQT_NO_TILE_GEMM=1: streaming kernels at every row count)
     float* splitk = nullptr;                  // split-K partial slabs of the streaming GEMM
     unsigned* xs_ctr = nullptr;               // arrival counters of the in-kernel split-K (zero between launches)
     int cur_w_nt = 0;                         // GemmArgs.w_nt of the streaming GEMMs being issued (set per block)
@@ -191,6 +193,18 @@ struct Timed {
             h->chain_valid = true;
         }
     }
+    // the launches so far belong to this timer's slot; what follows goes to `name` (a GEMM and its split-K combine)
+    void next(const char* name) {
+        if (!on) return;
+        hipEvent_t e;
+        hipEventCreate(&e);
+        hipEventRecord(e, st);
+        h->slots[slot].ev.push_back({h->chain_ev, e});
+        h->slots[slot].used++;
+        h->all_events.push_back(h->chain_ev);
+        h->chain_ev = e;
+        slot = slot_id(h, name);
+    }
     ~Timed() {
         if (!on) return;
         hipEvent_t e;
@@ -202,6 +216,17 @@ struct Timed {
         h->chain_ev = e;
     }
 };
+// Which kernel variant served a launch, as zero-time slots of the timing report ("variant:<kernel>:<shape class>"): counted only
+// while timing is on (un-graphed passes), so tests and bench.py can state what the timed schedule ran.
+static void count_variant(hqt_handle* h, const char* fmt, ...) {
+    if (!h->timing) return;
+    char buf[96];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    h->slots[slot_id(h, buf)].launches++;
+}
 static void timing_collect(hqt_handle* h) {
     if (h->chain_valid) hipEventSynchronize(h->chain_ev);
     for (auto& s : h->slots) {
@@ -304,6 +329,7 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
     DeviceGuard dg(device);
     if (!dg.ok) return fail(HQT_ERR_HIP, "hipSetDevice(%d) failed", device);
     std::unique_ptr<hqt_handle> h(new hqt_handle());
+    h->tile_gemm = getenv("HQT_NO_TILE_GEMM") == nullptr;
     h->cfg = *cfg;
     h->device = device;
     const hqt_config& c = h->cfg;
@@ -773,6 +799,7 @@ static int finalize_impl(hqt_handle* h) {
     }
     if (c.has_stage1 && h->w.count("stage1.encoder.conv_in.weight")) CHK(load_encoder(h));
     HIPCHK(stream_gemm_configure());
+    HIPCHK(tile_gemm_configure());
     HIPCHK(mfma_gemm_configure());
     HIPCHK(split_kernels_configure());
     HIPCHK(hipDeviceSynchronize());
@@ -806,7 +833,11 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     g.w_nt = h->cur_w_nt;
     if (g.alpha == 0.0f) g.alpha = 1.0f;
     if (g.lda == 0) g.lda = l.K;
-    Timed t(h, tag, st);
+    // tools/ar_pass_time.py --by-rows: one timing slot per (GEMM, row count) instead of per GEMM
+    static const bool by_rows = getenv("HQT_TIMING_BY_ROWS") != nullptr;
+    char slot_name[64];
+    snprintf(slot_name, sizeof slot_name, by_rows ? "%s@%d" : "%s", tag, g.M);
+    Timed t(h, slot_name, st);
     if (g.Bw_lo) {                              // SPLIT: the caller packed the operand planes (s1_operand) after checking the shape
         g.Bw = l.w16h; g.Bw_lo = l.w16l; g.Bw_frag = l.wfrag; g.Bw_frag16 = l.wfrag16;
         if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
@@ -822,10 +853,30 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         return HQT_OK;
     }
     if (md.fast) {
+        if (g.store == STORE_RESID) h->resid_nparts = g.N / 32;          // partial row statistics the producer leaves (streaming GEMM: one per 32 columns)
+        // merged passes (512+ rows): the LDS-tiled MFMA kernels (tile_gemm.hip); same operands, same store modes
+        if ((g.ln_parts ? l.wpk_ln : l.wpk) && h->tile_gemm && tile_gemm_ok(g, a_dt, c_dt)) {
+            const TilePlan tp = tile_gemm_plan(g);
+            if (tp.geom >= 0 && (size_t)tp.S * 32 * g.a_packed_mb * g.N <= h->splitk_elems) {
+                if (g.ln_parts) g.bias = l.bias_ln;
+                HIPCHK(launch_tile_gemm(g, g.ln_parts ? l.wpk_ln : l.wpk, a_dt, c_dt, tp, h->splitk, st));
+                if (tp.S > 1) count_variant(h, "variant:tile_gemm_%dx%d_splitk%d:%s%s", tp.bm, tp.bn, tp.S, tag, by_rows ? slot_name + strlen(tag) : "");
+                else count_variant(h, "variant:tile_gemm_%dx%d%s:%s%s", tp.bm, tp.bn, g.ln_parts ? "_dln" : "", tag, by_rows ? slot_name + strlen(tag) : "");
+                if (tp.S > 1) {
+                    char cn[64];
+                    snprintf(cn, sizeof cn, by_rows ? "gemm_combine@%d" : "gemm_combine", g.M);
+                    t.next(cn);
+                    HIPCHK(launch_resid_combine(g, h->splitk, tp.S, st));
+                }
+                if (g.store == STORE_RESID) h->resid_nparts = tp.S > 1 ? 1 : g.N / tp.bn;
+                return HQT_OK;
+            }
+        }
         if (g.ln_parts) {                       // deferred LayerNorm: gamma-folded weights, folded bias; stream kernel only
             if (!l.wpk_ln || !stream_gemm_ok(g, a_dt, c_dt)) return fail(HQT_ERR_STATE, "deferred-LayerNorm GEMM without folded weights (%s)", tag);
             g.bias = l.bias_ln;
             HIPCHK(launch_stream_gemm(g, l.wpk_ln, a_dt, c_dt, 1, nullptr, st));
+            count_variant(h, "variant:stream_gemm_dln:%s", tag);
             return HQT_OK;
         }
         if (l.wpk && !g.conv_taps && stream_gemm_ok(g, a_dt, c_dt)) {
@@ -836,6 +887,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
                 if (xs > 1 && (size_t)xs * 32 * g.a_packed_mb * g.N <= h->splitk_elems && (g.N / 32) * g.a_packed_mb <= 4096) { S = xs; g.xs_ctr = h->xs_ctr; }
             }
             HIPCHK(launch_stream_gemm(g, l.wpk, a_dt, c_dt, S, h->splitk, st));
+            count_variant(h, "variant:stream_gemm:%s", tag);
             if (S > 1 && !g.xs_ctr) { h->pend.slabs = h->splitk; h->pend.S = S; h->pend.rows = 32 * g.a_packed_mb; h->pend.bias = l.b32; }
             return HQT_OK;
         }
@@ -991,7 +1043,7 @@ static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, fl
     g.A = h->abuf; g.M = M; g.batch = 1; g.a_packed_mb = pk;
     g.C = x32; g.ldc = D; g.store = STORE_RESID; g.resid_pk = xpk; g.resid_parts = parts; g.c_packed_mb = pk;
     CHK(run_linear(h, c.md, g, bw.proj, DT_BF16, DT_F32, c.st, "gemm_proj"));
-    *nparts = D / 32;
+    *nparts = h->resid_nparts;
     g = GemmArgs{};
     g.A = xpk; g.M = M; g.batch = 1; g.a_packed_mb = pk;
     g.ln_parts = parts; g.ln_nparts = *nparts; g.ln_colsum = bw.fc1.colsum; g.ln_eps = 1e-5f;
@@ -1002,6 +1054,7 @@ static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, fl
     g.A = h->mbuf; g.M = M; g.batch = 1; g.a_packed_mb = pk;
     g.C = x32; g.ldc = D; g.store = STORE_RESID; g.resid_pk = xpk; g.resid_parts = parts; g.c_packed_mb = pk;
     CHK(run_linear(h, c.md, g, bw.fc2, DT_BF16, DT_F32, c.st, "gemm_fc2"));
+    *nparts = h->resid_nparts;
     return HQT_OK;
 }
 

@@ -23,6 +23,16 @@ int stream_gemm_splitk(const GemmArgs& g);
 int stream_gemm_xs_S(const GemmArgs& g);
 hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, int S, float* slabs, hipStream_t st);
 
+// ---- LDS-tiled MFMA GEMM of the merged AR passes (tile_gemm.hip): same operands and store modes as the streaming GEMM, 512+ rows.
+// S > 1 (STORE_RESID only): fp32 partial slabs [S][32 * a_packed_mb][N], finished by launch_resid_combine (x += bias + sum of
+// slabs, bf16 packed copy, whole-row statistics as ONE part).
+struct TilePlan { int geom; int bm, bn; int S; };    // geom < 0: not taken; S: split-K factor
+bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt);
+TilePlan tile_gemm_plan(const GemmArgs& g);
+hipError_t launch_tile_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, const TilePlan& p, float* slabs, hipStream_t st);
+hipError_t launch_resid_combine(const GemmArgs& g, const float* slabs, int S, hipStream_t st);
+hipError_t tile_gemm_configure();       // raise dynamic-LDS limits once (call outside stream capture)
+
 // ---- tiled MFMA GEMM / implicit-GEMM conv (decoder, text prefill)
 bool mfma_gemm_ok(const GemmArgs& g, int a_dt, int b_dt, int c_dt);
 hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hipStream_t st);

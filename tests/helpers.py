@@ -48,3 +48,38 @@ def gate(name: str, value: float, limit: float, op: str = '<=') -> None:
             fp.write(json.dumps({'gate': name, 'measured': value, 'limit': limit, 'op': op}) + '\n')
     ok = value <= limit if op == '<=' else value >= limit
     assert ok, f'{name}: measured {value} violates {op} {limit}'
+
+
+def philox_exp_noise(row_seeds, global_rows, n_steps: int, V: int, draws: int = 5) -> np.ndarray:
+    """The Exp(1) noise libhqt's sampler generates in-kernel (csrc/kernels.hip, sampler_kernel): Philox4x32-10 with key = the
+    row's 64-bit seed, counter = (vocabulary index // 4, step * draws + draw, global row lo, global row hi), lane v % 4 of the
+    output, q = -log((float(r >> 8) + 0.5) * 2^-24) in fp32.  The RNG is this build's own design (the reference draws from
+    torch's global generator), so this restatement is test infrastructure: it lets the oracle replay what a Philox-driven call
+    drew.  Returns [n_steps, draws, B, V] fp32."""
+    seeds = np.asarray(row_seeds, np.uint64)
+    rows = np.asarray(global_rows, np.int64).astype(np.uint64)
+    B = len(seeds)
+    V4 = (V + 3) // 4
+    M32 = np.uint64(0xFFFFFFFF)
+    out = np.empty((n_steps, draws, B, V4 * 4), np.float32)
+    c0_init = np.broadcast_to(np.arange(V4, dtype=np.uint64)[None, :], (B, V4))
+    for step in range(n_steps):
+        for d in range(draws):
+            c0 = c0_init.copy()
+            c1 = np.full((B, V4), step * draws + d, np.uint64)
+            c2 = np.broadcast_to((rows & M32)[:, None], (B, V4)).copy()
+            c3 = np.broadcast_to((rows >> np.uint64(32))[:, None], (B, V4)).copy()
+            k0 = np.broadcast_to((seeds & M32)[:, None], (B, V4)).copy()
+            k1 = np.broadcast_to((seeds >> np.uint64(32))[:, None], (B, V4)).copy()
+            for _ in range(10):
+                p0 = np.uint64(0xD2511F53) * c0
+                p1 = np.uint64(0xCD9E8D57) * c2
+                hi0, lo0 = p0 >> np.uint64(32), p0 & M32
+                hi1, lo1 = p1 >> np.uint64(32), p1 & M32
+                c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+                k0 = (k0 + np.uint64(0x9E3779B9)) & M32
+                k1 = (k1 + np.uint64(0xBB67AE85)) & M32
+            r = np.stack([c0, c1, c2, c3], axis=-1).reshape(B, V4 * 4)
+            u = ((r >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+            out[step, d] = -np.log(u, dtype=np.float32)
+    return out[..., :V]
