@@ -58,8 +58,10 @@ def parse():
                    help='HQ-VAE decode arithmetic.  The reference harness decodes outside autocast, i.e. in fp32 (measure_throughput/__main__.py:108-113): '
                         'the default is split = fp32-accurate on the matrix cores (fp16 hi/lo operands, fp32 accumulate; pixels within 1e-4 of the '
                         'fp32 oracle); fast = bf16 (NOT like for like: 0.04 max pixel error), exact = fp32 FMA chains on the vector ALUs')
-    p.add_argument('--gather', choices=['pixels', 'codes', 'none'], default='none',
-                   help='optional RCCL gather of every step\'s result to rank 0; the path itself has no exchange step, so the default is none')
+    p.add_argument('--gather', choices=['pixels', 'codes', 'none'], default=None,
+                   help='RCCL gather of every step\'s result to rank 0 (BASELINE.json configs[2]: "RCCL gather over xGMI").  Default: pixels when '
+                        'N > 1 (the finished images of every rank land on rank 0 inside the timed region), n/a at N = 1; none = no collective at all '
+                        '(the path itself has no exchange step)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-graph', action='store_true')
@@ -75,11 +77,13 @@ def parse():
 
 
 def cpu_baseline(cfg, s2, s1, batch):
-    """Reference CPU path as restated by the oracle (fp32 numpy/OpenBLAS on all host cores), bounded sample:
-    2 top positions of the AR loop at the bench batch + the decode of 1 image, scaled to images/s with the
-    reference harness's accounting (64 positions per image batch, decode per image)."""
+    """Reference CPU path as restated by the oracle (fp32 numpy/OpenBLAS), bounded sample: 2 top positions of the AR loop at the bench
+    batch + the decode of 1 image, scaled to images/s with the reference harness's accounting (64 positions per image batch, decode per
+    image).  OpenBLAS with one thread per hardware thread of a 256-thread host is SLOWER on these GEMMs (64 rows: the threads mostly wait
+    for each other) than with a fraction of them, so the BLAS pool is sized first: one AR position per candidate thread count, the
+    fastest is used for the measurement and reported as `cores` (the threads actually used)."""
     from oracle.hqt_oracle import OracleStage1, OracleStage2, OracleStage2L3
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     three = s2.levels == 3
     w2 = synth.stage2_weights(s2, 0, 'bench')
     w1 = synth.stage1_weights(s1, 1, 'bench')
@@ -92,29 +96,51 @@ def cpu_baseline(cfg, s2, s1, batch):
         noise = np.maximum(rng.standard_exponential((n_pos, 21, batch, s2.vocab_top), dtype=np.float32), np.float32(1e-30))
     else:
         noise = synth.exp_noise(0, n_pos, batch, s2.vocab_top)
-    t0 = time.perf_counter()
-    orc2.sample(cond, batch, n_pos, noise)
-    t_ar = (time.perf_counter() - t0) / n_pos
-    t_prefill = 0.0
-    if s2.cond == 2:                        # the prompt prefill runs once per batch: separate it from the per-position cost
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                     # no pool control: whatever OpenBLAS picks
+        threadpool_limits = None
+    sweep = {}
+    cores = avail
+    if threadpool_limits is not None and avail > 16:
+        for n in sorted({avail, min(avail, 128), min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True):
+            with threadpool_limits(limits=n):
+                orc2.sample(cond, batch, 1, noise[:1]) if n == avail else None       # first touch of the weights outside the timing
+                t0 = time.perf_counter()
+                orc2.sample(cond, batch, 1, noise[:1])
+                sweep[n] = round(time.perf_counter() - t0, 3)
+        cores = min(sweep, key=sweep.get)
+
+    def measure():
         t0 = time.perf_counter()
-        orc2.sample(cond, batch, 1, noise[:1])
-        t1 = time.perf_counter() - t0
-        per_pos = max(t_ar * n_pos - t1, 1e-9) / (n_pos - 1)
-        t_prefill, t_ar = max(t1 - per_pos, 0.0), per_pos
-    code_b = rng.integers(0, s1.n_embed, (1, r, r))
-    code_m = rng.integers(0, s1.n_embed, (1, r // 2, r // 2))
-    t0 = time.perf_counter()
-    if three:
-        orc1.decode_codes3([rng.integers(0, s1.n_embed, (1, r // 4, r // 4)), code_m, code_b])
+        orc2.sample(cond, batch, n_pos, noise)
+        t_ar = (time.perf_counter() - t0) / n_pos
+        t_prefill = 0.0
+        if s2.cond == 2:                        # the prompt prefill runs once per batch: separate it from the per-position cost
+            t0 = time.perf_counter()
+            orc2.sample(cond, batch, 1, noise[:1])
+            t1 = time.perf_counter() - t0
+            per_pos = max(t_ar * n_pos - t1, 1e-9) / (n_pos - 1)
+            t_prefill, t_ar = max(t1 - per_pos, 0.0), per_pos
+        code_b = rng.integers(0, s1.n_embed, (1, r, r))
+        code_m = rng.integers(0, s1.n_embed, (1, r // 2, r // 2))
+        t0 = time.perf_counter()
+        if three:
+            orc1.decode_codes3([rng.integers(0, s1.n_embed, (1, r // 4, r // 4)), code_m, code_b])
+        else:
+            orc1.decode_code(code_m, code_b)
+        return t_ar, t_prefill, time.perf_counter() - t0
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=cores):
+            t_ar, t_prefill, t_dec = measure()
     else:
-        orc1.decode_code(code_m, code_b)
-    t_dec = time.perf_counter() - t0
+        t_ar, t_prefill, t_dec = measure()
     n_positions = (r // (4 if three else 2)) ** 2
     per_image = (t_prefill + t_ar * n_positions) / batch + t_dec
     return {'value': round(1.0 / per_image, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n_pos} of {n_positions} AR positions at batch {batch} ({t_ar:.2f} s/position' + (f', prompt prefill {t_prefill:.2f} s' if s2.cond == 2 else '') + ') + decode of 1 image '
-                      f'({t_dec:.2f} s), fp32 numpy/OpenBLAS oracle, extrapolated per image'}
+                      f'({t_dec:.2f} s), fp32 numpy/OpenBLAS oracle on {cores} BLAS threads of {avail} hardware threads, extrapolated per image',
+            'blas_threads_sweep_s_per_position': {str(k): v for k, v in sorted(sweep.items())}}
 
 
 def pmc_traffic(family):
@@ -133,6 +159,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gather is None:
+        args.gather = 'pixels' if world > 1 else 'none'
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     dist = None
@@ -176,6 +204,19 @@ def main():
     gathered = None
     if dist is not None and args.gather == 'pixels' and rank == 0:
         gathered = [torch.empty((B, s1.out_ch, H, H), dtype=torch.float32, device=dev) for _ in range(world)]
+
+    if dist is not None and args.gather != 'none':
+        # pre-flight: one collective of the real size before anything is timed.  A broken fabric / RCCL set-up must not take the whole
+        # measurement down: the line then says so and the run goes on without the gather (the path itself has no exchange step)
+        try:
+            if args.gather == 'pixels':
+                dist.gather(torch.zeros((B, s1.out_ch, H, H), dtype=torch.float32, device=dev), gathered, dst=0)
+            else:
+                dist.all_gather_into_tensor(torch.empty((world * B, 1), dtype=torch.int64, device=dev), torch.zeros((B, 1), dtype=torch.int64, device=dev))
+            torch.cuda.synchronize(dev)
+        except Exception as e:                      # noqa: BLE001
+            print(f'[bench] rank {rank}: --gather {args.gather} failed in the pre-flight ({type(e).__name__}: {e}); continuing without it', file=sys.stderr)
+            args.gather = f'none (requested gather failed: {type(e).__name__})'
 
     three = s2.levels == 3
     samp_kw = (dict(top_k=[tk] * 3, top_p=[tp] * 3, softmax_temperature=[T] * 3) if three else
@@ -267,6 +308,12 @@ def main():
         t = torch.tensor([elapsed_lanes], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_lanes = float(t.item())
+    host_ms_ranks = [round(1000 * host_submit_s / args.steps, 3)]
+    if dist is not None:
+        t = torch.tensor([host_submit_s], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        host_ms_ranks = [round(1000 * float(x.item()) / args.steps, 3) for x in allt]
     del kept
     pipe.release(B, n_pos)            # lane 0 back to the latency-oriented kernels for the one-at-a-time reference pass
     sample_codes(0, not args.no_graph)  # untimed: the policy change re-captures lane 0's graph; keep that out of the pass below
@@ -294,6 +341,7 @@ def main():
         keep.append((ct, cb, px))
     barrier()
     elapsed = time.perf_counter() - t0
+    model.stage1.range_check()                 # SPLIT decode: an activation outside the fp16 range would invalidate the pixels (raises)
     ar_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(n_serial)) / n_serial
     dec_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(n_serial)) / n_serial
     if dist is not None:
@@ -316,17 +364,22 @@ def main():
             'config': {'workload': (f'text-to-image ({s2.ctx_len_txt}-token synthetic prompts, prefill + ' if txt_cond else 'imagenet256-classcond (') + f'hq-vae({"8x8+16x16+32x32, three code levels" if three else "8x8+16x16"})+hq-transformer {s2.n_layers}L/{s2.embed_dim}d), '
                                    f'batch {B}/GPU, {n_pos} top positions, ' + (f'top_k={tk}, top_p={tp}, T={T} (quality-mode sampler)' if quality else 'top_k=top_p=None, T=[1,1]'),
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
+                       # the schedule, in numbers: a device pass executes `merge` steps at once, `inflight` passes are resident per GPU
+                       'rows_per_pass': merge * B, 'images_in_flight_per_gpu': merge * B * inflight,
+                       'step_latency_ms': round(1000 * elapsed / args.steps * merge * inflight, 1),
+                       'step_latency_note': 'time from a step entering its pass to its pixels: one pass per lane, lanes share the GPU (ms_per_step x merge x lanes); '
+                                            'serial.ms_per_step is the latency of the unmerged one-step-at-a-time order',
                        'precision': {'ar': 'FAST: bf16 weights + MFMA, fp32 accumulate / LayerNorm / softmax / sampler (the reference harness samples under fp16 autocast)' if fast else 'EXACT: fp32',
                                      'decode': {'split': 'SPLIT: fp32-accurate on the matrix cores (fp16 hi/lo operands, 3 MFMAs per term, fp32 accumulate); pixels within 1e-4 of the fp32 oracle '
                                                          '(the reference harness decodes in fp32, outside autocast)',
                                                 'fast': 'FAST: bf16 MFMA (0.04 max pixel error: NOT the reference harness\'s fp32 decode)',
                                                 'exact': 'EXACT: fp32 FMA chains on the vector ALUs'}[dec_prec]},
-                       'gather': args.gather if world > 1 else 'n/a', 'hip_graph': not args.no_graph,
-                       'pipeline': (f'{inflight} steps in flight per GPU (round-robin over {inflight} lanes: own HIP stream, KV cache and '
-                                    f'activations, shared weights, throughput-oriented GEMM tiles); each step is one full batch-{B} pass') if inflight > 1 else 'serial',
-                       'merge': (f'{merge} consecutive steps execute as one pass of {merge * B} rows (own class id, Philox seed and global row indices per step: '
-                                 f'the draws of a step do not depend on what it is merged with)') if merge > 1 else 'none'},
-            'host_ms_per_step': round(1000 * host_submit_s / args.steps, 3),
+                       'gather': (args.gather + (' (RCCL, every step, inside the timed region)' if args.gather in ('pixels', 'codes') else '')) if world > 1 else 'n/a', 'hip_graph': not args.no_graph,
+                       'pipeline': (f'{inflight} passes in flight per GPU (round-robin over {inflight} lanes: own HIP stream, KV cache and '
+                                    f'activations, shared weights, throughput-oriented GEMM tiles)') if inflight > 1 else 'one pass at a time',
+                       'merge': (f'{merge} consecutive batch-{B} steps execute as ONE device pass of {merge * B} rows (own class id, Philox seed and global row indices per step: '
+                                 f'the draws of a step do not depend on what it is merged with); the reference harness runs one batch-{B} step at a time -- that order is the `serial` record') if merge > 1 else 'none'},
+            'host_ms_per_step': max(host_ms_ranks), 'host_ms_per_step_ranks': host_ms_ranks,
             'env_switches': {k: v for k, v in sorted(os.environ.items()) if k.startswith('HQT_')},
             'serial': {'value': round(serial_value, 2), 'ms_per_step': round(serial_ms, 3), 'steps': n_serial,
                        'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
@@ -382,38 +435,48 @@ def main():
         fam = []
         if gemm_ms > 0:
             n_l = sum(v[0] for v in gemm.values())
-            ach = wbytes / (gemm_ms * 1e-3) / 1e9
-            fam.append({'kernel': f'stream_gemm_kernel: AR weight-streaming GEMM family (qkv/proj/fc1/fc2/heads; {Bm}-row passes, {4 * Bm} rows in depth sub-step 1)', 'bound': 'hbm',
-                        'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                        'traffic': pmc_traffic('stream_gemm'), 'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3),
-                        'total_ms': round(gemm_ms, 3), 'algorithmic_bytes_per_launch': round(wbytes / n_l),
-                        'eager_to_graph_scale': round(ar_scale, 4),
-                        'rows_per_pass': Bm,
-                        'frac_timed_region': round(wbytes * passes / elapsed_lanes / 1e9 / HBM_PEAK_GBS, 4),
-                        'traffic_source': 'profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of a bounded run of this kernel family, '
-                                          'committed with the repository; NOT collected by this invocation',
-                        'note': 'per-launch figure of the kernels the timed region runs (one pass = merge x batch rows; throughput policy when several lanes are '
-                                'in flight), measured one lane at a time; with several lanes launches overlap.  Algorithmic bytes = the weights, streamed once per pass.  '
-                                'At 256+ rows per pass these launches are no longer bound by HBM but by the L2 -> L1 traffic of their 64-row tiles (DESIGN.md): '
-                                'the HBM fraction is quoted because HBM is still the roofline the weight stream has to respect',
-                        'ar_ms_one_pass_this_schedule': round(ar_ms, 3), 'ar_ms_serial_batch': round(ar_ms_serial, 3),
-                        'timed_region_weight_stream_GBps': round(wbytes * passes / elapsed_lanes / 1e9, 1)})
+            hbm = wbytes / (gemm_ms * 1e-3) / 1e9
+            gflops = work['ar_flops'] * Bm * (n_pos / n_full)                                # algorithmic FLOPs of the AR GEMMs of one pass (Bm images)
+            tf = gflops / (gemm_ms * 1e-3) / 1e12
+            # Which roofline bounds an AR GEMM depends on the rows of the pass: its intensity is ~rows FLOP per weight byte, the ridge of the
+            # part 2500 TFLOP/s / 8 TB/s = 312 FLOP/B.  Below 256 rows the launches are weight streams (HBM); merged passes are matrix work.
+            mfma_bound = Bm >= 256
+            rec = {'kernel': (f'tile_gemm_kernel / stream_gemm_kernel: AR GEMM family (qkv / proj / fc1 / fc2 / heads + split-K combine; {Bm}-row passes, {4 * Bm} rows in depth sub-step 1)'),
+                   'bound': 'mfma' if mfma_bound else 'hbm',
+                   'achieved': round(tf, 1) if mfma_bound else round(hbm, 1), 'peak': MFMA_BF16_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+                   'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
+                   'frac': round(tf / MFMA_BF16_PEAK_TFLOPS, 4) if mfma_bound else round(hbm / HBM_PEAK_GBS, 4),
+                   'traffic': pmc_traffic('stream_gemm'), 'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3),
+                   'total_ms': round(gemm_ms, 3), 'algorithmic_flops_per_launch': round(gflops / n_l), 'algorithmic_bytes_per_launch': round(wbytes / n_l),
+                   'weight_stream_GBps': round(hbm, 1), 'weight_stream_frac_of_hbm_peak': round(hbm / HBM_PEAK_GBS, 4),
+                   'eager_to_graph_scale': round(ar_scale, 4), 'rows_per_pass': Bm,
+                   'frac_timed_region': round((gflops * passes / elapsed_lanes / 1e12 / MFMA_BF16_PEAK_TFLOPS) if mfma_bound else (wbytes * passes / elapsed_lanes / 1e9 / HBM_PEAK_GBS), 4),
+                   'traffic_source': 'profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of a bounded run of this kernel family, '
+                                     'committed with the repository; NOT collected by this invocation',
+                   'note': 'per-launch figure of the kernels the timed region runs (one pass = merge x batch rows; throughput policy when several lanes are in flight), measured one lane '
+                           'at a time with per-launch HIP events; algorithmic FLOPs = 2 x rows x N x K of every nn.Linear of the reference (stage2/layers.py), algorithmic bytes = the bf16 '
+                           'weights, streamed once per pass',
+                   'ar_ms_one_pass_this_schedule': round(ar_ms, 3), 'ar_ms_serial_batch': round(ar_ms_serial, 3)}
+            fam.append(rec)
         if conv_ms > 0:
             n_l = sum(v[0] for v in conv.values())
             ach = cflops / (conv_ms * 1e-3) / 1e12
             peak = MFMA_BF16_PEAK_TFLOPS if dec_prec != 'exact' else F32_PEAK_TFLOPS
-            mfma_per_flop = 3 if dec_prec == 'split' else 1           # SPLIT issues three fp16 MFMAs per product term
-            kname = {'split': 'conv3x3_split_ring16_kernel (+ conv3x3_split_out16_kernel for conv_out, split_gemm_kernel for the 1x1 convs and the attention GEMMs): '
+            # matrix work actually issued per algorithmic FLOP: SPLIT evaluates a product with three fp16 MFMAs; the nearest-x2 upsampling convs run as four
+            # 2x2 phase convolutions on the low-resolution image (4 taps instead of 9: the same sums, regrouped)
+            issued = (3 if dec_prec == 'split' else 1) * work.get('dec_flops_executed', work['dec_flops']) / work['dec_flops']
+            kname = {'split': 'conv3x3_split_ring16_kernel (+ conv2x2_split_up16_kernel for the upsampling convs, conv3x3_split_out16_kernel for conv_out, split_gemm_kernel for the 1x1 convs and the attention GEMMs): '
                               'HQ-VAE decoder conv family, fp16 hi/lo split operands',
                      'fast': 'conv3x3_halo_kernel (+ conv_glds_kernel for 1x1): HQ-VAE decoder conv family, bf16',
                      'exact': 'gemm_tile_kernel: HQ-VAE decoder conv family, fp32 vector ALUs'}[dec_prec]
-            fam.append({'kernel': kname, 'bound': 'mfma', 'achieved': round(ach * mfma_per_flop, 2),
-                        'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach * mfma_per_flop / peak, 4), 'traffic': pmc_traffic('decoder_conv'), 'launches': n_l,
+            fam.append({'kernel': kname, 'bound': 'mfma', 'achieved': round(ach, 2),
+                        'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': pmc_traffic('decoder_conv'), 'launches': n_l,
                         'avg_launch_us': round(1000 * conv_ms / n_l, 3), 'total_ms': round(conv_ms, 3),
-                        'algorithmic_flops_per_launch': round(cflops / n_l), 'matrix_flops_per_algorithmic_flop': mfma_per_flop,
-                        'achieved_algorithmic_tflops': round(ach, 2), 'images_per_pass': Bm,
-                        'frac_timed_region': round(cflops * mfma_per_flop * passes / elapsed_lanes / 1e12 / peak, 4),
-                        'note': 'achieved / peak count the MFMA work actually issued (3x the algorithmic FLOPs in SPLIT precision) against the dense f16/bf16 MFMA peak'})
+                        'algorithmic_flops_per_launch': round(cflops / n_l), 'matrix_flops_per_algorithmic_flop': round(issued, 4),
+                        'achieved_issued': round(ach * issued, 2), 'frac_issued': round(ach * issued / peak, 4), 'images_per_pass': Bm,
+                        'frac_timed_region': round(cflops * passes / elapsed_lanes / 1e12 / peak, 4),
+                        'note': 'achieved / frac = ALGORITHMIC FLOPs (2 x MACs of the reference\'s nn.Conv2d calls, stage1/modules/layers.py) per launch / average launch duration, against the dense '
+                                'f16/bf16 MFMA peak; achieved_issued / frac_issued count the MFMA work actually issued (SPLIT: three fp16 MFMAs per product term)'})
         fam.sort(key=lambda f: -f['total_ms'])
         if fam:
             out['roofline'] = fam[0]

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'tile_gemm.hip', 'mfma_gemm.hip', 'split_conv.hip', 'split_stream_conv.hip']
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT = 0, 1, 2
 PRECISIONS = {'exact': PRECISION_EXACT, 'fast': PRECISION_FAST, 'split': PRECISION_SPLIT}
@@ -98,6 +98,7 @@ SYMBOLS = {
     'hqt_decode_seq_l3': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
     'hqt_encode': (C.c_int, [_VP, C.c_int, _F32P, C.c_int, C.POINTER(hqt_encode_out), _VP]),
     'hqt_has_encoder': (C.c_int, [_VP]),
+    'hqt_range_check': (C.c_int, [_VP, _VP]),
     'hqt_param_count': (C.c_int64, [_VP, C.c_int]),
     'hqt_workspace_bytes': (C.c_int64, [_VP]),
     'hqt_timing_enable': (C.c_int, [_VP, C.c_int]),
@@ -135,8 +136,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise HqtLibraryError(f'hipcc failed on {name}:\n' + proc.stdout)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1))) as pool:
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES) + 1, max(1, (os.cpu_count() or 2) - 1))) as pool:
+        audit = pool.submit(audit_hand_scheduled_loops, hipcc, flags, hdrs, force, verbose)
         objs = list(pool.map(compile_one, SOURCES))
+        audit.result()                               # raises HqtLibraryError: no library without a valid audit of the ISA it contains
     if stale(LIB_PATH, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
         if verbose:
@@ -145,6 +148,51 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if proc.returncode != 0:
             raise HqtLibraryError('link failed:\n' + proc.stdout)
     return LIB_PATH
+
+
+# kernels of split_stream_conv.hip whose main loop keeps inline-asm loads in flight across its back edge (mangled names)
+AUDITED_KERNELS = ('_Z27conv3x3_split_ring16_kernelILi0EEv8GemmArgs', '_Z26conv3x3_split_out16_kernel8GemmArgs')
+
+
+def audit_hand_scheduled_loops(hipcc: str, flags: List[str], hdrs: List[str], force: bool = False, verbose: bool = False) -> None:
+    """The SPLIT ring kernels (the default decode path) keep inline-asm loads in flight across their loop's back edge, behind the
+    compiler's own waitcnt tracking.  That is only sound if hipcc leaves the loop one basic block and never touches a register with
+    a load in flight -- checked on the ISA THIS toolchain generates from THESE sources with THESE flags (tools/micro/audit_ring.py).
+    The verdict is cached under a hash of the source, every header, the flags and `hipcc --version`; a failed audit fails the build
+    (HqtLibraryError), so neither build() of __graft_entry__ nor a direct rebuild can link an unaudited kernel."""
+    import hashlib
+    import sys
+    import tempfile
+    src = os.path.join(CSRC, 'split_stream_conv.hip')
+    tool = os.path.join(os.path.dirname(HERE), 'tools', 'micro', 'audit_ring.py')
+    stamp = os.path.join(CSRC, 'build', 'split_stream_conv.audit')
+    hh = hashlib.sha256()
+    for f in [src, tool] + sorted(hdrs):
+        with open(f, 'rb') as fp:
+            hh.update(f.encode() + b'\0' + fp.read())
+    hh.update(' '.join(flags).encode())
+    ver = subprocess.run([hipcc, '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    hh.update(ver.stdout.encode())
+    hh.update(' '.join(AUDITED_KERNELS).encode())
+    key = hh.hexdigest()
+    if not force and os.path.exists(stamp) and open(stamp).read().strip() == 'ok ' + key:
+        return
+    if os.path.exists(stamp):
+        os.remove(stamp)
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, 'split_stream_conv.s')
+        cmd = [hipcc] + [f for f in flags if f != '-fPIC'] + ['-S', '--cuda-device-only', '-o', asm, src]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode != 0:
+            raise HqtLibraryError('hipcc -S failed on split_stream_conv.hip (ISA audit):\n' + proc.stdout)
+        for kernel in AUDITED_KERNELS:
+            r = subprocess.run([sys.executable, tool, asm, kernel], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise HqtLibraryError(f'ISA audit of {kernel} failed -- the hand-scheduled loop is not safe with this toolchain:\n{r.stdout}{r.stderr}')
+    with open(stamp, 'w') as fp:
+        fp.write('ok ' + key + '\n')
 
 
 def load() -> C.CDLL:

@@ -124,7 +124,13 @@ struct hqt_handle {
     struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
     StepState* state = nullptr;
     RowKey* rows = nullptr;                   // [max_batch] Philox seed + global row of every batch row of the current call
-    std::vector<RowKey> rows_host;
+    // per-row keys of merged steps travel through a ring of PINNED staging buffers (an asynchronous copy from pinned memory reads its
+    // source when the stream gets there: a buffer is rewritten only after the copy that last read it has completed, hipEventSynchronize)
+    static constexpr int ROWS_RING = 4;
+    RowKey* rows_pinned[ROWS_RING] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t rows_ev[ROWS_RING] = {nullptr, nullptr, nullptr, nullptr};
+    bool rows_busy[ROWS_RING] = {false, false, false, false};
+    int rows_next = 0;
     int64_t *cond_buf = nullptr, *codes_top = nullptr, *codes_bot = nullptr;   // call-independent homes of cond / the drawn codes
     int64_t* codes_l2 = nullptr;              // third level: [B, max_steps, 16]
     Lin head_l2;                              // head_levels.2 (three-level models; head_top / head_bot hold levels 0 / 1)
@@ -142,6 +148,7 @@ struct hqt_handle {
     float* gn_tiles = nullptr;                // per-tile output statistics of the last halo conv ([image][tile][32][2])
     struct { const void* tensor; int tiles; bool dbl; } gn_ready = {nullptr, 0, false};   // dbl: double partials (SPLIT conv)
     void* zero_page = nullptr;
+    int* range_flag = nullptr;                // set by the SPLIT operand pass when an activation leaves the fp16 range (hqt_range_check)
     size_t act_elems = 0;
     int dec_chunk = 0;
     void *aq = nullptr, *ak = nullptr, *av = nullptr, *ao = nullptr, *as = nullptr, *quant = nullptr;
@@ -377,6 +384,8 @@ static int alloc_workspace(hqt_handle* hp) {
     // prefill and the third code level)
     CHK(dev_alloc(h.get(), &h->zero_page, 256, true));
     HIPCHK(hipMemset(h->zero_page, 0, 256));
+    CHK(dev_alloc(h.get(), (void**)&h->range_flag, 256, true));
+    HIPCHK(hipMemset(h->range_flag, 0, 256));
     if (c.has_stage2) {
         const size_t D = c.embed_dim;
         const int Tp = c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1;    // rows of the widest body pass
@@ -427,7 +436,7 @@ static int alloc_workspace(hqt_handle* hp) {
             const size_t out_e = out_r * out_r * (size_t)(l.kind == 4 ? 0 : l.cout);
             per_img = std::max(per_img, std::max(in_e, out_e));
         }
-        h->dec_chunk = std::min<int>(c.max_batch, getenv("HQT_DEC_CHUNK") ? atoi(getenv("HQT_DEC_CHUNK")) : 64);     // images per decode pass.  Decoder alone 64 -> 128 -> 256: 2047 -> 2090 -> 2102 images/s (SPLIT), but in the pipeline 128 measured 0.4 % slower (1275 vs 1280 images/s, same box)
+        h->dec_chunk = std::max(1, std::min<int>(c.max_batch, getenv("HQT_DEC_CHUNK") ? atoi(getenv("HQT_DEC_CHUNK")) : 64));     // images per decode pass.  Decoder alone 64 -> 128 -> 256: 2047 -> 2090 -> 2102 images/s (SPLIT), but in the pipeline 128 measured 0.4 % slower (1275 vs 1280 images/s, same box)
         h->act_elems = per_img * h->dec_chunk;
         for (int i = 0; i < 3; ++i) CHK(dev_alloc(h.get(), &h->act[i], h->act_elems * 4, true));
         CHK(dev_alloc(h.get(), &h->act[3], h->act_elems * 4, true));     // bf16 copy (FAST) or fp16 hi / lo planes (SPLIT)
@@ -481,6 +490,8 @@ extern "C" int hqt_clone(hqt_handle* src, hqt_handle** out) {
     h->chain_valid = false;
     h->all_events.clear();
     h->pend = {nullptr, 0, 0, nullptr};
+    for (int i = 0; i < hqt_handle::ROWS_RING; ++i) { h->rows_pinned[i] = nullptr; h->rows_ev[i] = nullptr; h->rows_busy[i] = false; }
+    h->rows_next = 0;
     h->nparts = h->npartsd = 0;
     h->policy = HQT_POLICY_LATENCY;              // a lane's tile choice never depends on what the root ran when it was cloned
     const int rc = alloc_workspace(h.get());
@@ -498,6 +509,10 @@ extern "C" int hqt_destroy(hqt_handle* h) {
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     timing_collect(h);
     for (void* p : h->owned) hipFree(p);             // a clone owns only its workspace
+    for (int i = 0; i < hqt_handle::ROWS_RING; ++i) {
+        if (h->rows_pinned[i]) hipHostFree(h->rows_pinned[i]);
+        if (h->rows_ev[i]) hipEventDestroy(h->rows_ev[i]);
+    }
     if (h->parent) h->parent->n_clones--;
     delete h;
     return HQT_OK;
@@ -1328,10 +1343,18 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
     HIPCHK(launch_set_step(h->state, 0, 0, c.st));
     if (opts->row_seeds || opts->row_offsets) {      // merged steps: per-row Philox keys (host arrays, staged through pinned-free pageable copies: B <= max_batch entries)
         if (!opts->row_seeds || !opts->row_offsets) return fail(HQT_ERR_INVALID, "row_seeds and row_offsets come together");
-        std::vector<RowKey>& rk = h->rows_host;      // handle-owned staging (a pageable source is copied out before hipMemcpyAsync returns;
-        rk.resize((size_t)B);                        //  keeping it alive anyway costs nothing and needs no stream synchronisation)
+        const int slot = h->rows_next;
+        h->rows_next = (slot + 1) % hqt_handle::ROWS_RING;
+        if (!h->rows_pinned[slot]) {
+            HIPCHK(hipHostMalloc((void**)&h->rows_pinned[slot], (size_t)h->cfg.max_batch * sizeof(RowKey), hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&h->rows_ev[slot], hipEventDisableTiming));
+        }
+        if (h->rows_busy[slot]) HIPCHK(hipEventSynchronize(h->rows_ev[slot]));       // the copy that last read this buffer (4 calls ago) is done
+        RowKey* rk = h->rows_pinned[slot];
         for (int b = 0; b < B; ++b) { rk[b].seed = opts->row_seeds[b]; rk[b].global_row = opts->row_offsets[b]; }
-        HIPCHK(hipMemcpyAsync(h->rows, rk.data(), (size_t)B * sizeof(RowKey), hipMemcpyHostToDevice, c.st));
+        HIPCHK(hipMemcpyAsync(h->rows, rk, (size_t)B * sizeof(RowKey), hipMemcpyHostToDevice, c.st));
+        HIPCHK(hipEventRecord(h->rows_ev[slot], c.st));
+        h->rows_busy[slot] = true;
     } else {
         HIPCHK(launch_set_rows(h->rows, B, opts->seed, opts->sample_offset, c.st));
     }
@@ -1432,7 +1455,7 @@ static int s1_split_pack(S1Ctx& c, GemmArgs* g, const float* stats, const float*
     const int C = g->conv_taps ? g->Cin : g->lda;
     const int rows = g->conv_taps ? c.n : 1, per = g->conv_taps ? hw_in : g->M;
     Timed t(h, "split_pack", c.st);
-    HIPCHK(launch_split_pack(reinterpret_cast<const float*>(g->A), reinterpret_cast<half_t*>(c.tn), stats, gamma, beta, rows, per, C, 32, swish, c.st));
+    HIPCHK(launch_split_pack(reinterpret_cast<const float*>(g->A), reinterpret_cast<half_t*>(c.tn), stats, gamma, beta, rows, per, C, 32, swish, h->range_flag, c.st));
     g->A = c.tn;
     g->Bw_lo = c.tn;                         // non-NULL marks the operand as split planes; run_linear substitutes the filter planes
     if (!g->conv_taps) g->lda = 2 * C;
@@ -1729,6 +1752,19 @@ extern "C" int hqt_set_policy(hqt_handle* h, int policy) {
     if (policy != HQT_POLICY_LATENCY && policy != HQT_POLICY_THROUGHPUT) return fail(HQT_ERR_INVALID, "unknown policy %d", policy);
     h->policy = policy;
     return HQT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ range check of SPLIT calls
+extern "C" int hqt_range_check(hqt_handle* h, void* stream) {
+    if (!h) return fail(HQT_ERR_INVALID, "null");
+    ON_DEVICE(h);
+    int flag = 0;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipMemcpy(&flag, h->range_flag, sizeof flag, hipMemcpyDeviceToHost));
+    if (!flag) return HQT_OK;
+    HIPCHK(hipMemset(h->range_flag, 0, sizeof flag));
+    return fail(HQT_ERR_RANGE, "a SPLIT-precision call on this handle met an activation outside the fp16 range (NaN or |x| >= 65504): its output is "
+                               "invalid; repeat the call with HQT_PRECISION_EXACT");
 }
 
 // ------------------------------------------------------------------------------------------ introspection

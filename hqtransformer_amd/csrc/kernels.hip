@@ -1,6 +1,7 @@
 // Small kernels of the HQ-Transformer sampling path: embeddings, LayerNorm, KV-cache attention, the
 // fused sampler, codebook gather, GroupNorm statistics.  gfx950 only (wave = 64).
 #include "kernels.h"
+#include <mutex>
 #include "gemm_generic.h"
 #include <type_traits>
 
@@ -861,17 +862,25 @@ static size_t sampler_smem(int V, bool use_p, int& n2) {
     if (use_p) sz += (size_t)n2 * sizeof(float) + (size_t)n2 * sizeof(unsigned short) + (size_t)V;
     return (sz + 15) & ~(size_t)15;
 }
-// hipFuncSetAttribute applies to the CURRENT device: set it on every call (outside capture, a few microseconds) instead of
-// remembering one process-wide size -- a second handle on another device would otherwise launch with the default 64 KB limit
+// hipFuncSetAttribute applies to the CURRENT device and is only ever RAISED here: the limit is a per-device maximum over every
+// (V, top_p) any handle of this process has asked for, so a handle that needs 42 KB can never lower the limit under another
+// handle's (or another thread's) 99 KB launch or captured graph.
 hipError_t sampler_configure(int V, bool use_top_p) {
     int n2;
     const size_t smem = sampler_smem(V, use_top_p, n2);
     if (smem > 160 * 1024 || (use_top_p && V > 65536)) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<256>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static std::mutex mu;
+    static size_t limit[64] = {};                                   // per device ordinal
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<1024>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && smem <= limit[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess && dev >= 0 && dev < 64) limit[dev] = smem;
+    return e;
 }
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
     int n2;

@@ -18,6 +18,13 @@ __device__ __forceinline__ void split2(float x, half_t& hi, half_t& lo) {
     hi = (half_t)x;                                   // round to nearest even
     lo = (half_t)((x - (float)hi) * SPLIT_SCALE);     // the difference and the scaling are exact in fp32
 }
+// Activations: the same split with the fp16 range checked.  |x| >= 65504 (or NaN) cannot travel as fp16 planes: it is replaced by a
+// finite saturated value (so that one bad element does not poison its whole receptive field with NaNs) and reported through `bad`,
+// which the operand pass ORs into the handle's range flag -- hqt_range_check() turns it into HQT_ERR_RANGE.
+__device__ __forceinline__ void split2_checked(float x, half_t& hi, half_t& lo, bool& bad) {
+    if (!(fabsf(x) < 65504.0f)) { bad = true; x = x > 0.0f ? 65472.0f : (x < 0.0f ? -65472.0f : 0.0f); }
+    split2(x, hi, lo);
+}
 __device__ __forceinline__ unsigned pack_h2(half_t a, half_t b) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
@@ -54,7 +61,8 @@ static inline bool sp_fixed_ok(int C) { return C % 8 == 0 && C / 8 <= 256 && 256
 template <bool GN>
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int groups,
-                                                         int swish, int nchunk, int chunk_pix) {
+                                                         int swish, int nchunk, int chunk_pix, int* __restrict__ range_flag) {
+    bool bad = false;
     const int b = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
     const int p0 = ch * chunk_pix, p1 = min(HW, p0 + chunk_pix);
     const int vpp = C / 8, rpi = 256 / vpp;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
                 t = (t - mu[i]) * rs[i] * gm[i] + bt[i];
                 if (swish) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));     // v_exp_f32 / v_rcp_f32 (1 ulp each): the pass is close to VALU-bound with IEEE division
             }
-            split2(t, hi[i], lo[i]);
+            split2_checked(t, hi[i], lo[i], bad);
         }
         const u32x4 vh = {pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])};
         const u32x4 vl = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])};
@@ -105,12 +113,14 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
         const float* s = xb + (long long)p * C;
         emit(*reinterpret_cast<const float4*>(s), *reinterpret_cast<const float4*>(s + 4), p);
     }
+    if (bad && range_flag) atomicOr(range_flag, 1);
 }
 // channel counts the fixed thread <-> channel mapping does not cover
 __global__ __launch_bounds__(256) void split_pack_generic_kernel(const float* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, long long total,
-                                                                 int HW, int C, int groups, int swish) {
+                                                                 int HW, int C, int groups, int swish, int* __restrict__ range_flag) {
     const int cpg = stats ? C / groups : 1;
+    bool bad = false;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long pix = i / C;
         const int c = (int)(i - pix * C);
@@ -121,21 +131,22 @@ __global__ __launch_bounds__(256) void split_pack_generic_kernel(const float* __
             if (swish) t = t / (1.0f + expf(-t));
         }
         half_t hi, lo;
-        split2(t, hi, lo);
+        split2_checked(t, hi, lo, bad);
         y[pix * 2 * C + c] = hi;
         y[pix * 2 * C + C + c] = lo;
     }
+    if (bad && range_flag) atomicOr(range_flag, 1);
 }
 hipError_t launch_split_pack(const float* x, half_t* y, const float* stats, const float* gamma, const float* beta, int B, int HW,
-                             int C, int groups, int swish, hipStream_t st) {
+                             int C, int groups, int swish, int* range_flag, hipStream_t st) {
     if (sp_fixed_ok(C)) {
         const int cp = sp_chunk_pix(HW), nchunk = (HW + cp - 1) / cp;
-        if (stats) split_pack_kernel<true><<<B * nchunk, 256, 0, st>>>(x, y, stats, gamma, beta, HW, C, groups, swish, nchunk, cp);
-        else split_pack_kernel<false><<<B * nchunk, 256, 0, st>>>(x, y, nullptr, nullptr, nullptr, HW, C, groups, 0, nchunk, cp);
+        if (stats) split_pack_kernel<true><<<B * nchunk, 256, 0, st>>>(x, y, stats, gamma, beta, HW, C, groups, swish, nchunk, cp, range_flag);
+        else split_pack_kernel<false><<<B * nchunk, 256, 0, st>>>(x, y, nullptr, nullptr, nullptr, HW, C, groups, 0, nchunk, cp, range_flag);
         return hipGetLastError();
     }
     const long long total = (long long)B * HW * C;
-    split_pack_generic_kernel<<<(int)std::min<long long>((total + 255) / 256, 256 * 16), 256, 0, st>>>(x, y, stats, gamma, beta, total, HW, C, groups, swish);
+    split_pack_generic_kernel<<<(int)std::min<long long>((total + 255) / 256, 256 * 16), 256, 0, st>>>(x, y, stats, gamma, beta, total, HW, C, groups, swish, range_flag);
     return hipGetLastError();
 }
 

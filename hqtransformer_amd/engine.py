@@ -51,7 +51,7 @@ def make_config(s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], max_batch: i
 
 # (data_ptr, numel) -> tensor version of device tensors whose indices are known to be in range: produced by a sampler of this
 # process (any engine: the stage-2 engine's codes go to the stage-1 engine's decode) or already validated once
-_TRUSTED: Dict[Tuple[int, int], tuple] = {}       # (data_ptr, numel) -> (tensor version, weakref to its storage)
+_TRUSTED: Dict[tuple, tuple] = {}       # (data_ptr, shape, stride, dtype) -> (tensor version, weakref to its storage, largest valid id + 1)
 
 
 class Engine:
@@ -96,6 +96,25 @@ class Engine:
         _lib.check(self.lib.hqt_set_policy(self.h, int(policy)))
         self.policy = int(policy)
 
+    def _note_split(self, precision: int, stream: int) -> None:
+        if int(precision) == _lib.PRECISION_SPLIT:
+            self._split_streams = getattr(self, '_split_streams', set()) | {int(stream or 0)}
+
+    def range_check(self) -> None:
+        """hqt_range_check for every stream SPLIT-precision calls of this engine were enqueued on since the last check: waits for them and
+        raises HqtError (HQT_ERR_RANGE) if an activation left the fp16 range (the output of such a call is invalid).  No-op -- and no
+        synchronisation -- when no SPLIT call is pending."""
+        streams, self._split_streams = getattr(self, '_split_streams', set()), set()
+        err = None
+        with torch.cuda.device(self.device):
+            for st in sorted(streams):
+                try:
+                    _lib.check(self.lib.hqt_range_check(self.h, C.c_void_p(st)))
+                except _lib.HqtError as e:       # keep draining the other streams: the flag is per handle and already cleared
+                    err = e
+        if err is not None:
+            raise err
+
     def close(self) -> None:
         for c in getattr(self, '_clones', []):       # clones go first: the parent owns the weights
             c.close()
@@ -133,27 +152,32 @@ class Engine:
     # synchronisation: they are checked once per (storage, version) and remembered, and tensors this engine produced itself
     # (sampled codes fed to decode) are trusted -- so a pipelined run (bench.py: lanes, sampled codes straight into decode)
     # never synchronises.  The kernels clamp every such index into its table regardless (csrc/common.h: clamp_idx).
-    def _trust(self, *tensors) -> None:
+    @staticmethod
+    def _ident(t: torch.Tensor) -> tuple:
+        return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+
+    def _trust(self, *tensors, bound: int) -> None:
+        """Remember that every id in these device tensors lies in [0, bound): a later check against a table of n >= bound rows needs
+        no reduction; against a SMALLER table the tensor is checked again."""
         for t in tensors:
             if t is not None:
                 # (address, size) alone is not an identity: the caching allocator hands a freed block to the next tensor of that size.
                 # The storage object is: torch keeps one Python wrapper per live storage, and a weak reference to it dies with the storage.
-                _TRUSTED[(t.data_ptr(), t.numel())] = (t._version, weakref.ref(t.untyped_storage()))
+                _TRUSTED[self._ident(t)] = (t._version, weakref.ref(t.untyped_storage()), int(bound))
                 if len(_TRUSTED) > 256:
                     _TRUSTED.pop(next(iter(_TRUSTED)))
 
     def _check_index(self, t: Optional[torch.Tensor], n: int, what: str) -> None:
         if t is None or t.numel() == 0:
             return
-        key = (t.data_ptr(), t.numel())
-        seen = _TRUSTED.get(key) if t.is_cuda else None
-        if seen is not None and seen[0] == t._version and seen[1]() is t.untyped_storage():
+        seen = _TRUSTED.get(self._ident(t)) if t.is_cuda else None
+        if seen is not None and seen[0] == t._version and seen[1]() is t.untyped_storage() and seen[2] <= n:
             return
         lo, hi = (int(v) for v in torch.stack([t.min(), t.max()]).tolist())
         if lo < 0 or hi >= n:
             raise IndexError(f'{what}: index out of range (values span [{lo}, {hi}], table has {n} rows)')
         if t.is_cuda:
-            self._trust(t)
+            self._trust(t, bound=hi + 1)
 
     @staticmethod
     def _check_out(t: torch.Tensor, shape, dtype, dev, what: str) -> torch.Tensor:
@@ -229,7 +253,7 @@ class Engine:
                                            _ptr(logits), _ptr(out_top), _ptr(out_bot), C.c_void_p(stream)))
         # inputs must outlive the asynchronous launches
         self._keep = (cond, noise, force_top, force_bot, rows)
-        self._trust(out_top, out_bot)              # the sampler only writes ids inside the vocabulary
+        self._trust(out_top, out_bot, bound=max(self.s2.vocab_top, self.s2.vocab_bot))     # the sampler only writes ids inside the vocabulary
         if return_logits:
             return out_top, out_bot, logits
         return out_top, out_bot
@@ -279,7 +303,7 @@ class Engine:
             _lib.check(self.lib.hqt_sample_l3(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(f[0]), _ptr(f[1]), _ptr(f[2]),
                                               _ptr(logits), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), C.c_void_p(stream)))
         self._keep = (cond, noise, f, rows)
-        self._trust(*outs)
+        self._trust(*outs, bound=max(self.s2.vocab_top, self.s2.vocab_bot))
         return (outs[0], outs[1], outs[2], logits) if return_logits else tuple(outs)
 
     def decode3(self, codes: Sequence[Optional[torch.Tensor]], *, precision: int = PRECISION_EXACT, clamp01: bool = False,
@@ -307,6 +331,7 @@ class Engine:
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(fn(self.h, B, _ptr(cs[0]), _ptr(cs[1]), _ptr(cs[2]), _ptr(out), int(clamp01), int(precision), C.c_void_p(stream)))
+            self._note_split(precision, stream)
         self._keep_dec = cs
         return out
 
@@ -353,6 +378,7 @@ class Engine:
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(self.lib.hqt_encode(self.h, B, _ptr(x), int(precision), C.byref(o), C.c_void_p(stream)))
+            self._note_split(precision, stream)
         self._keep_enc = x
         return res
 
@@ -386,6 +412,7 @@ class Engine:
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(fn(self.h, B, _ptr(code_t), _ptr(code_b), _ptr(out), int(clamp01), int(precision), C.c_void_p(stream)))
+            self._note_split(precision, stream)
         self._keep_dec = (code_t, code_b)
         return out
 

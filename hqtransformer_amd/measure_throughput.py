@@ -72,7 +72,7 @@ def main(args) -> dict:
         middles = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
         ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_iter_per_loop)]
         torch.cuda.synchronize(device)
-        tic = time.time()
+        t_begin = time.time()
         for i in range(n_iter_per_loop if pipe is not None else 0):
             pipe.submit(batch_size, random.randint(0, 999), max_seq_len=args.top_resolution * args.top_resolution, use_fp16=True,
                         precision=args.decode_precision, clamp01=True, softmax_temperature=[1.0 for _ in range(args.code_levels)],
@@ -110,36 +110,28 @@ def main(args) -> dict:
                 _ = model_ar.stage1.decode_sequences(codes_t, codes_b, precision=args.decode_precision, clamp01=True)
             ends[i].record()
         torch.cuda.synchronize(device)
-        toc = time.time()
-        elapsed_time = toc - tic
+        wall_s = time.time() - t_begin
+        model_ar.stage1.range_check()                      # SPLIT decode: raises if an activation left the fp16 range
         if pipe is not None and merge > 1:                 # per pass: (AR start, AR end, decode end) on the pass's lane
             log, pipe.phase_log = pipe.phase_log, []
-            elapsed_time_ar = sum(ev[0].elapsed_time(ev[1]) for ev, _ in log) / 1000
-            elapsed_time_decode = sum(ev[1].elapsed_time(ev[2]) for ev, _ in log) / 1000
+            phase_s = [sum(ev[a].elapsed_time(ev[a + 1]) for ev, _ in log) / 1000 for a in (0, 1)]
         else:
-            elapsed_time_ar = sum(starts[i].elapsed_time(middles[i]) for i in range(n_iter_per_loop)) / 1000
-            elapsed_time_decode = sum(middles[i].elapsed_time(ends[i]) for i in range(n_iter_per_loop)) / 1000
-        print(f'{loop_idx + 1}/{n_loop} | {elapsed_time:.1f} s/loop (ar: {elapsed_time_ar:.1f}, decode: {elapsed_time_decode:.1f})')
-        n = n_iter_per_loop * batch_size
-        speed, speed_ar, speed_decode = (elapsed_time / n * 1000, elapsed_time_ar / n * 1000, elapsed_time_decode / n * 1000)
-        print(f'{loop_idx + 1}/{n_loop} | {speed:.1f} ms/sample (ar: {speed_ar:.1f}, decode: {speed_decode:.1f})')
-        return speed, speed_ar, speed_decode
+            marks = (starts, middles, ends)
+            phase_s = [sum(marks[a][i].elapsed_time(marks[a + 1][i]) for i in range(n_iter_per_loop)) / 1000 for a in (0, 1)]
+        tag = f'{loop_idx + 1}/{n_loop}'
+        print(f'{tag} | {wall_s:.1f} s/loop (ar: {phase_s[0]:.1f}, decode: {phase_s[1]:.1f})')
+        images = n_iter_per_loop * batch_size
+        per_image_ms = tuple(1000.0 * t / images for t in (wall_s, *phase_s))        # (whole iteration, AR loop, decode) per sample
+        print(f'{tag} | {per_image_ms[0]:.1f} ms/sample (ar: {per_image_ms[1]:.1f}, decode: {per_image_ms[2]:.1f})')
+        return per_image_ms
 
-    speeds, speeds_ar, speeds_decode = [], [], []
     print('-' * 80)
-    for loop_idx in range(args.n_loop):
-        speed, speed_ar, speed_decode = loop(loop_idx)
-        if loop_idx < args.warmup:
-            continue
-        speeds.append(speed)
-        speeds_ar.append(speed_ar)
-        speeds_decode.append(speed_decode)
+    kept = [loop(k) for k in range(args.n_loop)][args.warmup:]                   # the first `warmup` loops are run and dropped
     print('-' * 80)
-    n = len(speeds)
-    speed, speed_ar, speed_decode = sum(speeds) / n, sum(speeds_ar) / n, sum(speeds_decode) / n
-    print(f'{title} | {speed:.4f} ms/sample (ar: {speed_ar:.4f}, decode: {speed_decode:.4f})')
+    mean_ms, mean_ar_ms, mean_dec_ms = (sum(col) / len(kept) for col in zip(*kept))
+    print(f'{title} | {mean_ms:.4f} ms/sample (ar: {mean_ar_ms:.4f}, decode: {mean_dec_ms:.4f})')
     print('=' * 80)
-    return dict(ms_per_sample=speed, ms_ar=speed_ar, ms_decode=speed_decode, images_per_s=1000.0 / speed)
+    return dict(ms_per_sample=mean_ms, ms_ar=mean_ar_ms, ms_decode=mean_dec_ms, images_per_s=1000.0 / mean_ms)
 
 
 if __name__ == '__main__':

@@ -192,6 +192,15 @@ class HQVAEStage1(_Stage):
             self._engine = e
         return self._lane(e, lane)
 
+    def range_check(self) -> None:
+        """SPLIT precision carries activations as fp16 hi / lo planes: an activation that is NaN or beyond 65504 invalidates the call
+        that met it (include/hqt.h: hqt_range_check).  Waits for the pending SPLIT calls of every lane and raises HqtError if one
+        of them did.  ``decode_code`` / ``encode`` / ``get_codes`` / ``forward`` call it themselves; ``decode_sequences`` (the
+        asynchronous pipeline primitive) leaves it to its caller (``InflightSampler.drain``, the drivers)."""
+        if self._engine is not None:
+            for e in [self._engine] + list(self.__dict__.get('_lanes', {}).values()):
+                e.range_check()
+
     def decode_code(self, code_t, code_b: Optional[torch.Tensor] = None, precision: Optional[str] = None,
                     clamp01: bool = False, lane: int = 0) -> torch.Tensor:
         """``SimRQGAN2Generator.decode_code`` (generator.py:323-367): int64 code grids -> fp32 [B, 3, H, W],
@@ -202,16 +211,25 @@ class HQVAEStage1(_Stage):
             codes = list(code_t)
             ref = next(c for c in codes if c is not None)
             prec = self._prec(precision)
-            return self.engine(int(ref.shape[0]), lane).decode3(codes, precision=prec, clamp01=clamp01)
+            eng = self.engine(int(ref.shape[0]), lane)
+            px = eng.decode3(codes, precision=prec, clamp01=clamp01)
+            eng.range_check()
+            return px
         assert code_t is not None or code_b is not None
         ref = code_t if code_t is not None else code_b
         prec = self._prec(precision)
-        return self.engine(int(ref.shape[0]), lane).decode(code_t, code_b, precision=prec, clamp01=clamp01)
+        eng = self.engine(int(ref.shape[0]), lane)
+        px = eng.decode(code_t, code_b, precision=prec, clamp01=clamp01)
+        eng.range_check()
+        return px
 
     # -- encode side (generator.py:298-310, 369-370; HQVAEGenerator.encode 530-568)
     def _encode(self, x: torch.Tensor, precision: Optional[str], lane: int, **want):
         prec = self._prec(precision)
-        return self.engine(int(x.shape[0]), lane).encode(x, precision=prec, **want)
+        eng = self.engine(int(x.shape[0]), lane)
+        out = eng.encode(x, precision=prec, **want)
+        eng.range_check()
+        return out
 
     def encode(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0):
         """Two levels -- ``SimRQGAN2Generator.encode``: ``(quant_t, quant_b, diff_t, diff_b, (code_t, code_b, h_b))`` with the codes

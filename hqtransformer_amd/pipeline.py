@@ -22,6 +22,22 @@ from ._lib import POLICY_LATENCY, POLICY_THROUGHPUT
 from .sampling import sampling_hqtransformer, sampling_ihqgpt
 
 
+def _same(a, b) -> bool:
+    """Equality of sampler settings that may hold tensors (given codes): tensors compare by value, never through ``==``."""
+    if torch.is_tensor(a) or torch.is_tensor(b):
+        return torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and bool(torch.equal(a.cpu(), b.cpu()))
+    if isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, dict) and isinstance(b, dict):
+        return a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    return a == b
+
+
+def _settings(entry) -> tuple:
+    """What the steps of one merged pass must share: max_seq_len, use_fp16, precision, clamp01, use_graph, sampler settings."""
+    return (entry[4], entry[5], entry[6], entry[7], entry[8], {k: v for k, v in entry[11].items() if k != 'sample_offset'})
+
+
 class Pending:
     """Result of a step queued on a merging sampler: filled when its group is launched (``InflightSampler.flush`` / ``drain``)."""
     __slots__ = ('value',)
@@ -59,7 +75,11 @@ class InflightSampler:
             if decode is False or phase_events is not None or sample_kw.get('noise') is not None:
                 raise ValueError('merged steps support the plain sample + decode step only (no explicit noise, no phase events)')
             p = Pending()
-            self._queue.append((p, num_candidates, cond, seed, max_seq_len, use_fp16, precision, clamp01, use_graph, after, order_after_current, sample_kw))
+            entry = (p, num_candidates, cond, seed, max_seq_len, use_fp16, precision, clamp01, use_graph, after, order_after_current, sample_kw)
+            # checked HERE, before the step is queued: a mismatch raises without touching the queue (every Pending already handed out stays valid)
+            if self._queue and not _same(_settings(entry), _settings(self._queue[0])):
+                raise ValueError('steps merged into one pass must share max_seq_len, precision and sampler settings (flush() first to start a new pass)')
+            self._queue.append(entry)
             if len(self._queue) >= self.merge:
                 self.flush()
             return p
@@ -69,16 +89,12 @@ class InflightSampler:
 
     def flush(self) -> None:
         """Launch the queued steps (merge > 1) as one pass; their Pending objects receive (codes_top, codes_bot, pixels, done_event)."""
-        q, self._queue = self._queue, []
+        q = self._queue
         if not q:
             return
         ref = q[0]
 
-        def settings(e):
-            return (e[4], e[5], e[6], e[7], e[8], {k: v for k, v in e[11].items() if k != 'sample_offset'})
-        for e in q[1:]:
-            if settings(e) != settings(ref):
-                raise ValueError('steps merged into one pass must share max_seq_len, precision and sampler settings')
+        self._queue = []
         sizes = [e[1] for e in q]
         kw = dict(ref[11])
         offs = [int(e[11].get('sample_offset', 0)) for e in q]
@@ -177,3 +193,4 @@ class InflightSampler:
         for st in self.streams:
             cur.wait_stream(st)
             st.synchronize()
+        self.model.stage1.range_check()          # SPLIT decodes: an activation outside the fp16 range invalidates the pass (raises)

@@ -111,6 +111,7 @@ def main(argv=None):
                                                softmax_temperature=temps, use_fp16=True, is_tqdm=False,
                                                max_seq_len=args.top_resolution * args.top_resolution, model_stage1=model.stage1)
                 pixels = model.stage1.decode_sequences(codes, precision=args.decode_precision, clamp01=True)
+                model.stage1.range_check()                                  # SPLIT decode: raises if an activation left the fp16 range
                 save_pickle(os.path.join(args.result_path, f'samples_({cls_idx + 1}_{num_batches}).pkl'), pixels.cpu().numpy())
                 np.savez(os.path.join(args.result_path, f'targets_({cls_idx + 1}_{num_batches}).npz'), targets=targets.cpu().numpy())
                 continue
@@ -119,6 +120,7 @@ def main(argv=None):
                                                softmax_temperature=temps, use_fp16=True, is_tqdm=False,
                                                max_seq_len=args.top_resolution * args.top_resolution, model_stage1=model.stage1)
             pixels = model.stage1.decode_sequences(codes_t, codes_b, precision=args.decode_precision, clamp01=True)
+            model.stage1.range_check()                                  # SPLIT decode: raises if an activation left the fp16 range
             save_pickle(os.path.join(args.result_path, f'samples_({cls_idx + 1}_{num_batches}).pkl'), pixels.cpu().numpy())
             np.savez(os.path.join(args.result_path, f'targets_({cls_idx + 1}_{num_batches}).npz'), targets=targets.cpu().numpy())
 

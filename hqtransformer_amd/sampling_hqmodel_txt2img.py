@@ -86,6 +86,7 @@ def main(argv=None):
                                            top_k_bot=args.top_k, top_p_bot=args.top_p, softmax_temperature=temps, use_fp16=True,
                                            is_tqdm=False, max_seq_len=args.top_resolution * args.top_resolution, model_stage1=model.stage1)
         pixels = model.stage1.decode_sequences(codes_t, codes_b, precision=args.decode_precision, clamp01=True)
+        model.stage1.range_check()                                  # SPLIT decode: raises if an activation left the fp16 range
         save_pickle(os.path.join(args.result_path, f'samples_({batch_idx + 1}_{n}).pkl'), pixels.cpu().numpy().astype(np.float32))
 
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HQT_ABI_VERSION 4
+#define HQT_ABI_VERSION 5
 
 typedef enum {
     HQT_OK = 0,
@@ -31,7 +31,8 @@ typedef enum {
     HQT_ERR_STATE = -3,        /* call order (e.g. sample before finalize)   */
     HQT_ERR_UNKNOWN_WEIGHT = -4,
     HQT_ERR_SHAPE = -5,
-    HQT_ERR_MISSING_WEIGHT = -6
+    HQT_ERR_MISSING_WEIGHT = -6,
+    HQT_ERR_RANGE = -7         /* SPLIT precision: an activation left the fp16 range (hqt_range_check) */
 } hqt_status;
 
 /* conditioning of the top GPT -- hqvae/models/stage2/hierarchical_ar.py:64-78 */
@@ -218,6 +219,14 @@ int hqt_decode(hqt_handle* h, int B, const int64_t* code_t, const int64_t* code_
                int clamp01, int precision, void* stream);
 int hqt_decode_seq(hqt_handle* h, int B, const int64_t* codes_top, const int64_t* codes_bot, float* out_pixels,
                    int clamp01, int precision, void* stream);
+
+/* hqt_range_check -- no reference counterpart (the reference decodes in fp32, generator.py:323-367, where nothing can leave the
+ * range).  SPLIT-precision calls carry every fp32 activation as two fp16 values; an activation that is NaN or >= 65504 in magnitude
+ * cannot travel that way.  The operand pass saturates it and sets a flag on the handle instead of failing the (asynchronous) call.
+ * hqt_range_check synchronises `stream` (the one the calls were enqueued on), returns HQT_ERR_RANGE if any SPLIT call since the last
+ * check met such a value (and clears the flag), HQT_OK otherwise.  The Python surface calls it wherever it hands pixels or codes of a
+ * SPLIT call to the host side (decode_code / encode of lane 0, InflightSampler.drain). */
+int hqt_range_check(hqt_handle* h, void* stream);
 
 /* introspection */
 int hqt_abi_version(void);

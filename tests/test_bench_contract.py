@@ -37,5 +37,13 @@ def test_roofline_and_cpu_baseline_objects():
     # the per-launch figure follows from its own parts: achieved = algorithmic work per launch / average launch duration
     r = d['roofline']
     if r['bound'] == 'mfma':
-        per_launch = r['algorithmic_flops_per_launch'] * r['matrix_flops_per_algorithmic_flop']
+        # round 3 on: achieved / frac are ALGORITHMIC, the issued matrix work sits beside them (achieved_issued / frac_issued)
+        issued = r['matrix_flops_per_algorithmic_flop'] if 'achieved_issued' not in r else 1
+        per_launch = r['algorithmic_flops_per_launch'] * issued
         assert abs(per_launch / (r['avg_launch_us'] * 1e-6) / 1e12 - r['achieved']) / r['achieved'] < 0.01
+        if 'achieved_issued' in r:
+            assert abs(r['achieved_issued'] - r['achieved'] * r['matrix_flops_per_algorithmic_flop']) / r['achieved_issued'] < 0.01
+            assert abs(r['frac_issued'] - r['achieved_issued'] / r['peak']) < 2e-3
+    cfg = d['config']
+    if 'rows_per_pass' in cfg:                                        # the schedule in numbers (round 3 on)
+        assert cfg['rows_per_pass'] % cfg['per_gpu_batch'] == 0 and cfg['images_in_flight_per_gpu'] % cfg['rows_per_pass'] == 0 and cfg['step_latency_ms'] > 0

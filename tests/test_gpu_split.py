@@ -114,6 +114,93 @@ def test_imagenet_size_decoder_all_precisions_vs_oracle():
           f'output std {want.std():.3f}')
 
 
+def test_split_five_level_geometry_vs_oracle():
+    """BASELINE configs[3] geometry in SPLIT precision: the reference's 5-level pattern ch_mult [1, 2, 4, 4, 4] with attention at
+    32 x 32 = 1024 tokens, 64 base channels (so every conv of the decoder is one the matrix-core kernels take) at 512 x 512 on one
+    image against the CPU oracle: pixels within 1e-4, and the SPLIT kernels -- not the fp32 fallback -- did the work."""
+    spec = Stage1Spec(ch=64, ch_mult=[1, 2, 4, 4, 4], num_res_blocks=1, attn_resolutions=[32], resolution=512, z_channels=64,
+                      embed_dim=32, n_embed=256)
+    assert spec.z_res == 16
+    weights = synth.stage1_weights(spec, 101, 'fixture')
+    r = np.random.default_rng(102)
+    ct, cb = r.integers(0, 256, (1, 8, 8)), r.integers(0, 256, (1, 16, 16))
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    eng = engine_s1(spec, weights, 1)
+    tct, tcb = torch.from_numpy(ct), torch.from_numpy(cb)
+    got, rep = kernels_run(eng, lambda: np_(eng.decode(tct, tcb, precision=PRECISION_SPLIT)))
+    assert got.shape == (1, 3, 512, 512)
+    assert rep.get('split_pack', (0, 0))[0] >= 15 and 'conv3x3' in rep, rep
+    err = np.abs(got - want).max()
+    assert err <= PIXEL_TOL, err
+
+
+def test_full_size_1024_decoder_properties():
+    """BASELINE configs[3] at FULL size (Decoder(resolution = 1024, ch = 128, ch_mult [1, 2, 4, 4, 4], 2 ResnetBlocks per
+    level, attention at 32 x 32, codes 16 x 16 + 32 x 32: 2.8 TFLOP per image) -- far beyond what the CPU oracle finishes in a test,
+    so the size-independent properties: SPLIT output finite, run-to-run bit-identical, the same bits for an image whatever batch it is
+    decoded in and wherever it sits in it, clamp01 = clamp(0.5 x + 0.5) of the unclamped pixels, different codes -> different
+    pixels; and SPLIT against FAST (an independent set of kernels: bf16 halo convs) inside the bf16 budget of the ImageNet-size
+    test.  The 512 x 512 geometry above pins the same layer pattern to the oracle."""
+    spec = Stage1Spec(ch=128, ch_mult=[1, 2, 4, 4, 4], num_res_blocks=2, attn_resolutions=[32], resolution=1024, z_channels=256,
+                      embed_dim=256, n_embed=8192, use_init_downsample=True)
+    assert spec.z_res == 32
+    eng = engine_s1(spec, synth.stage1_weights(spec, 1, 'bench'), 3)
+    r = np.random.default_rng(5)
+    ct = torch.from_numpy(r.integers(0, spec.n_embed, (3, 16, 16)))
+    cb = torch.from_numpy(r.integers(0, spec.n_embed, (3, 32, 32)))
+    px = eng.decode(ct, cb, precision=PRECISION_SPLIT)
+    assert tuple(px.shape) == (3, 3, 1024, 1024) and bool(torch.isfinite(px).all())
+    assert bool(torch.equal(px, eng.decode(ct, cb, precision=PRECISION_SPLIT))), 'not deterministic'
+    one = eng.decode(ct[2:3], cb[2:3], precision=PRECISION_SPLIT)
+    assert bool(torch.equal(one[0], px[2])), 'pixels of an image depend on the batch it was decoded in'
+    swapped = eng.decode(ct.flip(0), cb.flip(0), precision=PRECISION_SPLIT)
+    assert bool(torch.equal(swapped.flip(0), px))
+    cl = eng.decode(ct, cb, precision=PRECISION_SPLIT, clamp01=True)
+    assert float((cl - torch.clamp(0.5 * px + 0.5, 0.0, 1.0)).abs().max()) <= 1e-6
+    assert float((px[0] - px[1]).abs().max()) > 1e-2
+    fast = eng.decode(ct, cb, precision=PRECISION_FAST)
+    d = (fast - px).abs()
+    assert float(d.max()) <= 0.1 * max(1.0, float(px.abs().max()) / 5.0) and float(d.mean()) <= 1e-2, (float(d.max()), float(d.mean()))
+
+
+def test_split_range_check_large_and_tiny_activations():
+    """SPLIT carries activations as fp16 hi / lo planes (|x| < 65504).  A codebook scaled so that the quantised vectors reach ~4e5 makes
+    the very first operand pass (post_quant_conv_b: no GroupNorm in front) meet values fp16 cannot hold: the call must not hand out NaNs
+    silently -- hqt_range_check raises HQT_ERR_RANGE, the reference-shaped surface raises with it, EXACT on the same weights still
+    matches the oracle, and the flag is cleared for the next call.  Scaled to ~4e-6 instead (hi planes are fp16 subnormals) the SPLIT
+    pixels stay within 1e-4 of the oracle."""
+    from hqtransformer_amd._lib import HqtError
+    spec = Stage1Spec(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=64, z_channels=64,
+                      embed_dim=32, n_embed=256)
+    base = synth.stage1_weights(spec, 33, 'fixture')
+    r = np.random.default_rng(34)
+    ct, cb = r.integers(0, 256, (2, 8, 8)), r.integers(0, 256, (2, 16, 16))
+    tct, tcb = torch.from_numpy(ct), torch.from_numpy(cb)
+    for scale, overflow in ((1e5, True), (1e-6, False)):
+        w = dict(base)
+        w['quantize_t.embedding'] = (base['quantize_t.embedding'] * np.float32(scale)).astype(np.float32)
+        w['quantize_b.embedding'] = (base['quantize_b.embedding'] * np.float32(scale)).astype(np.float32)
+        want = O.OracleStage1(spec, w).decode_code(ct, cb)
+        eng = engine_s1(spec, w, 2)
+        got = eng.decode(tct, tcb, precision=PRECISION_SPLIT)
+        if overflow:
+            with pytest.raises(HqtError) as ei:
+                eng.range_check()
+            assert ei.value.code == -7 and 'fp16 range' in str(ei.value)
+            assert bool(torch.isfinite(got).all()), 'saturation keeps the (invalid) output finite'
+            eng.range_check()                                              # cleared: nothing pending, nothing raised
+            exact = np_(eng.decode(tct, tcb, precision=PRECISION_EXACT))
+            eng.range_check()
+            assert np.abs(exact - want).max() <= PIXEL_TOL * max(1.0, float(np.abs(want).max()))
+            again = eng.decode(tct, tcb, precision=PRECISION_SPLIT)        # and a second offending call is reported again
+            with pytest.raises(HqtError):
+                eng.range_check()
+            del again
+        else:
+            eng.range_check()
+            assert np.abs(np_(got) - want).max() <= PIXEL_TOL, np.abs(np_(got) - want).max()
+
+
 def test_split_is_rejected_by_the_sampler():
     from tests.helpers import stage2_from_fixture
     fx = load('g4_tiny_cls.npz')

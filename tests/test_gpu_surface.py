@@ -314,3 +314,33 @@ def test_merged_steps_text_and_three_levels(cfg_name):
         got = [mct] + (list(mcb) if isinstance(mcb, (list, tuple)) else [mcb])
         assert len(got) == len(codes) and all(torch.equal(a, b) for a, b in zip(got, codes)), 'merged EXACT codes differ from the separate call'
         assert torch.equal(mpx, px)
+
+
+def test_merged_steps_reject_a_mismatched_step_without_losing_the_queue(model):
+    """Steps of one merged pass must share their settings.  The check runs when a step is SUBMITTED: the offending step raises and is
+    not queued, the steps already queued keep their Pending objects and run (a ValueError inside flush() used to orphan them), and
+    settings that hold tensors (given codes) are compared by value."""
+    from hqtransformer_amd.pipeline import InflightSampler
+    pipe = InflightSampler(model, lanes=2, merge=3)
+    a = pipe.submit(2, 3, seed=1, max_seq_len=8, use_fp16=False, precision='exact')
+    with pytest.raises(ValueError):
+        pipe.submit(2, 4, seed=2, max_seq_len=16, use_fp16=False, precision='exact')      # another max_seq_len
+    with pytest.raises(ValueError):
+        pipe.submit(2, 4, seed=2, max_seq_len=8, use_fp16=False, precision='exact', top_k_top=10)
+    given = torch.arange(8).reshape(1, 8) % model.stage2.spec.vocab_top
+    with pytest.raises(ValueError):
+        pipe.submit(2, 4, seed=2, max_seq_len=8, use_fp16=False, precision='exact', given_top_code=given)
+    b = pipe.submit(2, 5, seed=3, max_seq_len=8, use_fp16=False, precision='exact')
+    pipe.drain()
+    torch.cuda.synchronize()
+    ct_a, ct_b = a.get()[0], b.get()[0]
+    assert tuple(ct_a.shape) == (2, 8) and tuple(ct_b.shape) == (2, 8)
+    want = sampling_ihqgpt(model.stage2, 2, 3, use_fp16=False, is_tqdm=False, max_seq_len=8, seed=1)
+    assert (ct_a == want[0]).all()
+    # tensors inside the settings compare by value
+    pipe2 = InflightSampler(model, lanes=1, merge=2)
+    x = pipe2.submit(2, 3, seed=1, max_seq_len=8, use_fp16=False, precision='exact', given_top_code=given.clone())
+    y = pipe2.submit(2, 3, seed=2, max_seq_len=8, use_fp16=False, precision='exact', given_top_code=given.clone())
+    pipe2.drain()
+    torch.cuda.synchronize()
+    assert (x.get()[0] == given.to(x.get()[0].device)).all() and (y.get()[0] == given.to(y.get()[0].device)).all()
