@@ -151,7 +151,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 # kernels of split_stream_conv.hip whose main loop keeps inline-asm loads in flight across its back edge (mangled names)
-AUDITED_KERNELS = ('_Z27conv3x3_split_ring16_kernelILi0EEv8GemmArgs', '_Z26conv3x3_split_out16_kernel8GemmArgs')
+AUDITED_KERNELS = ('_Z27conv3x3_split_ring16_kernelILi0EEv8GemmArgs', '_Z25conv2x2_split_up16_kernelILi0EEv8GemmArgs', '_Z26conv3x3_split_out16_kernel8GemmArgs')
 
 
 def audit_hand_scheduled_loops(hipcc: str, flags: List[str], hdrs: List[str], force: bool = False, verbose: bool = False) -> None:

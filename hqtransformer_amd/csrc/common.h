@@ -181,6 +181,7 @@ struct GemmArgs {
     const void* Bw_lo;
     const void* Bw_frag;     // optional: the same filters packed in MFMA fragment order (split_stream_conv.hip)
     const void* Bw_frag16;   // optional: ... packed for v_mfma_f32_16x16x32_f16 (16-channel blocks; conv3x3_split_ring16_kernel)
+    const void* Bw_up16;     // optional, upsampling convs: the four 2x2 phase filters (pre-summed taps), packed like Bw_frag16 (conv2x2_split_up16_kernel)
     double* gn_part_out_d;
 };
 

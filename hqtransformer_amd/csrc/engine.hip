@@ -67,6 +67,7 @@ struct Lin {            // one nn.Linear / conv filter bank in every layout the 
     half_t* w16l = nullptr;
     half_t* wfrag = nullptr;      // 3x3 filters, hi + lo, packed in MFMA fragment order (split_stream_conv.hip)
     half_t* wfrag16 = nullptr;    // ... in 16-channel blocks for the 16x16x32 MFMA shape
+    half_t* wup16 = nullptr;      // upsampling convs: the four 2x2 phase filters (pre-summed taps), same packing
     bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)
     bf16_t* wpk_ln = nullptr;     // same packing of gamma o W (deferred LayerNorm), with its column sums and folded bias
     float* colsum = nullptr;
@@ -617,7 +618,7 @@ static int load_block(hqt_handle* h, const std::string& p, BlockW& b) {
     return HQT_OK;
 }
 
-static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int ksz, Lin& l) {
+static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int ksz, Lin& l, bool upsampling = false) {
     const float *w, *b;
     CHK(get_w(h, "stage1." + name + ".weight", {O, I, ksz, ksz}, &w));
     CHK(get_w(h, "stage1." + name + ".bias", {O}, &b));
@@ -634,6 +635,11 @@ static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int k
         if (O % 128 == 0 || O <= 16) {           // 16-channel-block packing: the ring16 kernel (whole 128-channel tiles) and conv_out
             CHK(dev_alloc(h, (void**)&l.wfrag16, split_frag_elems(O, I) * sizeof(half_t), false));
             HIPCHK(launch_pack_split_frag16(wt, l.wfrag16, O, I, 0));
+        }
+        if (upsampling && O % 128 == 0 && I % 64 == 0) {      // nearest x2 + 3x3 = four 2x2 phase convs on the low-resolution image
+            CHK(dev_alloc(h, (void**)&l.wup16, split_up_elems(O, I) * sizeof(half_t), false));
+            HIPCHK(hipMemset(l.wup16, 0, split_up_elems(O, I) * sizeof(half_t)));
+            HIPCHK(launch_pack_split_up16(wt, l.wup16, O, I, 0));
         }
     }
     return HQT_OK;
@@ -789,7 +795,7 @@ static int finalize_impl(hqt_handle* h) {
             CHK(load_conv(h, "post_quant_conv_b", c.s1_z_channels, 2 * E, 1, h->post_quant));
         }
         for (auto& l : h->dec) {
-            if (l.kind == 0 || l.kind == 3) CHK(load_conv(h, l.name, l.cout, l.cin, 3, l.conv1));
+            if (l.kind == 0 || l.kind == 3) CHK(load_conv(h, l.name, l.cout, l.cin, 3, l.conv1, l.kind == 3));
             else if (l.kind == 1) {
                 CHK(get_w(h, "stage1." + l.name + ".norm1.weight", {l.cin}, &l.n1_g));
                 CHK(get_w(h, "stage1." + l.name + ".norm1.bias", {l.cin}, &l.n1_b));
@@ -854,7 +860,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     snprintf(slot_name, sizeof slot_name, by_rows ? "%s@%d" : "%s", tag, g.M);
     Timed t(h, slot_name, st);
     if (g.Bw_lo) {                              // SPLIT: the caller packed the operand planes (s1_operand) after checking the shape
-        g.Bw = l.w16h; g.Bw_lo = l.w16l; g.Bw_frag = l.wfrag; g.Bw_frag16 = l.wfrag16;
+        g.Bw = l.w16h; g.Bw_lo = l.w16l; g.Bw_frag = l.wfrag; g.Bw_frag16 = l.wfrag16; g.Bw_up16 = l.wup16;
         if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
         if (g.conv_taps == 9) {
             if (g.store == STORE_ROWS && h->gn_tiles && conv_halo_stats_ok(g.N, 32)) {   // every such output is normalised next
@@ -1444,7 +1450,7 @@ struct S1Ctx {
 static bool split_shape_ok(const hqt_handle* h, const GemmArgs& g, const Lin& l) {
     if (!l.w16h) return false;
     GemmArgs t = g;
-    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l; t.Bw_frag = l.wfrag; t.Bw_frag16 = l.wfrag16;
+    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l; t.Bw_frag = l.wfrag; t.Bw_frag16 = l.wfrag16; t.Bw_up16 = l.wup16;
     if (t.lda == 0) t.lda = l.K;
     return t.conv_taps == 9 ? split_conv3_ok(t) : split_gemm_ok(t);
 }

@@ -39,6 +39,9 @@ hipError_t split_kernels_configure();             // raise the dynamic-LDS limit
 size_t split_frag_elems(int N, int Cin);          // fp16 elements of the packed hi + lo fragments of an [N][9 Cin] filter bank (Cin % 32 == 0)
 hipError_t launch_pack_split_frag(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);
 hipError_t launch_pack_split_frag16(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);   // 16-channel blocks (GemmArgs::Bw_frag16), same size
+// upsampling conv (nearest x2 + 3x3) as four 2x2 phase convolutions on the low-resolution image: pre-summed filters (GemmArgs::Bw_up16)
+size_t split_up_elems(int N, int Cin);
+hipError_t launch_pack_split_up16(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);
 bool split_stream_ok(const GemmArgs& g);          // g already passed split_conv3_ok
 int split_stream_tiles_per_image(const GemmArgs& g);
 hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st);

@@ -1000,6 +1000,309 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring16_kernel(GemmArgs g
 
 
 // ---------------------------------------------------------------------------------------------
+// Upsampling convolution (stage1/modules/layers.py:42-53: nearest x2, then a 3x3 'same' conv) as FOUR 2x2 convolutions on the
+// LOW-resolution image.  Output pixel (2 y + a, 2 x + b) sees, through its 3x3 window on the upsampled image, only the low-resolution
+// pixels of rows {y - 1 + a, y + a} and columns {x - 1 + b, x + b}; taps that land on the same source pixel are added up once, at
+// finalize (pack_split_up16_kernel):
+//     rows:  a = 0: [w0 | w1 + w2]     a = 1: [w0 + w1 | w2]      (columns alike with b)
+// The same sums as the reference, regrouped -- 4 multiply-adds per output and input channel instead of 9 (2.25x fewer MFMAs on 36 % of
+// the decoder's convolution work), no approximation beyond the rounding of the summed filters, which are split into hi / lo like any
+// other.  Zero padding carries over: row -1 / H of the low-resolution image is exactly what rows -1 / 2 H of the upsampled one are.
+// Kernel = conv3x3_split_ring16_kernel with a workgroup = an 8 x 16 tile of LOW-resolution pixels x 128 channels of ONE phase (a, b)
+// (grid.x = 4 phases x N / 128), the same (8 + 2) x (16 + 2) patch image, 4 taps per 32-channel chunk at patch offsets (a + ty, b + tx);
+// with a chunk only 4 taps long the six patch pieces of the next chunk are fetched at taps 0, 1 (three each) and written at taps 2, 3,
+// and the filters run ONE tap ahead (ring of 2: 32 registers) -- the second workgroup of the CU covers what that exposes.
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_split_up16_kernel(const float* __restrict__ w, half_t* __restrict__ out, int N, int Cin, size_t total) {
+    const int NC = Cin / 32, NG = (N + 31) / 32;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        size_t ch = i >> 9;
+        const int plane = (int)(ch & 1); ch >>= 1;
+        const int blk = (int)(ch & 1); ch >>= 1;
+        const int tap = (int)(ch & 3); ch >>= 2;
+        const int c = (int)(ch % NC); ch /= NC;
+        const int t = (int)(ch % NG);
+        const int phase = (int)(ch / NG);
+        const int pa = phase >> 1, pb = phase & 1, ty = tap >> 1, tx = tap & 1;
+        const int n = t * 32 + blk * 16 + (lane & 15), kin = c * 32 + 8 * (lane >> 4) + j;
+        // 3x3 taps that fall on low-resolution offset ty (tx) for phase pa (pb)
+        const int ky0 = pa == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = pa == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+        const int kx0 = pb == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = pb == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+        double x = 0.0;
+        if (n < N)
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) x += (double)w[(size_t)n * 9 * Cin + (size_t)(ky * 3 + kx) * Cin + kin];
+        const half_t hi = (half_t)(float)x;
+        out[i] = plane ? (half_t)(float)((x - (double)(float)hi) * 2048.0) : hi;
+    }
+}
+// 4 phases x ceil(N / 32) channel groups x NC chunks x 4 taps x 4 KiB (+ one tap of padding: the filters run one tap ahead)
+size_t split_up_elems(int N, int Cin) { return (size_t)4 * ((N + 31) / 32) * (Cin / 32) * 4 * 2048 + 2048; }
+hipError_t launch_pack_split_up16(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st) {
+    const size_t total = split_up_elems(N, Cin) - 2048;
+    pack_split_up16_kernel<<<(int)std::min<size_t>((total + 255) / 256, 8192), 256, 0, st>>>(w_tapmajor, out, N, Cin, total);
+    return hipGetLastError();
+}
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv2x2_split_up16_kernel(GemmArgs g) {
+    constexpr int NI = 8, TAPS = 4;                                 // pixel blocks = tile rows; taps per chunk
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fx = lane & 15, fk = lane >> 4;
+    int tile_m, tile_v;
+    r_xcd_tile(tile_m, tile_v);
+    const int NT = g.N / 128;                                       // real 128-channel tiles; the grid is 4 NT wide
+    const int phase = tile_v / NT, pa = phase >> 1, pb = phase & 1;
+    const int n0 = (tile_v - phase * NT) * 128;
+    const int Hin = g.H >> 1, Win = g.W >> 1;                       // g.H / g.W: the OUTPUT
+    const int tiles_x = Win / R_TX, tiles_y = Hin / R_TY;
+    const int img = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * R_TY, tx0 = (trem % tiles_x) * R_TX;     // low-resolution pixels
+    const half_t* Abase = reinterpret_cast<const half_t*>(g.A);                 // [pixel][hi Cin | lo Cin]
+    const int NC = g.Cin / 32;
+
+    // ---- patch pieces: the (8 + 2) x (16 + 2) low-resolution neighbourhood, as in the ring kernels
+    constexpr int PPW = 2 * R_PIECES / 4;
+    static_assert(PPW == 6, "six pieces per wave and chunk");
+    typedef int rsrc_t __attribute__((ext_vector_type(4)));
+    rsrc_t img_rsrc;
+    {
+        const unsigned long long ib = (unsigned long long)(size_t)(Abase + (long long)img * Hin * Win * (2 * g.Cin));
+        img_rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ib);
+        img_rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ib >> 32) & 0xffff);      // stride 0
+        img_rsrc[2] = __builtin_amdgcn_readfirstlane(Hin * Win * 2 * g.Cin * 2);               // bytes
+        img_rsrc[3] = 0x00020000;                                                              // raw buffer, 32-bit data format (gfx9)
+    }
+    unsigned poff[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int piece = wave + 4 * u;
+        const int q = piece * 16 + (lane >> 2);
+        const int qy = (q * 3641) >> 16, qx = q - qy * R_PITCH;                 // q / 18 for q < 192
+        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+        const bool in = (q < R_ROWS) & ((unsigned)iy < (unsigned)Hin) & ((unsigned)ix < (unsigned)Win);
+        const unsigned off = (unsigned)(((iy * Win + ix) * (2 * g.Cin) + (lane & 3) * 8) * 2);
+        poff[u] = in ? off : 0x80000000u;
+    }
+    u32x4 pst[PPW];                                                 // the six pieces of the next chunk: loaded at taps 0 / 1, written at taps 2 / 3
+    unsigned piece_base = lds_base + wave * (16 * G_PITCH) + (lane >> 2) * G_PITCH + (lane & 3) * 16;
+    auto load_piece = [&](int c, int u) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pst[u]) : "v"(poff[u % 3]), "s"(img_rsrc), "s"(c * 64 + (u / 3) * g.Cin * 2));
+    };
+#define HQT_STORE_PIECE(buf, u)                                                                                                \
+    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(piece_base), "v"(pst[u]),                                            \
+                 "n"(((buf) * 2 + (u) / 3) * G_PLANE + 4 * ((u) % 3) * 16 * G_PITCH) : "memory")
+
+    // this wave's filter stream: 4 KiB per tap ([block 0 hi][block 0 lo][block 1 hi][block 1 lo]), 4 taps per chunk
+    const char* bfrag = reinterpret_cast<const char*>(reinterpret_cast<const half_t*>(g.Bw_up16) +
+                                                      ((size_t)phase * (g.N / 32) + n0 / 32 + wave) * ((size_t)NC * TAPS * 2048));
+    unsigned lane16 = lane * 16;
+
+    f32x4 accm[NI][2], accx[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accm[i][j][r] = 0.0f; accx[i][j][r] = 0.0f; }
+    // fragment of pixel block i at tap (ty, tx) of phase (pa, pb): patch row (i + pa + ty) * 18 + fx + pb + tx -- the phase goes into the base
+    const unsigned abase = lds_base + (fx + pa * R_PITCH + pb) * G_PITCH + fk * 16;
+    half8 ah[4], al[4];                                             // pixel blocks in flight: slot = block % 4
+    half8 wh[2][2], wl[2][2];                                       // filter fragments [tap % 2][channel block]
+#define HQT_READ_A16(ps, tapoff, i)                                                                                            \
+    do {                                                                                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ah[(i) % 4]) : "v"(abase), "n"((ps) * 2 * G_PLANE + ((i) * R_PITCH + (tapoff)) * G_PITCH));            \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[(i) % 4]) : "v"(abase), "n"((ps) * 2 * G_PLANE + ((i) * R_PITCH + (tapoff)) * G_PITCH + G_PLANE));  \
+    } while (0)
+    auto load_b = [&](long long S, int slot) {
+        const char* p = bfrag + S * 4096;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wh[slot][0]) : "v"(lane16), "s"(p));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(wl[slot][0]) : "v"(lane16), "s"(p));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(wh[slot][1]) : "v"(lane16), "s"(p));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(wl[slot][1]) : "v"(lane16), "s"(p));
+    };
+
+    // ---- prologue: the first patch through the piece registers, the filters of tap 0; everything lands first
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) load_piece(0, u);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pst[0]), "+v"(pst[1]), "+v"(pst[2]), "+v"(pst[3]), "+v"(pst[4]), "+v"(pst[5]));
+    HQT_STORE_PIECE(0, 0); HQT_STORE_PIECE(0, 1); HQT_STORE_PIECE(0, 2); HQT_STORE_PIECE(0, 3); HQT_STORE_PIECE(0, 4); HQT_STORE_PIECE(0, 5);
+    load_b(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    // ---- main loop: one iteration = two chunks = 8 taps of straight-line code.  Vector-memory operations in issue order per tap t:
+    //      [filters of tap t + 1: 4] then, at taps 0 and 1, [three pieces].  They retire in that order, so the wait for the filters of
+    //      tap t (issued at tap t - 1) leaves 3 younger loads in flight behind taps 0 / 1 and none behind taps 2 / 3 -- by then every
+    //      piece has landed too, and the ds_writes at taps 2 / 3 need no wait of their own (the asm operands still carry the dependence).
+#pragma unroll 1
+    for (int c0 = 0; c0 < NC; c0 += 2) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = c0 + cc, cn = min(c + 1, NC - 1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (ABL != 4) { HQT_READ_A16(cc, 0, 0); HQT_READ_A16(cc, 0, 1); HQT_READ_A16(cc, 0, 2); HQT_READ_A16(cc, 0, 3); }
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int s = cc * TAPS + tap, slot = s % 2, nslot = (s + 1) % 2;
+                const long long S = (long long)c0 * TAPS + s;
+                const int tapoff = (tap / 2) * R_PITCH + tap % 2, ntapoff = ((tap + 1) / 2) * R_PITCH + (tap + 1) % 2;
+                if (ABL != 4) {
+                    if (tap == 1 || tap == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(wh[slot][0]), "+v"(wl[slot][0]), "+v"(wh[slot][1]), "+v"(wl[slot][1]));
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wh[slot][0]), "+v"(wl[slot][0]), "+v"(wh[slot][1]), "+v"(wl[slot][1]));
+                }
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int i0 = 2 * pr, i1 = 2 * pr + 1;
+                    if (ABL != 4) {
+                        const bool more = !(tap == TAPS - 1 && pr == 3);       // the last pair of a chunk has nothing behind it
+                        if (more) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[i0 % 4]), "+v"(al[i0 % 4]), "+v"(ah[i1 % 4]), "+v"(al[i1 % 4]));
+                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[i0 % 4]), "+v"(al[i0 % 4]), "+v"(ah[i1 % 4]), "+v"(al[i1 % 4]));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            accm[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][j], ah[(i0 + ii) % 4], accm[i0 + ii][j], 0, 0, 0);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            accx[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[slot][j], al[(i0 + ii) % 4], accx[i0 + ii][j], 0, 0, 0);
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            accx[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[slot][j], ah[(i0 + ii) % 4], accx[i0 + ii][j], 0, 0, 0);
+                    if (ABL == 4) continue;
+                    // the piece written here goes in FRONT of the fragment reads: lgkmcnt(4) of the next pair then covers exactly those reads
+                    if (pr >= 1 && tap >= 2 && ABL != 2) {
+                        const int u = 3 * (tap - 2) + pr - 1;
+                        asm volatile("s_waitcnt vmcnt(4)" : "+v"(pst[u]));      // (already true: see above)
+                        if (u == 0) HQT_STORE_PIECE(cc ^ 1, 0); else if (u == 1) HQT_STORE_PIECE(cc ^ 1, 1); else if (u == 2) HQT_STORE_PIECE(cc ^ 1, 2);
+                        else if (u == 3) HQT_STORE_PIECE(cc ^ 1, 3); else if (u == 4) HQT_STORE_PIECE(cc ^ 1, 4); else HQT_STORE_PIECE(cc ^ 1, 5);
+                    }
+                    // refill the two slots: blocks (i0 + 4, i1 + 4) of this tap, or blocks (i0 - 4, i1 - 4) of the next tap
+                    if (pr < 2) {
+                        if (pr == 0) { HQT_READ_A16(cc, tapoff, 4); HQT_READ_A16(cc, tapoff, 5); }
+                        else { HQT_READ_A16(cc, tapoff, 6); HQT_READ_A16(cc, tapoff, 7); }
+                    } else if (tap < TAPS - 1) {
+                        if (pr == 2) { HQT_READ_A16(cc, ntapoff, 0); HQT_READ_A16(cc, ntapoff, 1); }
+                        else { HQT_READ_A16(cc, ntapoff, 2); HQT_READ_A16(cc, ntapoff, 3); }
+                    }
+                    if (pr == 0) load_b(S + 1, nslot);                  // the slot tap s - 1 released takes the filters of tap s + 1
+                    if (pr >= 1 && tap < 2 && ABL != 2) load_piece(cn, 3 * tap + pr - 1);
+                }
+            }
+        }
+    }
+#undef HQT_READ_A16
+#undef HQT_STORE_PIECE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // the patch buffers become the epilogue's staging area
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 1) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc += accm[i][j][r] + accx[i][j][r];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
+        return;
+    }
+    // ---- epilogue: as the ring16 kernel, with low-resolution tile pixel (row, col) stored at output pixel (2 (ty0 + row) + pa, 2 (tx0 + col) + pb)
+    char* stage = lds_raw;
+    float* Cb = reinterpret_cast<float*>(g.C);
+    const float* Rb = reinterpret_cast<const float*>(g.resid);
+    const int c8 = (tid & 15) * 8, nn = n0 + c8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (g.bias && nn + e < g.N) ? g.bias[nn + e] : 0.0f;
+    float gs[8], gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half > 0) __syncthreads();                  // the previous half has been read back
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = half * 4 + ii, r = ii * 16 + fx;      // pixel within the staged 64
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nl = wave * 32 + j * 16 + 4 * fk;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = accm[i][j][e] + accx[i][j][e] * R_INV;
+                *reinterpret_cast<f32x4*>(stage + r * R_CPITCH + nl * 4) = v;
+            }
+        }
+        __syncthreads();
+        if (nn < g.N) {                                 // N % 8 == 0
+            long long moff[4];
+            f32x4 r0[4], r1[4];
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int r = p4 * 16 + (tid >> 4);
+                const long long oy = 2 * (ty0 + half * 4 + (r >> 4)) + pa, ox = 2 * (tx0 + (r & 15)) + pb;
+                moff[p4] = (((long long)img * g.H + oy) * g.W + ox) * g.ldc + nn;
+                if (Rb) { r0[p4] = *reinterpret_cast<const f32x4*>(Rb + moff[p4]); r1[p4] = *reinterpret_cast<const f32x4*>(Rb + moff[p4] + 4); }
+            }
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int r = p4 * 16 + (tid >> 4);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * R_CPITCH + c8 * 4);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * R_CPITCH + c8 * 4 + 16);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
+                if (Rb) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += r0[p4][e]; v[4 + e] += r1[p4][e]; }
+                }
+                const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *reinterpret_cast<f32x4*>(Cb + moff[p4]) = o0;
+                *reinterpret_cast<f32x4*>(Cb + moff[p4] + 4) = o1;
+                if (g.gn_part_out_d) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
+                }
+            }
+        }
+    }
+    if (g.gn_part_out_d) {                              // uniform branch (kernel argument): barriers are safe here
+        __syncthreads();
+        float* redw = reinterpret_cast<float*>(lds_raw);                    // [16 pixel rows][128 channels][2]; zeros from idle threads
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
+            redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
+        }
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(lds_raw);
+        if (tid < 128) {
+            double sa = 0.0, sq = 0.0;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) { sa += (double)red[((rg * 128) + tid) * 2]; sq += (double)red[((rg * 128) + tid) * 2 + 1]; }
+            const int cpg = g.N / g.gn_out_groups;
+            for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
+            const int ch = n0 + tid;
+            if (ch < g.N && (tid & (cpg - 1)) == 0) {       // one partial per (low-resolution tile, phase): 4 tiles_x tiles_y per image
+                double* pp = g.gn_part_out_d + ((((long long)img * (tiles_x * tiles_y) + trem) * 4 + phase) * g.gn_out_groups + ch / cpg) * 2;
+                pp[0] = sa; pp[1] = sq;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // conv_out (C_in -> 3 channels, NCHW fp32 + clamp) on the ring16 structure: the output channels are padded to ONE 16-channel MFMA block
 // (32 in the stream kernel's variant: 10x the matrix work the 3 channels need, 36 % pipe utilisation), so the four waves of a tile split
 // its PIXELS: wave w owns tile rows 2 w and 2 w + 1 (2 pixel blocks x 1 channel block: 6 MFMAs per tap) and all of them fetch the same
@@ -1157,12 +1460,20 @@ bool split_stream_ok(const GemmArgs& g) {
     if (g.store == STORE_NCHW) return g.N <= 32;
     return g.N % 128 == 0 && g.ldc % 8 == 0;              // whole 128-channel tiles (the packed fragments hold ceil(N / 32) n-tiles)
 }
-int split_stream_tiles_per_image(const GemmArgs& g) { return (g.H / R_TY) * (g.W / R_TX); }
+// upsampling conv as four 2x2 phase convolutions on the low-resolution image (conv2x2_split_up16_kernel)
+static bool split_up_shape(const GemmArgs& g) {
+    static const bool off = getenv("HQT_SPLIT_UP") && atoi(getenv("HQT_SPLIT_UP")) == 0;              // A/B switch: 0 = nine taps on the upsampled image
+    return !off && g.upsample == 1 && g.Bw_up16 && g.store == STORE_ROWS && (g.H / 2) % R_TY == 0 && (g.W / 2) % R_TX == 0 && g.N % 128 == 0;
+}
+int split_stream_tiles_per_image(const GemmArgs& g) { return split_up_shape(g) ? 4 * (g.H / 2 / R_TY) * (g.W / 2 / R_TX) : (g.H / R_TY) * (g.W / R_TX); }
 hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st) {
     if (g.store == STORE_NCHW) {
         static const bool out16 = !(getenv("HQT_SPLIT_OUT16") && atoi(getenv("HQT_SPLIT_OUT16")) == 0);     // A/B switch: 0 = the 32-channel stream variant
         if (out16 && g.Bw_frag16 && g.N <= 16) conv3x3_split_out16_kernel<<<dim3(1, g.M / (R_TY * R_TX), 1), 256, G_LDS, st>>>(g);
         else conv3x3_split_stream_kernel<true, 32><<<dim3(1, g.M / (R_TY * R_TX), 1), 256, R_LDS, st>>>(g);
+    }
+    else if (split_up_shape(g)) {
+        conv2x2_split_up16_kernel<0><<<dim3(4 * (g.N / 128), g.M / 4 / (R_TY * R_TX), 1), 256, G_LDS, st>>>(g);
     }
     else {
         static const bool ring = !(getenv("HQT_SPLIT_RING") && atoi(getenv("HQT_SPLIT_RING")) == 0);     // A/B switch: 0 = the stream kernel
@@ -1180,6 +1491,8 @@ hipError_t split_stream_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_ring_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_ring16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2x2_split_up16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_out16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;

@@ -201,6 +201,53 @@ def test_split_range_check_large_and_tiny_activations():
             assert np.abs(np_(got) - want).max() <= PIXEL_TOL, np.abs(np_(got) - want).max()
 
 
+def test_upsampling_conv_as_four_phase_convs_matches_the_nine_tap_form():
+    """The nearest-x2 upsampling convs run as four 2x2 convolutions on the low-resolution image with pre-summed taps
+    (conv2x2_split_up16_kernel: the same sums as layers.py:42-53, regrouped).  HQT_SPLIT_UP=0 switches back to nine taps on the
+    upsampled image (conv3x3_split_ring16_kernel); both must sit within 1e-4 of the oracle, and within 2e-5 of each other, on a
+    decoder whose three upsampling convs all take the phase kernel -- borders, the 16-pixel-wide single-tile case and GroupNorm
+    statistics from the phase partials included."""
+    import subprocess
+    import sys
+    import tempfile
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from hqtransformer_amd import synth
+from hqtransformer_amd._lib import PRECISION_SPLIT
+from hqtransformer_amd.engine import Engine
+from hqtransformer_amd.spec import Stage1Spec
+spec = Stage1Spec(ch=128, ch_mult=[1, 1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=128, z_channels=64, embed_dim=32, n_embed=256, use_init_downsample=True)
+w = synth.stage1_weights(spec, 41, 'fixture')
+r = np.random.default_rng(42)
+ct, cb = r.integers(0, 256, (3, 8, 8)), r.integers(0, 256, (3, 16, 16))
+e = Engine(None, spec, torch.device('cuda:0'), 3); e.load(stage1=w); e.finalize()
+e.timing(True); e.timing_reset()
+px = e.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_SPLIT)
+torch.cuda.synchronize()
+np.save(sys.argv[1], px.cpu().numpy())
+""" % ROOT
+    spec = Stage1Spec(ch=128, ch_mult=[1, 1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=128, z_channels=64,
+                      embed_dim=32, n_embed=256, use_init_downsample=True)
+    assert spec.z_res == 16
+    weights = synth.stage1_weights(spec, 41, 'fixture')
+    r = np.random.default_rng(42)
+    ct, cb = r.integers(0, 256, (3, 8, 8)), r.integers(0, 256, (3, 16, 16))
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (('phase', {}), ('nine', {'HQT_SPLIT_UP': '0'})):
+            path = os.path.join(tmp, name + '.npy')
+            rr = subprocess.run([sys.executable, '-c', code, path], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert rr.returncode == 0, (name, rr.stdout[-1500:], rr.stderr[-1500:])
+            out[name] = np.load(path)
+    for name, px in out.items():
+        err = np.abs(px - want).max()
+        assert err <= PIXEL_TOL, (name, err)
+    assert np.abs(out['phase'] - out['nine']).max() <= 2e-5
+    assert not np.array_equal(out['phase'], out['nine']), 'HQT_SPLIT_UP=0 did not change the kernel'
+
+
 def test_split_is_rejected_by_the_sampler():
     from tests.helpers import stage2_from_fixture
     fx = load('g4_tiny_cls.npz')

@@ -322,25 +322,25 @@ def test_merged_steps_reject_a_mismatched_step_without_losing_the_queue(model):
     settings that hold tensors (given codes) are compared by value."""
     from hqtransformer_amd.pipeline import InflightSampler
     pipe = InflightSampler(model, lanes=2, merge=3)
-    a = pipe.submit(2, 3, seed=1, max_seq_len=8, use_fp16=False, precision='exact')
+    a = pipe.submit(2, 3, seed=1, max_seq_len=64, use_fp16=False, precision='exact')
     with pytest.raises(ValueError):
-        pipe.submit(2, 4, seed=2, max_seq_len=16, use_fp16=False, precision='exact')      # another max_seq_len
+        pipe.submit(2, 4, seed=2, max_seq_len=32, use_fp16=False, precision='exact')      # another max_seq_len
     with pytest.raises(ValueError):
-        pipe.submit(2, 4, seed=2, max_seq_len=8, use_fp16=False, precision='exact', top_k_top=10)
-    given = torch.arange(8).reshape(1, 8) % model.stage2.spec.vocab_top
+        pipe.submit(2, 4, seed=2, max_seq_len=64, use_fp16=False, precision='exact', top_k_top=10)
+    given = torch.arange(64).reshape(1, 64) % model.stage2.spec.vocab_top
     with pytest.raises(ValueError):
-        pipe.submit(2, 4, seed=2, max_seq_len=8, use_fp16=False, precision='exact', given_top_code=given)
-    b = pipe.submit(2, 5, seed=3, max_seq_len=8, use_fp16=False, precision='exact')
+        pipe.submit(2, 4, seed=2, max_seq_len=64, use_fp16=False, precision='exact', given_top_code=given)
+    b = pipe.submit(2, 5, seed=3, max_seq_len=64, use_fp16=False, precision='exact')
     pipe.drain()
     torch.cuda.synchronize()
     ct_a, ct_b = a.get()[0], b.get()[0]
-    assert tuple(ct_a.shape) == (2, 8) and tuple(ct_b.shape) == (2, 8)
-    want = sampling_ihqgpt(model.stage2, 2, 3, use_fp16=False, is_tqdm=False, max_seq_len=8, seed=1)
+    assert tuple(ct_a.shape) == (2, 64) and tuple(ct_b.shape) == (2, 64)
+    want = sampling_ihqgpt(model.stage2, 2, 3, use_fp16=False, is_tqdm=False, max_seq_len=64, seed=1)
     assert (ct_a == want[0]).all()
     # tensors inside the settings compare by value
     pipe2 = InflightSampler(model, lanes=1, merge=2)
-    x = pipe2.submit(2, 3, seed=1, max_seq_len=8, use_fp16=False, precision='exact', given_top_code=given.clone())
-    y = pipe2.submit(2, 3, seed=2, max_seq_len=8, use_fp16=False, precision='exact', given_top_code=given.clone())
+    x = pipe2.submit(2, 3, seed=1, max_seq_len=64, use_fp16=False, precision='exact', given_top_code=given.clone())
+    y = pipe2.submit(2, 3, seed=2, max_seq_len=64, use_fp16=False, precision='exact', given_top_code=given.clone())
     pipe2.drain()
     torch.cuda.synchronize()
     assert (x.get()[0] == given.to(x.get()[0].device)).all() and (y.get()[0] == given.to(y.get()[0].device)).all()

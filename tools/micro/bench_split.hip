@@ -79,11 +79,25 @@ static float run_ring16(const GemmArgs& g, hipStream_t st, int reps) {
     return 1000.f * ms / reps;
 }
 
+template <int ABL>
+static float run_up16(const GemmArgs& g, hipStream_t st, int reps) {
+    const dim3 grid(4 * (g.N / 128), g.M / 4 / 128, 1);
+    void (*k)(GemmArgs) = conv2x2_split_up16_kernel<ABL>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+    k<<<grid, 256, G_LDS, st>>>(g);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) k<<<grid, 256, G_LDS, st>>>(g);
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return 1000.f * ms / reps;
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 64;
     hipStream_t st; CK(hipStreamCreate(&st));
     const Shape shapes[] = {
-        {"res16  512->512", 16, 512, 512, 0}, {"res32  512->512", 32, 512, 512, 0}, {"up64   512->512 (x2)", 64, 512, 512, 1},
+        {"res16  512->512", 16, 512, 512, 0}, {"up32   512->512 (x2)", 32, 512, 512, 1}, {"res32  512->512", 32, 512, 512, 0}, {"up64   512->512 (x2)", 64, 512, 512, 1},
         {"res64  256->256", 64, 256, 256, 0}, {"up128  256->256 (x2)", 128, 256, 256, 1}, {"res128 128->128", 128, 128, 128, 0},
         {"up256  128->128 (x2)", 256, 128, 128, 1},
     };
@@ -111,7 +125,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(W32, wf.data(), wmax * 4, hipMemcpyHostToDevice));
     }
     printf("%-22s %8s | %7s %7s %7s | %7s %7s %7s %7s | %7s %7s\n", "layer (batch 64)", "GF x3", "pc1 us", "TF eq", "pc0 us", "no-epi", "no-dma", "dma", "mfma", "pc0nodma", "pc0 mfma");
-    double tot = 0, totf = 0, tot_stream = 0, tot_ring = 0, tot_ring16 = 0;
+    double tot = 0, totf = 0, tot_stream = 0, tot_ring = 0, tot_ring16 = 0, tot_up16 = 0;
     for (const Shape& s : shapes) {
         GemmArgs g{};
         g.A = A; g.conv_taps = 9; g.H = s.res; g.W = s.res; g.Cin = s.cin; g.upsample = s.up;
@@ -139,6 +153,16 @@ int main(int argc, char** argv) {
             const float h0 = run_ring16<0>(gh, st, reps), h1 = run_ring16<1>(gh, st, reps), h2 = run_ring16<2>(gh, st, reps), h4 = run_ring16<4>(gh, st, reps);
             printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f\n", "   ring16 (16x16x32 MFMA)", "", h0, fl / h0 * 1e-6, "", h1, h2, "", h4);
             tot_ring16 += h0;
+            if (s.up) {       // the same layer as four 2x2 phase convolutions on the low-resolution image (4 / 9 of the MFMAs)
+                static half_t* Wup = nullptr;
+                if (!Wup) CK(hipMalloc(&Wup, split_up_elems(512, 512) * 2));
+                CK(hipMemset(Wup, 0, split_up_elems(512, 512) * 2));
+                CK(launch_pack_split_up16(W32, Wup, s.cout, s.cin, st));
+                GemmArgs gu = gh; gu.Bw_up16 = Wup;
+                const float u0 = run_up16<0>(gu, st, reps), u1 = run_up16<1>(gu, st, reps), u2 = run_up16<2>(gu, st, reps), u4 = run_up16<4>(gu, st, reps);
+                printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f   (TF eq of the 9-tap work: %.1f)\n", "   up16 (4 phases x 2x2 taps)", "", u0, fl * 4 / 9 / u0 * 1e-6, "", u1, u2, "", u4, fl / u0 * 1e-6);
+                tot_up16 += u0;
+            } else tot_up16 += h0;
         }
         {
             static long long* dbg = nullptr;
@@ -153,6 +177,6 @@ int main(int argc, char** argv) {
         }
         tot += std::min(t0, w0); totf += fl;
     }
-    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent; stream kernel: %.1f us, %.1f; ring kernel: %.1f us, %.1f; ring16: %.1f us, %.1f\n", tot, totf / tot * 1e-6, tot_stream, totf / tot_stream * 1e-6, tot_ring, totf / tot_ring * 1e-6, tot_ring16, totf / tot_ring16 * 1e-6);
+    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent; stream kernel: %.1f us, %.1f; ring kernel: %.1f us, %.1f; ring16: %.1f us, %.1f; ring16 + up16: %.1f us\n", tot, totf / tot * 1e-6, tot_stream, totf / tot_stream * 1e-6, tot_ring, totf / tot_ring * 1e-6, tot_ring16, totf / tot_ring16 * 1e-6, tot_up16);
     return 0;
 }
