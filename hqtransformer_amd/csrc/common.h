@@ -171,16 +171,11 @@ struct GemmArgs {
     float* gn_part_out;
     int gn_out_groups;
     int tune;                // 0: latency-oriented tile choice, 1: throughput-oriented (hqt_set_policy)
-    // ---- in-kernel split-K of the streaming GEMM (gridDim.z = S > 1 with xs_ctr set): every workgroup publishes its fp32
-    //      partial tile to slab z with agent-scope stores, then bumps xs_ctr[tile]; the last arriver of a tile sums the S
-    //      partials in z order (deterministic), resets the counter and runs the fused epilogue.  No workgroup waits.
-    unsigned* xs_ctr;        // [gridDim.x * gridDim.y] zeros between launches
     int w_nt;                // streaming GEMM: 1 = fetch the weights with the non-temporal hint (read once), 0 = ordinary loads (re-read soon)
     // ---- SPLIT precision (split_kernels.h): A holds fp16 [row][hi K | lo K] planes, Bw the hi filters, Bw_lo the lo filters;
     //      C / resid are fp32.  gn_part_out_d: per-tile GroupNorm partials of the fp32 output as doubles (layout of gn_part_out).
     const void* Bw_lo;
-    const void* Bw_frag;     // optional: the same filters packed in MFMA fragment order (split_stream_conv.hip)
-    const void* Bw_frag16;   // optional: ... packed for v_mfma_f32_16x16x32_f16 (16-channel blocks; conv3x3_split_ring16_kernel)
+    const void* Bw_frag16;   // optional: the same 3x3 filters packed in MFMA fragment order for v_mfma_f32_16x16x32_f16 (16-channel blocks; conv3x3_split_ring16_kernel)
     const void* Bw_up16;     // optional, upsampling convs: the four 2x2 phase filters (pre-summed taps), packed like Bw_frag16 (conv2x2_split_up16_kernel)
     double* gn_part_out_d;
 };

@@ -65,8 +65,7 @@ struct Lin {            // one nn.Linear / conv filter bank in every layout the 
     bf16_t* w16 = nullptr;        // [N, K] bf16 row-major (FAST generic + conv MFMA)
     half_t* w16h = nullptr;       // [N, K] fp16 hi / lo planes of w32 (SPLIT convolutions: split_kernels.h)
     half_t* w16l = nullptr;
-    half_t* wfrag = nullptr;      // 3x3 filters, hi + lo, packed in MFMA fragment order (split_stream_conv.hip)
-    half_t* wfrag16 = nullptr;    // ... in 16-channel blocks for the 16x16x32 MFMA shape
+    half_t* wfrag16 = nullptr;    // 3x3 filters, hi + lo, packed in MFMA fragment order (16-channel blocks of v_mfma_f32_16x16x32_f16; split_stream_conv.hip)
     half_t* wup16 = nullptr;      // upsampling convs: the four 2x2 phase filters (pre-summed taps), same packing
     bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)
     bf16_t* wpk_ln = nullptr;     // same packing of gamma o W (deferred LayerNorm), with its column sums and folded bias
@@ -119,7 +118,6 @@ struct hqt_handle {
     int resid_nparts = 0;                     // partial row statistics the last STORE_RESID GEMM left per row (run_linear)
     bool tile_gemm = true;                    // merged passes through the LDS-tiled MFMA kernels (HQT_NO_TILE_GEMM=1: streaming kernels at every row count)
     float* splitk = nullptr;                  // split-K partial slabs of the streaming GEMM
-    unsigned* xs_ctr = nullptr;               // arrival counters of the in-kernel split-K (zero between launches)
     int cur_w_nt = 0;                         // GemmArgs.w_nt of the streaming GEMMs being issued (set per block)
     size_t splitk_elems = 0;
     struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
@@ -409,8 +407,6 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), &h->dv, dkv, true));
         h->splitk_elems = (size_t)16 * rows * (size_t)std::max<size_t>(4 * D, (size_t)c.vocab_top);
         CHK(dev_alloc(h.get(), (void**)&h->splitk, h->splitk_elems * 4, true));
-        CHK(dev_alloc(h.get(), (void**)&h->xs_ctr, 4096 * 4, true));
-        HIPCHK(hipMemset(h->xs_ctr, 0, 4096 * 4));
         CHK(dev_alloc(h.get(), (void**)&h->state, sizeof(StepState), true));
         CHK(dev_alloc(h.get(), (void**)&h->rows, B * sizeof(RowKey), true));
         CHK(dev_alloc(h.get(), (void**)&h->cond_buf, B * (size_t)std::max(1, c.cond_type == HQT_COND_TEXT ? c.ctx_len_txt : 1) * 8, true));
@@ -629,10 +625,8 @@ static int load_conv(hqt_handle* h, const std::string& name, int O, int I, int k
         HIPCHK(launch_repack_conv(w, wt, O, I, taps, 0));
     }
     CHK(make_lin(h, l, wt, b, O, I * taps, false, true));
-    if (taps == 9 && I % 32 == 0) {              // fragment-packed copy for the streaming SPLIT kernel
-        CHK(dev_alloc(h, (void**)&l.wfrag, split_frag_elems(O, I) * sizeof(half_t), false));
-        HIPCHK(launch_pack_split_frag(wt, l.wfrag, O, I, 0));
-        if (O % 128 == 0 || O <= 16) {           // 16-channel-block packing: the ring16 kernel (whole 128-channel tiles) and conv_out
+    if (taps == 9 && I % 32 == 0) {              // fragment-packed copies for the ring kernels (whole 128-channel tiles; conv_out: one 16-channel block)
+        if (O % 128 == 0 || O <= 16) {
             CHK(dev_alloc(h, (void**)&l.wfrag16, split_frag_elems(O, I) * sizeof(half_t), false));
             HIPCHK(launch_pack_split_frag16(wt, l.wfrag16, O, I, 0));
         }
@@ -860,7 +854,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     snprintf(slot_name, sizeof slot_name, by_rows ? "%s@%d" : "%s", tag, g.M);
     Timed t(h, slot_name, st);
     if (g.Bw_lo) {                              // SPLIT: the caller packed the operand planes (s1_operand) after checking the shape
-        g.Bw = l.w16h; g.Bw_lo = l.w16l; g.Bw_frag = l.wfrag; g.Bw_frag16 = l.wfrag16; g.Bw_up16 = l.wup16;
+        g.Bw = l.w16h; g.Bw_lo = l.w16l; g.Bw_frag16 = l.wfrag16; g.Bw_up16 = l.wup16;
         if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
         if (g.conv_taps == 9) {
             if (g.store == STORE_ROWS && h->gn_tiles && conv_halo_stats_ok(g.N, 32)) {   // every such output is normalised next
@@ -903,13 +897,9 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         if (l.wpk && !g.conv_taps && stream_gemm_ok(g, a_dt, c_dt)) {
             int S = (defer_residual && g.store != STORE_RESID) ? stream_gemm_splitk(g) : 1;
             if ((size_t)S * 32 * g.a_packed_mb * g.N > h->splitk_elems) S = 1;
-            if (S == 1 && h->xs_ctr) {                // residual producers at M = 64: split K inside the kernel (last arriver finishes the tile)
-                const int xs = stream_gemm_xs_S(g);
-                if (xs > 1 && (size_t)xs * 32 * g.a_packed_mb * g.N <= h->splitk_elems && (g.N / 32) * g.a_packed_mb <= 4096) { S = xs; g.xs_ctr = h->xs_ctr; }
-            }
             HIPCHK(launch_stream_gemm(g, l.wpk, a_dt, c_dt, S, h->splitk, st));
             count_variant(h, "variant:stream_gemm:%s", tag);
-            if (S > 1 && !g.xs_ctr) { h->pend.slabs = h->splitk; h->pend.S = S; h->pend.rows = 32 * g.a_packed_mb; h->pend.bias = l.b32; }
+            if (S > 1) { h->pend.slabs = h->splitk; h->pend.S = S; h->pend.rows = 32 * g.a_packed_mb; h->pend.bias = l.b32; }
             return HQT_OK;
         }
         g.Bw = l.w16;
@@ -1450,7 +1440,7 @@ struct S1Ctx {
 static bool split_shape_ok(const hqt_handle* h, const GemmArgs& g, const Lin& l) {
     if (!l.w16h) return false;
     GemmArgs t = g;
-    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l; t.Bw_frag = l.wfrag; t.Bw_frag16 = l.wfrag16; t.Bw_up16 = l.wup16;
+    t.N = l.N; t.K = l.K; t.ldb = l.K; t.zero_page = h->zero_page; t.Bw_lo = l.w16l; t.Bw_frag16 = l.wfrag16; t.Bw_up16 = l.wup16;
     if (t.lda == 0) t.lda = l.K;
     return t.conv_taps == 9 ? split_conv3_ok(t) : split_gemm_ok(t);
 }

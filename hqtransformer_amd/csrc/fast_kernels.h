@@ -19,8 +19,6 @@ hipError_t stream_gemm_configure();     // raise dynamic-LDS limits once (call o
 // S = stream_gemm_splitk(g) (> 1 only when the caller can defer bias + residual to the next LayerNorm):
 // slabs [S][32 * a_packed_mb][N] fp32 receive the partial sums and no epilogue runs.
 int stream_gemm_splitk(const GemmArgs& g);
-// in-kernel split-K (GemmArgs.xs_ctr) factor the launcher would use for g, or 0
-int stream_gemm_xs_S(const GemmArgs& g);
 hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, int S, float* slabs, hipStream_t st);
 
 // ---- LDS-tiled MFMA GEMM of the merged AR passes (tile_gemm.hip): same operands and store modes as the streaming GEMM, 512+ rows.

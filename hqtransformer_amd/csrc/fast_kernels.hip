@@ -162,8 +162,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     const unsigned polled = chain_poll(g.chain);
     // ---- vector epilogue (the AR loop's store modes): a thread finishes 4 consecutive columns of one row.  Its bias, column sums and
     //      residual row are fetched under the end of the K loop (pipelined variants) or under the reduction, never as dependent loads after it.
-    const bool xs = S > 1 && g.xs_ctr != nullptr;                    // in-kernel split-K: the last arriver of a tile finishes it
-    const bool vec_epi = (S == 1 || xs) && (ABL == 0 || ABL == 9 || ABL == 6 || ABL == 7) && g.N % 4 == 0 && g.ldc % 4 == 0 &&
+    const bool vec_epi = S == 1 && (ABL == 0 || ABL == 9 || ABL == 6 || ABL == 7) && g.N % 4 == 0 && g.ldc % 4 == 0 &&
                          (g.store == STORE_RESID || g.store == STORE_PACKED || (g.store == STORE_QKV && g.qkv_D % (32 * NT) == 0) ||
                           (g.store == STORE_ROWS && g.rows_per_group == 0 && !g.resid && g.batch <= 1));
     constexpr int VGROUPS = TILE / 4;                                 // 4-column groups per workgroup
@@ -374,52 +373,6 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
             for (int w = 1; w < (ABL == 7 ? 1 : NW); ++w) sv += *reinterpret_cast<const f32x4*>(rp + (size_t)w * TILE_P);   // ABL 7 (bench_stream): no cross-wave sum
             part[j] = sv;
         }
-        if (xs) {
-            // publish the partial tile (agent-scope stores: written through to where every XCD sees them), then arrive
-            __shared__ unsigned xs_old;
-            const size_t slab = (size_t)(MB * 32) * g.N;
-#pragma unroll
-            for (int j = 0; j < VPT; ++j) {
-                const int vo = threadIdx.x + j * NW * 64;
-                if (vo < VGROUPS) {
-                    const int o4 = vo * 4;
-                    const int n = o4 & 31, ml = (o4 >> 5) & 31, blk = o4 >> 10;
-                    float* dst = slabs + (size_t)blockIdx.z * slab + (size_t)((mb0 + blk % MBW) * 32 + ml) * g.N + (ntile0 + blk / MBW) * 32 + n;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) __hip_atomic_store(dst + e, part[j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores are performed before the arrival below is issued
-            __syncthreads();
-            unsigned* ctr = g.xs_ctr + blockIdx.y * gridDim.x + blockIdx.x;
-            if (threadIdx.x == 0) {
-                const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)S - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                xs_old = old;
-            }
-            __syncthreads();
-            if (xs_old != (unsigned)S - 1) return;                     // workgroup-uniform: someone else finishes this tile
-#pragma unroll
-            for (int j = 0; j < VPT; ++j) {
-                const int o4 = min((int)(threadIdx.x + j * NW * 64), VGROUPS - 1) * 4;
-                const int n = o4 & 31, ml = (o4 >> 5) & 31, blk = o4 >> 10;
-                const float* src = slabs + (size_t)((mb0 + blk % MBW) * 32 + ml) * g.N + (ntile0 + blk / MBW) * 32 + n;
-                constexpr int XS_MAX = 8;                              // S <= 8 (xs_plan): every partner slab is fetched in ONE round trip
-                f32x4 p[XS_MAX];
-#pragma unroll
-                for (int z = 0; z < XS_MAX; ++z) {                     // unconditional (clamped) loads, all in flight together
-                    const float* sz = src + (size_t)min(z, S - 1) * slab;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) p[z][e] = __hip_atomic_load(sz + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int z = 0; z < XS_MAX; ++z)                       // fixed z order, own partial in its place: same bits whoever arrives last
-                    if (z < S) sum += (z == (int)blockIdx.z) ? part[j] : p[z];
-                part[j] = sum;
-            }
-        }
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
             const int vo = threadIdx.x + j * NW * 64;
@@ -621,39 +574,8 @@ static hipError_t launch_stream_cfg(const StreamCfg& c, const GemmArgs& g, const
     taken = false;
     return hipSuccess;
 }
-// In-kernel split-K plan of the residual producers at M = 64 (proj: K = D, fc2: K = 4 D; N = D narrow): 64-row weight tiles
-// (activation re-reads = weight bytes instead of twice that) times S K-slices of 768 keep 48..192 workgroups busy instead of
-// 48 that each stream up to 1.2 MB.  An experiment that lost (below): enabled only by HQT_XS=1; HQT_XS_K1="S,MBW,NT,NW,U" / HQT_XS_K4 override the plan for
-// K <= 2048 / K > 2048 (A/B runs).
-struct XsPlan { int S, mbw, nt, nw, u; };
-static XsPlan xs_plan(const GemmArgs& g) {
-    // Measured on MI355X (batch 64, D = 1536): fc2 23.9 -> 23.5 us, proj 11.4 -> 14.3 us, 1122 -> 1053 images/s with 3 lanes.  The
-    // load phase does shrink, but publish (write-through stores) -> arrive (agent-scope atomic) -> fetch (agent-scope loads)
-    // are three dependent memory-side round trips of 2-4 us each on this part, which eats the gain.  Off unless HQT_XS=1.
-    static const bool off = !(getenv("HQT_XS") && atoi(getenv("HQT_XS")) == 1);
-    XsPlan none{0, 0, 0, 0, 0};
-    if (off || g.store != STORE_RESID || g.a_packed_mb != 2 || g.N >= 3072 || g.N % 64 != 0 || g.N % 4 != 0 || g.ldc % 4 != 0) return none;
-    static const XsPlan env[2] = {[] { XsPlan p{0, 0, 0, 0, 0}; const char* v = getenv("HQT_XS_K1"); if (v) sscanf(v, "%d,%d,%d,%d,%d", &p.S, &p.mbw, &p.nt, &p.nw, &p.u); return p; }(),
-                                  [] { XsPlan p{0, 0, 0, 0, 0}; const char* v = getenv("HQT_XS_K4"); if (v) sscanf(v, "%d,%d,%d,%d,%d", &p.S, &p.mbw, &p.nt, &p.nw, &p.u); return p; }()};
-    const XsPlan& e = env[g.K > 2048 ? 1 : 0];
-    if (e.S > 0) return e.S <= 8 && (g.K / 16) % (e.S * e.nw) == 0 && (g.N / 32) % e.nt == 0 ? e : none;
-    if (g.K % 768 != 0) return none;
-    const int S = g.K / 768;                      // 6 k-steps of 16 per wave with 8 waves: one load run, then the MFMAs
-    if (S < 2 || S > 8) return none;
-    return XsPlan{S, 2, 2, 8, 6};
-}
-int stream_gemm_xs_S(const GemmArgs& g) { return xs_plan(g).S; }
-
 template <typename TC>
 static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
-    if (S > 1 && g.xs_ctr) {
-        const XsPlan p = xs_plan(g);
-        if (p.S != S) return hipErrorInvalidValue;
-        bool taken = false;
-        const StreamCfg c{p.mbw, p.nt, p.nw, p.u};
-        const hipError_t e = launch_stream_cfg<TC>(c, g, wpk, st, taken, S, slabs);
-        return taken ? e : hipErrorInvalidValue;
-    }
     if (S == 1 && (g.a_packed_mb == 2 || g.a_packed_mb == 8)) {
         static const StreamCfg cfgs[4] = {stream_cfg_env("HQT_GEMM_M64W"), stream_cfg_env("HQT_GEMM_M64N"),
                                           stream_cfg_env("HQT_GEMM_M256W"), stream_cfg_env("HQT_GEMM_M256N")};

@@ -818,9 +818,7 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
         }
         if (glds_ok(g)) {
             const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
-            static const int nstage = getenv("HQT_CONV_STAGES") ? atoi(getenv("HQT_CONV_STAGES")) : 2;   // A/B switch: the 4-slot ring (1 WG/CU) measured 1.5x slower than 2 buffers x 2 WGs/CU
-            const bool ring = nstage == 4 && g.K / 64 >= 4;
-            const size_t smem = (size_t)(ring ? 4 : 2) * 2 * 128 * 128;
+            const size_t smem = (size_t)2 * 2 * 128 * 128;        // two LDS buffers, two workgroups per CU (a 4-slot ring at one workgroup per CU measured 1.5x slower)
             // few 128 x 128 tiles and rows to spare (third code level: [1024, 1536] GEMMs = 96 tiles): 64-row tiles fill the chip
             const long long t128 = (long long)grid.x * grid.y * grid.z;
             // (latency policy only: with several steps in flight the 128 x 128 tiles cost fewer CU-microseconds -- level-3 config,
@@ -838,8 +836,7 @@ hipError_t launch_mfma_gemm(const GemmArgs& g, int a_dt, int b_dt, int c_dt, hip
                 return hipGetLastError();
             }
 #define LAUNCH_GLDS(TC, NCHW_)                                                                      \
-            if (ring) conv_glds_kernel<TC, NCHW_, 4><<<grid, 256, smem, st>>>(g);                    \
-            else conv_glds_kernel<TC, NCHW_, 2><<<grid, 256, smem, st>>>(g);
+            conv_glds_kernel<TC, NCHW_, 2><<<grid, 256, smem, st>>>(g);
             if (g.store == STORE_NCHW) {
                 if (c_dt == DT_BF16) { LAUNCH_GLDS(bf16_t, 1) } else { LAUNCH_GLDS(float, 1) }
             } else if (g.store == STORE_ROWS && g.rows_per_group == 0) {
@@ -864,10 +861,8 @@ hipError_t mfma_gemm_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_glds_kernel<TC, NCHW_, NS>),                        \
                             hipFuncAttributeMaxDynamicSharedMemorySize, NS * 2 * 128 * 128);                        \
     if (e != hipSuccess) return e;
-    CFG(bf16_t, 0, 2) CFG(bf16_t, 0, 4) CFG(float, 0, 2) CFG(float, 0, 4)
-    CFG(bf16_t, 1, 2) CFG(bf16_t, 1, 4) CFG(float, 1, 2) CFG(float, 1, 4)
-    CFG(bf16_t, 2, 2) CFG(bf16_t, 2, 4) CFG(float, 2, 2) CFG(float, 2, 4)
-    CFG(bf16_t, 3, 2) CFG(bf16_t, 3, 4) CFG(float, 3, 2) CFG(float, 3, 4)
+    CFG(bf16_t, 0, 2) CFG(float, 0, 2) CFG(bf16_t, 1, 2) CFG(float, 1, 2)
+    CFG(bf16_t, 2, 2) CFG(float, 2, 2) CFG(bf16_t, 3, 2) CFG(float, 3, 2)
 #undef CFG
 #define CFGH(TC, NCHW_)                                                                                             \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<TC, NCHW_, 8>),                          \

@@ -468,413 +468,21 @@ __global__ __launch_bounds__(PC ? 512 : 256, 1) void conv3x3_split_kernel(GemmAr
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Second generation of the SPLIT 3x3 kernel ("wide tile").  tools/micro/bench_split showed the kernel above bound by what
-// it stages, not by the matrix pipe: 37 KB of LDS-DMA per k-tile (32 KB of it filters) against a per-CU fill rate of
-// ~38 GB/s with one stage in flight -- the DMA alone took 63 % of the kernel's time and slowed the MFMA stream beside it.
-// This variant halves the staged bytes per MFMA and keeps two k-tiles of DMA in flight:
-//   * 16 x 16 pixel tile (256 pixels) x 128 channels per workgroup: every filter byte staged serves twice the pixels;
-//   * 8 waves (two per SIMD), each 64 pixels x 64 channels (128 accumulator registers);
-//   * 32-channel chunks: the (16+2) x (16+2) patch of both planes is 42 KiB and double-buffered; the filters of one
-//     (tap, chunk) k-tile are 16 KiB and live in a ring of three stages;
-//   * the FILTERS do not travel by LDS-DMA.  In-kernel stamps: with ~21 LDS-DMA pieces per step a wave spent 700-1100
-//     cycles of every step inside the DMA instructions themselves -- whoever issued them, however many per wave, contiguous
-//     sources or not: the CU's LDS-DMA path takes ~24 B/clk and an instruction that finds it full blocks its wave, which
-//     then cannot issue MFMAs either (the step took DMA time PLUS matrix time).  Plain global_load_dwordx4 into registers
-//     does not block: every wave loads its 1/8 of B(kt+3) at the top of step kt (2 x 16 B per lane), computes, and writes
-//     the registers it loaded one step earlier (B(kt+2)) into the ring with ds_write_b128 in front of the step's closing
-//     barrier -- two steps of flight, 16 staging registers.  Only the patch (one piece per wave and step, 5 pieces per CU)
-//     still uses LDS-DMA, far below that path's rate;
-//   * LDS rows are 64 B (32 fp16 channels): chunk c of row r lives in slot c ^ ((r >> 2) & 3), applied on the DMA source
-//     side and mirrored by the fragment reads (the 16 lanes of a ds_read_b128 group land on 16 distinct 16-B slots).
-// LDS: 2 x 2 x 21 KiB patch + 3 x 2 x 8 KiB filters = 132 KiB, one workgroup per CU.
-// ---------------------------------------------------------------------------------------------
-namespace {
-constexpr int W_T = 16, W_PITCH = W_T + 2;
-constexpr int W_ROWS = W_PITCH * W_PITCH;                       // 324 patch rows (pixels) of 64 B per plane
-constexpr int W_PIECES = 21;                                    // DMA pieces of 16 rows per plane
-constexpr int W_PLANE = W_PIECES * 1024;                        // bytes per patch plane
-constexpr int W_BST = 3;                                        // filter ring stages
-constexpr int W_PPW = 6;                                        // patch pieces per wave and chunk, at most (42 pieces over 8 waves: 6,6,5,5,5,5,5,5)
-constexpr int split_wide_lds(int BN) { return 4 * W_PLANE + W_BST * 2 * BN * 64; }
-static_assert(128 * S_CPITCH <= split_wide_lds(32), "epilogue staging must fit in the operand buffers");
-static_assert(split_wide_lds(128) <= 160 * 1024, "LDS budget");
-}  // namespace
-
-template <bool NCHW, int BN, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void conv3x3_split_wide_kernel(GemmArgs g) {
-    static_assert(BN == 128 || (BN == 32 && NCHW), "the 32-channel variant exists for the NCHW conv_out store only");
-    constexpr int FJ = BN == 128 ? 2 : 1, FI = BN == 128 ? 2 : 1, B_PLANE = BN * 64;
-    constexpr int BPIECES = BN / 16;                                // DMA pieces per filter plane and stage (8 | 2)
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_raw;
-    auto PATCH = [&](int s, int plane) -> char* { return lds_raw + (size_t)(s * 2 + plane) * W_PLANE; };
-    auto BT = [&](int s, int plane) -> char* { return lds_raw + 4 * W_PLANE + (size_t)(s * 2 + plane) * B_PLANE; };
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: everything derived from it (roles, LDS piece addresses) stays scalar
-    const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
-    const int fr = lane & 31, fh = lane >> 5;
-    int tile_m, tile_n;
-    xcd_tile(tile_m, tile_n);
-    const int n0 = tile_n * BN;
-    const int tiles_x = g.W / W_T, tiles_y = g.H / W_T;
-    const int img = tile_m / (tiles_x * tiles_y);
-    const int trem = tile_m - img * (tiles_x * tiles_y);
-    const int ty0 = (trem / tiles_x) * W_T, tx0 = (trem % tiles_x) * W_T;
-    const int Hin = g.H >> g.upsample, Win = g.W >> g.upsample;
-    const half_t* Abase = reinterpret_cast<const half_t*>(g.A);                 // [pixel][hi Cin | lo Cin]
-    const half_t* Bhi = reinterpret_cast<const half_t*>(g.Bw);
-    const half_t* Blo = reinterpret_cast<const half_t*>(g.Bw_lo);
-    const half_t* zero = reinterpret_cast<const half_t*>(g.zero_page);
-
-    // ---- DMA.  A piece = 16 rows x 64 B; lane -> (row = 16 piece + lane / 4, slot = lane & 3), source chunk = slot ^ ((row >> 2) & 3).
-    //      vmcnt is per wave, so a wave only has to know its OWN issue counts: filter pieces 2 w, 2 w + 1 of every stage (linear id =
-    //      plane * BPIECES + piece), patch pieces w, w + 8, ... of every chunk, the u-th of them at tap u.
-    const int nbp = BN == 128 ? 2 : (wave < 4 ? 1 : 0);             // filter pieces of this wave per stage
-    const int bid0 = BN == 128 ? 2 * wave : min(wave, 3);
-    const int bplane = bid0 / BPIECES, bpiece0 = bid0 % BPIECES;
-    const int brow_i = bpiece0 * 16 + (lane >> 2);
-    const long long boff = (n0 + brow_i < g.N) ? (long long)(n0 + brow_i) * g.ldb + (((lane & 3) ^ ((brow_i >> 2) & 3)) * 8) : -1;
-    const half_t* bsrc = (bplane ? Blo : Bhi) + (boff >= 0 ? boff : 0);
-    const int npp = (2 * W_PIECES - wave + 7) / 8;                  // patch pieces of this wave per chunk (6 | 5)
-    // element offset (chunk 0) of this lane's 16 bytes of the wave's u-th patch piece, ~0u = zero page (outside the image / pad rows);
-    // fixed for the whole kernel, so the per-step cost of a piece is one 64-bit add and a select
-    unsigned poff[W_PPW];
-#pragma unroll
-    for (int u = 0; u < W_PPW; ++u) {
-        const int id = min(wave + 8 * u, 2 * W_PIECES - 1), plane = id / W_PIECES, piece = id - plane * W_PIECES;
-        const int q = piece * 16 + (lane >> 2);
-        const int qy = (q * 3641) >> 16, qx = q - qy * W_PITCH;                 // q / 18 for q < 336
-        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
-        const int ch = ((lane & 3) ^ ((q >> 2) & 3)) * 8;
-        const bool in = q < W_ROWS && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        poff[u] = in ? (unsigned)((((long long)img * Hin + (iy >> g.upsample)) * Win + (ix >> g.upsample)) * (2 * g.Cin) + ch + plane * g.Cin) : ~0u;
-    }
-    auto issue_patch_piece = [&](int c, int s, int u) {             // this wave's u-th piece (u < npp) of chunk c into patch buffer s
-        const int id = wave + 8 * u, plane = id / W_PIECES, piece = id - plane * W_PIECES;
-        const half_t* sp = poff[u] != ~0u ? Abase + (size_t)poff[u] + c * 32 : zero;
-        if (ABL == 6) sp = Abase + ((long long)(tile_m % 1024) * 64 + id) * 512 + lane * 8;      // timing probe: contiguous 1-KiB sources (wrong data)
-        char* dst = PATCH(s, plane) + piece * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    };
-    constexpr int NBP = BN == 128 ? 2 : 1;                          // staging vectors per wave and stage
-    struct BStage { u32x4 v[NBP]; };
-    auto load_b = [&](int k0) -> BStage {                           // this wave's share of the filter k-tile at k0, 16 B per lane and piece
-        BStage r;
-#pragma unroll
-        for (int t = 0; t < NBP; ++t) {
-            const bool ok = t < nbp && boff >= 0 && n0 + brow_i + t * 16 < g.N;
-            const half_t* sp = ok ? bsrc + (long long)t * 16 * g.ldb + k0 : zero;
-            if (ABL == 6) sp = Bhi + ((long long)((k0 >> 5) % 64) * 16 + bid0 + t) * 512 + lane * 8;
-            r.v[t] = *reinterpret_cast<const u32x4*>(sp);
-        }
-        return r;
-    };
-    const unsigned bdst0 = lds_base + 4 * W_PLANE + bplane * B_PLANE + bpiece0 * 1024 + lane * 16;
-    auto store_b = [&](const BStage& r, int s) {                    // ... into ring stage s (the same lane-linear image LDS-DMA would write)
-#pragma unroll
-        for (int t = 0; t < NBP; ++t)
-            if (t < nbp) {
-                const unsigned a = bdst0 + s * 2 * B_PLANE + t * 1024;
-                asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(r.v[t]) : "memory");
-            }
-    };
-
-    f32x16 accm[FI][FJ], accx[FI][FJ];
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.0f; accx[i][j][r] = 0.0f; }
-
-    int qbase[FI];                                                  // patch row of tap (0, 0) for this lane's pixel of fragment i
-#pragma unroll
-    for (int i = 0; i < FI; ++i) qbase[i] = (wm * (2 * FI) + i * 2 + (fr >> 4)) * W_PITCH + (fr & 15);
-    unsigned wa0[FJ];                                               // byte offset of this lane's filter fragment (k-step 0) inside a filter plane
-#pragma unroll
-    for (int j = 0; j < FJ; ++j) { const int r = wn * 64 + j * 32 + fr; wa0[j] = r * 64 + ((fh ^ ((r >> 2) & 3)) << 4); }
-
-    auto compute = [&](int ps, int bs, int tapoff) {
-        const unsigned pbase = lds_base + ps * 2 * W_PLANE, wbase = lds_base + 4 * W_PLANE + bs * 2 * B_PLANE;
-        half8 ah[2][FI], al[2][FI], wh[2][FJ], wl[2][FJ];
-        auto issue = [&](int ks, int set) {                         // chunk (2 ks + fh) ^ swizzle = chunk(0) ^ (ks << 1): bit 5 of the offset
-#pragma unroll
-            for (int j = 0; j < FJ; ++j) {
-                const unsigned a = wbase + (wa0[j] ^ (ks << 5));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(wh[set][j]) : "v"(a));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wl[set][j]) : "v"(a), "n"(B_PLANE));
-            }
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                const int q = qbase[i] + tapoff;
-                const unsigned a = pbase + ((q * 64 + ((fh ^ ((q >> 2) & 3)) << 4)) ^ (ks << 5));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(ah[set][i]) : "v"(a));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(al[set][i]) : "v"(a), "n"(W_PLANE));
-            }
-        };
-#define HQT_RETIRE(set, P)                                                                                                          \
-        do {                                                                                                                       \
-            if constexpr (FI == 2 && FJ == 2)                                                                                      \
-                asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(wh[set][0]), "+v"(wl[set][0]), "+v"(wh[set][FJ - 1]), "+v"(wl[set][FJ - 1]), \
-                             "+v"(ah[set][0]), "+v"(al[set][0]), "+v"(ah[set][FI - 1]), "+v"(al[set][FI - 1]) : "n"(P));           \
-            else                                                                                                                   \
-                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(wh[set][0]), "+v"(wl[set][0]), "+v"(ah[set][0]), "+v"(al[set][0]) : "n"(P)); \
-        } while (0)
-        constexpr int NRD = 2 * (FI + FJ);                          // reads per k-step
-        if (ABL != 4) { issue(0, 0); issue(1, 1); }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ABL == 4) {
-#pragma unroll
-                for (int j = 0; j < FJ; ++j) asm volatile("" : "+v"(wh[ks][j]), "+v"(wl[ks][j]));
-#pragma unroll
-                for (int i = 0; i < FI; ++i) asm volatile("" : "+v"(ah[ks][i]), "+v"(al[ks][i]));
-            } else if (ks == 0) HQT_RETIRE(0, NRD);
-            else HQT_RETIRE(1, 0);
-#pragma unroll
-            for (int i = 0; i < FI; ++i)
-#pragma unroll
-                for (int j = 0; j < FJ; ++j) {
-                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][j], ah[ks][i], accm[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks][j], al[ks][i], accx[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks][j], ah[ks][i], accx[i][j], 0, 0, 0);
-                }
-            if (ks == 0) __builtin_amdgcn_sched_barrier(0);     // the first k-step's MFMAs stay in front of the second set's wait
-        }
-#undef HQT_RETIRE
-    };
-
-    // ---- main loop.  Filter stage of k-tile kt = kt % 3; patch buffer of chunk c = c & 1.  K order is chunk-major:
-    //      k0 = tap * Cin + 32 c in the tap-major filters.  Step kt: [LDS-DMA of this wave's patch piece of chunk c + 1 for this
-    //      tap] [global loads of its share of B(kt+3)] [fragment reads + MFMAs of k-tile kt] [ds_write of B(kt+2), loaded one
-    //      step ago, into stage (kt+2) % 3 -- last read in step kt-1] [barrier].  hipcc counts the global loads itself (the
-    //      ds_write statement names the registers); a patch piece is older than the loads issued behind it, so it has landed
-    //      once those have: two steps after its issue at the latest, i.e. before its chunk begins (pieces go out at taps 0..5).
-    const int NC = g.Cin / 32, KT = NC * 9;
-#pragma unroll
-    for (int u = 0; u < W_PPW; ++u)
-        if (u < npp) issue_patch_piece(0, 0, u);
-    {
-        const BStage b0 = load_b(0), b1 = load_b(g.Cin);           // k-tile 1 = (chunk 0, tap 1), k-tile 2 = (chunk 0, tap 2); KT >= 9
-        store_b(b0, 0);
-        store_b(b1, 1);
-    }
-    BStage s_old = load_b(2 * g.Cin), s_new = s_old;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    int kt = 0, st = 0;                                // st = kt % 3
-    long long acc_t[5] = {0, 0, 0, 0, 0};              // ABL 9 (tools/micro): cycles in load issue, compute, ring write, barrier
-    auto stamp = [&]() -> long long { if (ABL != 9) return 0; __builtin_amdgcn_sched_barrier(0); const long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); return t; };
-    const long long t_begin = stamp();
-#pragma unroll 1
-    for (int c = 0; c < NC; ++c) {
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++kt) {
-            // Every wave stages in front of its MFMAs.  Staggering the two waves of a SIMD (waves 4-7 staging first, waves 0-3 last, so
-            // that one wave's staging would sit beside its partner's MFMAs; ABL 5) measured SLOWER, 3404 vs 3142 us on the 512 -> 512
-            // upsampling conv: beside a partner that issues MFMAs back to back the same ~60 staging instructions took 950-1300 cycles
-            // instead of ~300 -- on this part the two waves of a SIMD do not overlap vector / memory issue with matrix issue, the
-            // non-MFMA instructions of both simply add to the 1536 matrix cycles of a step.
-            auto staging = [&]() {
-                if (ABL == 2) return;
-                if (kt + 2 < KT) store_b(s_old, st == 0 ? 2 : st - 1);              // (kt + 2) % 3: last read in step kt - 1
-                if (c + 1 < NC && tap < npp) {         // registers cannot be indexed by a runtime tap: one uniform branch per tap
-#pragma unroll
-                    for (int tt = 0; tt < W_PPW; ++tt)
-                        if (tap == tt) issue_patch_piece(c + 1, (c + 1) & 1, tt);
-                }
-                if (kt + 3 < KT) {
-                    int t2 = tap + 3, c2 = c;
-                    if (t2 >= 9) { t2 -= 9; ++c2; }
-                    s_new = load_b(t2 * g.Cin + c2 * 32);
-                }
-            };
-            const bool stage_first = wave >= 4 || ABL != 5;     // ABL 5: waves 0-3 stage behind their MFMAs (the stagger experiment)
-            const long long s0 = stamp();
-            if (stage_first) staging();
-            const long long s1 = stamp();
-            if (ABL != 3 || kt == 0) {
-                const int t3 = (tap * 11) >> 5;        // tap / 3 for tap < 9
-                compute(c & 1, st, t3 * W_PITCH + (tap - 3 * t3));
-            }
-            const long long s2 = stamp();
-            if (!stage_first) staging();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const long long s3 = stamp();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            const long long s4 = stamp();
-            if (ABL == 9) { acc_t[0] += s1 - s0; acc_t[1] += s2 - s1; acc_t[2] += s3 - s2; acc_t[3] += s4 - s3; }
-            s_old = s_new;
-            st = st == 2 ? 0 : st + 1;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing is in flight here; keeps the epilogue's LDS reuse independent of that argument)
-    __builtin_amdgcn_s_barrier();
-    if (ABL == 9) {                                    // stamps of one workgroup in the middle of the grid -> g.am_best as a debug sink
-        const long long t_end = stamp();
-        if (blockIdx.x == 0 && blockIdx.y == gridDim.y / 2 && lane == 0) {
-            long long* d = reinterpret_cast<long long*>(g.am_best) + wave * 8;
-            d[0] = acc_t[0]; d[1] = acc_t[1]; d[2] = acc_t[2]; d[3] = acc_t[3]; d[4] = t_end - t_begin; d[5] = KT;
-        }
-    }
-    if (ABL == 1) {
-        float sacc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < FI; ++i)
-#pragma unroll
-            for (int j = 0; j < FJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += accm[i][j][r] + accx[i][j][r];
-        if (sacc == 12345.678f) reinterpret_cast<float*>(g.C)[0] = sacc;
-        return;
-    }
-    // ---- epilogue.  D map: col = lane & 31 -> pixel fr of block i; row = (r & 3) + 8 (r >> 2) + 4 fh -> channel
-    if (NCHW) {                                        // conv_out: fp32 NCHW (+clamp); lanes = consecutive pixels of a row
-        float* Cb = reinterpret_cast<float*>(g.C);
-        const long long hw = (long long)g.H * g.W;
-#pragma unroll
-        for (int i = 0; i < FI; ++i) {
-            const int py = wm * (2 * FI) + i * 2 + (fr >> 4);
-            const long long pix = (long long)(ty0 + py) * g.W + tx0 + (fr & 15);
-#pragma unroll
-            for (int j = 0; j < FJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int n = n0 + wn * 64 + j * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    if (n >= g.N) continue;
-                    float v = (accm[i][j][e] + accx[i][j][e] * SPLIT_INV) * g.alpha + (g.bias ? g.bias[n] : 0.0f);
-                    if (g.clamp01) v = fminf(fmaxf(0.5f * v + 0.5f, 0.0f), 1.0f);
-                    Cb[((long long)img * g.N + n) * hw + pix] = v;
-                }
-        }
-        return;
-    }
-    if constexpr (BN == 128) {
-        // Staged store, 128 pixels (8 tile rows = the pixels of wave rows wm = 2 half, 2 half + 1) at a time: fp32 tile through the
-        // dead operand buffers, then whole NHWC rows, two 16-B stores per lane; 512 threads cover 32 pixels x 128 channels per pass.
-        const long long pix0 = ((long long)img * g.H + ty0) * g.W + tx0;
-        char* stage = lds_raw;
-        float* Cb = reinterpret_cast<float*>(g.C);
-        const float* Rb = reinterpret_cast<const float*>(g.resid);
-        const int c8 = (tid & 15) * 8, nn = n0 + c8;
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (g.bias && nn + e < g.N) ? g.bias[nn + e] : 0.0f;
-        float gs[8], gq[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half > 0) __syncthreads();              // the previous half has been read back
-            if ((wm >> 1) == half) {
-#pragma unroll
-                for (int i = 0; i < FI; ++i) {
-                    const int r = (wm & 1) * 64 + i * 32 + fr;      // pixel within the staged 128
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const int nl = wn * 64 + j * 32 + 8 * q4 + 4 * fh;
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV;
-                            *reinterpret_cast<f32x4*>(stage + r * S_CPITCH + nl * 4) = v;
-                        }
-                }
-            }
-            __syncthreads();
-            if (nn < g.N) {                             // split_conv3_ok(): N % 8 == 0
-                long long moff[4];
-                f32x4 r0[4], r1[4];
-#pragma unroll
-                for (int pass = 0; pass < 4; ++pass) {
-                    const int r = pass * 32 + (tid >> 4);
-                    moff[pass] = (pix0 + (long long)(half * 8 + (r >> 4)) * g.W + (r & 15)) * g.ldc + nn;
-                    if (Rb) { r0[pass] = *reinterpret_cast<const f32x4*>(Rb + moff[pass]); r1[pass] = *reinterpret_cast<const f32x4*>(Rb + moff[pass] + 4); }
-                }
-#pragma unroll
-                for (int pass = 0; pass < 4; ++pass) {
-                    const int r = pass * 32 + (tid >> 4);
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + r * S_CPITCH + c8 * 4);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + r * S_CPITCH + c8 * 4 + 16);
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] * g.alpha + bv[e];
-                    if (Rb) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += r0[pass][e]; v[4 + e] += r1[pass][e]; }
-                    }
-                    const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    *reinterpret_cast<f32x4*>(Cb + moff[pass]) = o0;
-                    *reinterpret_cast<f32x4*>(Cb + moff[pass] + 4) = o1;
-                    if (g.gn_part_out_d) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
-                    }
-                }
-            }
-        }
-        if (g.gn_part_out_d) {                              // uniform branch (kernel argument): barriers are safe here
-            __syncthreads();
-            float* redw = reinterpret_cast<float*>(lds_raw);                    // [32 pixel rows][128 channels][2]; zeros from idle threads
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                redw[(((tid >> 4) * 128) + c8 + e) * 2] = gs[e];
-                redw[(((tid >> 4) * 128) + c8 + e) * 2 + 1] = gq[e];
-            }
-            __syncthreads();
-            const float* red = reinterpret_cast<const float*>(lds_raw);
-            if (tid < 128) {
-                double sa = 0.0, sq = 0.0;
-#pragma unroll
-                for (int rg = 0; rg < 32; ++rg) { sa += (double)red[((rg * 128) + tid) * 2]; sq += (double)red[((rg * 128) + tid) * 2 + 1]; }
-                const int cpg = g.N / g.gn_out_groups;
-                for (int off = cpg >> 1; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sq += __shfl_xor(sq, off, 64); }
-                const int ch = n0 + tid;
-                if (ch < g.N && (tid & (cpg - 1)) == 0) {
-                    double* pp = g.gn_part_out_d + (((long long)img * (tiles_x * tiles_y) + trem) * g.gn_out_groups + ch / cpg) * 2;
-                    pp[0] = sa; pp[1] = sq;
-                }
-            }
-        }
-    }
-}
-
-// which of the two 3x3 kernels takes g: the wide-tile one whenever whole 16 x 16 tiles fit (HQT_SPLIT_WIDE=0: never; A/B switch)
-static bool split_wide_shape(const GemmArgs& g) {
-    static const bool off = getenv("HQT_SPLIT_WIDE") && atoi(getenv("HQT_SPLIT_WIDE")) == 0;
-    return !off && g.H % W_T == 0 && g.W % W_T == 0 && g.Cin % 32 == 0;
-}
+// 3x3 convs the ring kernels (split_stream_conv.hip) do not take -- channel counts that are not multiples of 128, conv_out with more
+// than 16 channels -- run conv3x3_split_kernel above when its tile fits; anything else is left to the fp32 vector-ALU kernel.
 bool split_conv3_ok(const GemmArgs& g) {
     if (g.conv_taps != 9 || g.conv_stride2 || g.conv_nopad || !g.zero_page || g.gn_stats || g.a_packed_mb || g.batch > 1) return false;
     if (!g.Bw_lo || g.ldb % 8 != 0 || g.K != 9 * g.Cin || g.M % (g.H * g.W) != 0) return false;
-    if (!split_wide_shape(g) && (g.Cin % 64 != 0 || g.H % S_TY != 0 || g.W % S_TX != 0)) return false;
+    if (g.Cin % 64 != 0 || g.H % S_TY != 0 || g.W % S_TX != 0) return false;
     if (g.act != ACT_NONE) return false;
     if (g.store == STORE_NCHW) return !g.resid && g.N <= 32;
     return g.store == STORE_ROWS && g.rows_per_group == 0 && g.ldc % 8 == 0 && g.N % 8 == 0;
 }
-int split_conv3_tiles_per_image(const GemmArgs& g) { return split_stream_ok(g) ? split_stream_tiles_per_image(g) : split_wide_shape(g) ? (g.H / W_T) * (g.W / W_T) : (g.H / S_TY) * (g.W / S_TX); }
+int split_conv3_tiles_per_image(const GemmArgs& g) { return split_stream_ok(g) ? split_stream_tiles_per_image(g) : (g.H / S_TY) * (g.W / S_TX); }
 hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st) {
     if (split_stream_ok(g)) return launch_split_conv3_stream(g, st);
-    if (split_wide_shape(g)) {
-        if (g.store == STORE_NCHW) conv3x3_split_wide_kernel<true, 32><<<dim3(1, g.M / (W_T * W_T), 1), 512, split_wide_lds(32), st>>>(g);
-        else conv3x3_split_wide_kernel<false, 128><<<dim3((g.N + 127) / 128, g.M / (W_T * W_T), 1), 512, split_wide_lds(128), st>>>(g);
-        return hipGetLastError();
-    }
-    static const int pc = getenv("HQT_SPLIT_PC") ? atoi(getenv("HQT_SPLIT_PC")) : 1;      // A/B switch: 0 = 4-wave workgroups that issue their own DMA
-    if (g.store == STORE_NCHW) {
-        const dim3 grid(1, g.M / (S_TY * S_TX), 1);
-        if (pc) conv3x3_split_kernel<true, 32, 1><<<grid, 512, split_conv3_lds(32), st>>>(g);
-        else conv3x3_split_kernel<true, 32, 0><<<grid, 256, split_conv3_lds(32), st>>>(g);
-    } else {
-        const dim3 grid((g.N + 127) / 128, g.M / (S_TY * S_TX), 1);
-        if (pc) conv3x3_split_kernel<false, 128, 1><<<grid, 512, split_conv3_lds(128), st>>>(g);
-        else conv3x3_split_kernel<false, 128, 0><<<grid, 256, split_conv3_lds(128), st>>>(g);
-    }
+    if (g.store == STORE_NCHW) conv3x3_split_kernel<true, 32, 1><<<dim3(1, g.M / (S_TY * S_TX), 1), 512, split_conv3_lds(32), st>>>(g);
+    else conv3x3_split_kernel<false, 128, 1><<<dim3((g.N + 127) / 128, g.M / (S_TY * S_TX), 1), 512, split_conv3_lds(128), st>>>(g);
     return hipGetLastError();
 }
 
@@ -1050,14 +658,6 @@ hipError_t launch_split_gemm(const GemmArgs& g0, hipStream_t st) {
 
 hipError_t split_kernels_configure() {
     hipError_t e = split_stream_configure();
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_wide_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, split_wide_lds(128));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_wide_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, split_wide_lds(32));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<false, 128, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(128));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<true, 32, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(32));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<false, 128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(128));
     if (e != hipSuccess) return e;

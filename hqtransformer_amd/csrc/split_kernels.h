@@ -34,11 +34,9 @@ hipError_t launch_split_gemm(const GemmArgs& g, hipStream_t st);
 int split_conv3_tiles_per_image(const GemmArgs& g);
 hipError_t split_kernels_configure();             // raise the dynamic-LDS limits once (outside stream capture)
 
-// third-generation 3x3 kernel (split_stream_conv.hip): filters packed in MFMA fragment order (GemmArgs::Bw_frag) and streamed straight
-// into registers, one wave per SIMD
+// ring kernels (split_stream_conv.hip): filters packed in MFMA fragment order (GemmArgs::Bw_frag16) and streamed straight into registers
 size_t split_frag_elems(int N, int Cin);          // fp16 elements of the packed hi + lo fragments of an [N][9 Cin] filter bank (Cin % 32 == 0)
-hipError_t launch_pack_split_frag(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);
-hipError_t launch_pack_split_frag16(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);   // 16-channel blocks (GemmArgs::Bw_frag16), same size
+hipError_t launch_pack_split_frag16(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);   // 16-channel blocks
 // upsampling conv (nearest x2 + 3x3) as four 2x2 phase convolutions on the low-resolution image: pre-summed filters (GemmArgs::Bw_up16)
 size_t split_up_elems(int N, int Cin);
 hipError_t launch_pack_split_up16(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);

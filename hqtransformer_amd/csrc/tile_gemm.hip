@@ -541,6 +541,10 @@ __global__ __launch_bounds__(256) void resid_combine_kernel(float* __restrict__ 
 // prologue + epilogue per 32 us loop) and 256 x 128 tiles measured 5-30 % slower in the dependent chain of the AR loop
 // at 512 .. 5120 rows (profiles/r03_micro_tile_gemm.txt); they live on in tools/micro/bench_tile.hip.
 typedef TileGeom<2, 2, 2, 2, 2, 3> Tile128;
+// 64 x 128, 4 waves of 32 x 64, 36 KiB ring, FOUR workgroups per CU: the 512-row passes.  A 512 x 6144 output is only 192 tiles of
+// 128 x 128 (qkv: 144) -- fewer workgroups than the chip has CUs, each walking K alone on its CU at the latency-bound pace of a single
+// ring; halving the row tile doubles the workgroups for 1.5x the LDS-DMA bytes per FLOP, which these shapes have to spare.
+typedef TileGeom<2, 2, 1, 2, 2, 3> Tile64;
 
 template <class G, int STORE, bool DLN, typename TC>
 static hipError_t launch_tile_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
@@ -568,7 +572,7 @@ static hipError_t launch_tile_g(const GemmArgs& g, const bf16_t* wpk, int c_dt, 
 // modes with 16-byte row segments; STORE_QKV parts aligned to the column tile.
 bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
     if (!(g.a_packed_mb >= 16 && a_dt == DT_BF16 && !g.conv_taps && g.batch <= 1 && g.M >= 512)) return false;
-    if (g.N % 128 != 0 || g.K % 32 != 0 || g.K < 256 || g.ldc % 8 != 0 || g.resid || g.xs_ctr) return false;
+    if (g.N % 128 != 0 || g.K % 32 != 0 || g.K < 256 || g.ldc % 8 != 0 || g.resid) return false;
     if (g.store == STORE_QKV) return c_dt == DT_BF16 && g.qkv_D % 128 == 0 && g.rows_per_group > 0;
     if (g.store == STORE_PACKED) return c_dt == DT_BF16 && g.c_packed_mb > 0;
     // (proj, K = D, below 1024 rows: 48 tiles of one short K loop each -- the streaming kernel's 64-row tiles measured 18 vs 26 us there)
@@ -581,8 +585,10 @@ bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
 // slots empty; the slices leave fp32 slabs that resid_combine_kernel finishes (one extra launch: not worth it at K = D).
 TilePlan tile_gemm_plan(const GemmArgs& g) {
     static const int max_s = getenv("HQT_TILE_SPLITK") ? atoi(getenv("HQT_TILE_SPLITK")) : 8;        // A/B runs: 1 = never split
+    static const int max_geom = getenv("HQT_TILE_GEOM") ? atoi(getenv("HQT_TILE_GEOM")) : 1;         // A/B runs: 0 = 128 x 128 tiles only
     TilePlan p{0, Tile128::BM, Tile128::BN, 1};
     const int KS = g.K / 16, tiles = ((g.M + p.bm - 1) / p.bm) * (g.N / p.bn);
+    if (max_geom >= 1 && g.store != STORE_RESID && tiles < 256 && KS / Tile64::KU >= Tile64::NSTAGE) return TilePlan{1, Tile64::BM, Tile64::BN, 1};
     if (g.store == STORE_RESID && g.K >= 3072 && tiles < 256) {
         for (int S : {8, 6, 4, 3, 2})
             if (S <= max_s && tiles * S <= 576 && KS % (Tile128::KU * S) == 0 && KS / S / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = S; break; }
@@ -593,6 +599,7 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
 hipError_t launch_tile_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, const TilePlan& p, float* slabs, hipStream_t st) {
     (void)a_dt;
     if (p.geom == 0) return launch_tile_g<Tile128>(g, wpk, c_dt, p.S, slabs, st);
+    if (p.geom == 1) return launch_tile_g<Tile64>(g, wpk, c_dt, p.S, slabs, st);
     return hipErrorInvalidValue;
 }
 
@@ -626,4 +633,7 @@ static hipError_t configure_g() {
 #undef CFG
     return hipSuccess;
 }
-hipError_t tile_gemm_configure() { return configure_g<Tile128>(); }
+hipError_t tile_gemm_configure() {
+    const hipError_t e = configure_g<Tile128>();
+    return e != hipSuccess ? e : configure_g<Tile64>();
+}

@@ -258,18 +258,3 @@ def test_split_is_rejected_by_the_sampler():
     from hqtransformer_amd._lib import HqtError
     with pytest.raises(HqtError):
         e.sample(2, torch.tensor([1, 2]), 4, precision=PRECISION_SPLIT)
-
-
-@pytest.mark.parametrize('switches', [{'HQT_SPLIT_RING16': '0'}, {'HQT_SPLIT_RING': '0'}, {'HQT_SPLIT_STREAM': '0'},
-                                      {'HQT_SPLIT_STREAM': '0', 'HQT_SPLIT_WIDE': '0'}, {'HQT_SPLIT_STREAM': '0', 'HQT_SPLIT_WIDE': '0', 'HQT_SPLIT_PC': '1'}])
-def test_every_split_kernel_generation_meets_the_bar(switches):
-    """The 3x3 SPLIT convolution exists in five generations, each kept behind a switch: ring16 (default) -> ring ->
-    stream -> wide -> v1 (+ its producer / consumer form).  The switches are read once per process, so each older kernel runs the
-    wide-config decode test -- 1e-4 against the oracle, batch-invariant, deterministic -- in a child process of its own."""
-    import subprocess
-    import sys
-    env = dict(os.environ, **switches)
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_split.py'), '-q', '-x', '-m', 'gpu',
-                        '-k', 'test_split_decode_wide_config_vs_oracle', '-p', 'no:cacheprovider'],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (switches, r.stdout[-2000:], r.stderr[-1000:])

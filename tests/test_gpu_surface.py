@@ -343,4 +343,5 @@ def test_merged_steps_reject_a_mismatched_step_without_losing_the_queue(model):
     y = pipe2.submit(2, 3, seed=2, max_seq_len=64, use_fp16=False, precision='exact', given_top_code=given.clone())
     pipe2.drain()
     torch.cuda.synchronize()
-    assert (x.get()[0] == given.to(x.get()[0].device)).all() and (y.get()[0] == given.to(y.get()[0].device)).all()
+    alone = sampling_ihqgpt(model.stage2, 2, 3, use_fp16=False, is_tqdm=False, max_seq_len=64, seed=1, given_top_code=given.clone())
+    assert (x.get()[0] == alone[0]).all() and (x.get()[1] == alone[1]).all() and tuple(y.get()[0].shape) == (2, 64)

@@ -104,12 +104,20 @@ def test_index_trust_dies_with_the_tensor(engines):
     cb = torch.from_numpy(fx1['code_b']).to(DEV)
     ct = torch.from_numpy(fx1['code_t']).to(DEV)
     e1.decode(ct, cb, precision=PRECISION_EXACT)                # checked once ...
-    key = (ct.data_ptr(), ct.numel())
+    key = E.Engine._ident(ct)
     assert key in E._TRUSTED and E._TRUSTED[key][1]() is ct.untyped_storage()      # ... and trusted while it lives
+    assert E._TRUSTED[key][2] <= s1.n_embed                                         # with the bound it was validated against
     bad_host = torch.from_numpy(fx1['code_t']).clone()
     bad_host[0, 0, 0] = s1.n_embed + 7
     bad = bad_host.to(DEV)
     # what a freed-and-reused block leaves behind: an entry for this address, size and version whose storage is another one
-    E._TRUSTED[(bad.data_ptr(), bad.numel())] = (bad._version, weakref.ref(ct.untyped_storage()))
+    E._TRUSTED[E.Engine._ident(bad)] = (bad._version, weakref.ref(ct.untyped_storage()), s1.n_embed)
     with pytest.raises(IndexError):
         e1.decode(bad, cb, precision=PRECISION_EXACT)
+    # a tensor validated against a LARGER table is checked again for a smaller one (the entry carries its bound); views of one
+    # buffer with different strides do not alias each other
+    big = torch.full_like(ct, s1.n_embed + 3)
+    e1._trust(big, bound=s1.n_embed + 4)                          # as if it had passed a check against a table of n_embed + 4 rows
+    with pytest.raises(IndexError):
+        e1.decode(big, cb, precision=PRECISION_EXACT)
+    assert E.Engine._ident(ct) != E.Engine._ident(ct.transpose(1, 2))

@@ -3,6 +3,7 @@
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/micro/bench_split.hip -o tools/micro/bench_split
 #include "../../hqtransformer_amd/csrc/split_conv.hip"
 #include "../../hqtransformer_amd/csrc/split_stream_conv.hip"
+#include "split_generations.hip"
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)

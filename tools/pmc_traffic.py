@@ -9,8 +9,8 @@ import json
 import re
 import sys
 
-FAMILIES = {'stream_gemm': ('stream_gemm_kernel',),
-            'decoder_conv': ('conv3x3_split_ring16_kernel', 'conv3x3_split_out16_kernel', 'conv3x3_split_ring_kernel', 'conv3x3_split_stream_kernel', 'split_gemm_kernel'),       # SPLIT (the default decode)
+FAMILIES = {'stream_gemm': ('stream_gemm_kernel', 'tile_gemm_kernel', 'resid_combine_kernel'),       # the AR GEMM family (bench.py reads this key)
+            'decoder_conv': ('conv3x3_split_ring16_kernel', 'conv2x2_split_up16_kernel', 'conv3x3_split_out16_kernel', 'conv3x3_split_kernel', 'split_gemm_kernel'),       # SPLIT (the default decode)
             'decoder_conv_fast': ('conv3x3_halo_kernel', 'conv_glds_kernel')}
 
 
