@@ -180,6 +180,8 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    # small control tensors (elapsed times) travel on the backend's native device: the GPU for nccl / RCCL, the host for the gloo test hook
+    cdev = dev if (dist is None or dist.get_backend() == 'nccl') else torch.device('cpu')
 
     cfg = load_config(args.config)
     model = ImageGPT2(cfg, seed=0).to(dev).eval()
@@ -305,12 +307,12 @@ def main():
     barrier()
     elapsed_lanes = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed_lanes], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed_lanes], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_lanes = float(t.item())
     host_ms_ranks = [round(1000 * host_submit_s / args.steps, 3)]
     if dist is not None:
-        t = torch.tensor([host_submit_s], dtype=torch.float64, device=dev)
+        t = torch.tensor([host_submit_s], dtype=torch.float64, device=cdev)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         host_ms_ranks = [round(1000 * float(x.item()) / args.steps, 3) for x in allt]
@@ -345,7 +347,7 @@ def main():
     ar_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(n_serial)) / n_serial
     dec_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(n_serial)) / n_serial
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     serial_value = world * B * n_serial / elapsed

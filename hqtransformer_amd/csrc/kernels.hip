@@ -517,6 +517,138 @@ __global__ __launch_bounds__(256) void attention_fewq_kernel(AttnArgs a) {
     }
 }
 
+// Causal prefill of the text prompt (stage2/layers.py:107-111: every prompt token attends to itself and its predecessors), FAST
+// precision, head size 64, up to 64 tokens: ONE wave per (sample, head) computes the whole T x T attention on the matrix cores
+// instead of one wave per query re-reading the keys.
+//   S^T = K Q^T   (v_mfma_f32_32x32x16_bf16; A = K rows, B = Q rows: both fragments are 16 contiguous bytes of a cache / q row, loaded
+//                  straight from memory -- every K, Q, V element is fetched exactly once per (sample, head))
+// leaves the scores of a query in ONE lane (column = query, the 16 registers of a tile = keys), so the causal mask, the maximum and
+// the sum of the softmax are register loops plus one cross-half shuffle.  The probabilities then serve, converted to bf16 in place,
+// as the B operand of
+//   O^T = V^T P^T (A = V^T: element j of lane half h in k-step s is key 16 s + 8 (j >> 2) + 4 h + (j & 3), the order in which the
+//                  accumulator registers hold P -- cdna_hip_programming.md, 'An accumulator tile as the next MFMA's operand')
+// Key tiles above the diagonal are skipped.  Outputs leave as 8-byte pieces of a row (4 consecutive head dimensions per register quad).
+template <int NT>
+__global__ __launch_bounds__(256) void attention_prefill_mfma_kernel(AttnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+    typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gid = blockIdx.x * 4 + wave;
+    if (gid >= a.B * a.n_heads) return;
+    const int h = gid % a.n_heads, b = gid / a.n_heads;
+    const int D = a.n_heads * 64, T = a.Tq;
+    const int r = lane & 31, hf = lane >> 5;
+    const bf16_t* qb = reinterpret_cast<const bf16_t*>(a.q) + (long long)b * T * D + h * 64;
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(a.kcache) + (long long)b * a.Tmax * D + h * 64;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(a.vcache) + (long long)b * a.Tmax * D + h * 64;
+    bf16x8_t kf[NT][4], qf[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long long row = min(32 * t + r, T - 1);                 // clamped: rows beyond the prompt repeat its last token and are masked / not stored
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(kb + row * D + 16 * ks + 8 * hf);
+            qf[t][ks] = *reinterpret_cast<const bf16x8_t*>(qb + row * D + 16 * ks + 8 * hf);
+        }
+    }
+    // V^T fragments: element j <- V[key(kt, s, hf, j)][32 dt + r]; all loads in flight while the scores are computed
+    unsigned short vraw[2][NT][2][8];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long long key = min(32 * kt + 16 * s2 + 8 * (j >> 2) + 4 * hf + (j & 3), T - 1);
+                    vraw[dt][kt][s2][j] = vb[key * D + 32 * dt + r];
+                }
+    const float scale = 1.0f / sqrtf(64.0f);
+    float inv_sum[NT];
+    bf16x8_t pf[NT][NT][2];                                           // [key tile][query tile][k-step]: P^T as the B operand
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        f32x16_t sc[NT];
+        const int q = 32 * qt + r;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt <= qt; ++kt) {
+            f32x16_t acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[qt][ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                const float v = key <= q ? acc[i] * scale : -INFINITY;
+                acc[i] = v;
+                m = fmaxf(m, v);
+            }
+            sc[kt] = acc;
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));                          // the other half of this query's keys; finite: key 0 is always visible
+        float sum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt <= qt; ++kt) {
+            float e[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { e[i] = __expf(sc[kt][i] - m); sum += e[i]; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8_t f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (__bf16)e[8 * s2 + j];
+                pf[kt][qt][s2] = f;
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        inv_sum[qt] = 1.0f / sum;
+    }
+    const int row_base = b * T;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        bf16x8_t vf[NT][2];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+                u16x8_t raw;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[j] = vraw[dt][kt][s2][j];
+                vf[kt][s2] = __builtin_bit_cast(bf16x8_t, raw);
+            }
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            f32x16_t o;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt <= qt; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s2], pf[kt][qt][s2], o, 0, 0, 0);
+            const int q = 32 * qt + r;
+            if (q < T) {
+                const int row = row_base + q;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int col = h * 64 + 32 * dt + 8 * g4 + 4 * hf;
+                    bf16_t* dst = a.out_packed_mb ? reinterpret_cast<bf16_t*>(a.out) + packed_off(row, col, a.out_packed_mb)
+                                                  : reinterpret_cast<bf16_t*>(a.out) + (long long)row * D + col;
+                    uint2 pk;
+                    pk.x = (unsigned)f32_to_bf16(o[4 * g4] * inv_sum[qt]) | ((unsigned)f32_to_bf16(o[4 * g4 + 1] * inv_sum[qt]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(o[4 * g4 + 2] * inv_sum[qt]) | ((unsigned)f32_to_bf16(o[4 * g4 + 3] * inv_sum[qt]) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            }
+        }
+    }
+#endif
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
     const int chunks = a.head_dim / 8;
     if (a.head_dim % 8 != 0 || chunks > 64 || (chunks & (chunks - 1)) != 0) return hipErrorInvalidValue;
@@ -529,6 +661,14 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
             else { if (one) attention_fewq_kernel<float, 1><<<g2, 256, 0, st>>>(a); else attention_fewq_kernel<float, 2><<<g2, 256, 0, st>>>(a); }
             return hipGetLastError();
         }
+    }
+    // causal prefill of a whole prompt (bf16, head size 64, nothing cached before it): the matrix-core kernel, one wave per (sample, head)
+    if (a.causal && a.dtype == DT_BF16 && a.head_dim == 64 && a.Tq > 4 && a.Tq <= 64 && a.t_base == 0 && !a.t_base_dev && !a.dbg &&
+        (a.n_heads * 64) % 8 == 0) {
+        const int g2 = (a.B * a.n_heads + 3) / 4;
+        if (a.Tq <= 32) attention_prefill_mfma_kernel<1><<<g2, 256, 0, st>>>(a);
+        else attention_prefill_mfma_kernel<2><<<g2, 256, 0, st>>>(a);
+        return hipGetLastError();
     }
     const int grid = (a.B * a.n_heads * a.Tq + 3) / 4;
     if (a.dtype == DT_BF16) attention_kernel<bf16_t><<<grid, 256, 0, st>>>(a);

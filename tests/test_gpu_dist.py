@@ -58,3 +58,39 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run(tmp_path, mode):
         assert np.array_equal(got['pixels'], px.cpu().numpy())
     assert len(info['host_ms_per_submit_3_lanes']) == 2
     print('host ms per submitted step (3 lanes) per rank:', [round(v, 3) for v in info['host_ms_per_submit_3_lanes']])
+
+
+def _bench_two_ranks(extra_env, gpus_needed):
+    if torch.cuda.device_count() < gpus_needed:
+        pytest.skip(f'needs {gpus_needed} visible GPUs (this box has {torch.cuda.device_count()})')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--merge', '2', '--inflight', '2',
+           '--config', os.path.join(ROOT, 'configs', 'tiny-cls.yaml'), '--no-cpu-baseline', '--no-roofline']
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    return json.loads(line)
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), on boxes with a single GPU:
+    HQT_BENCH_SHARE_GPU=1 maps both ranks onto the visible device and rendezvous runs over gloo -- the N > 1 control flow (default
+    `--gather pixels`, its pre-flight, barrier + max-over-ranks timing, per-rank host times, one JSON line from rank 0); the numbers
+    mean nothing."""
+    d = _bench_two_ranks({'HQT_BENCH_SHARE_GPU': '1'}, 1)
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 * d['config']['per_gpu_batch'] and d['scaling'] == 'weak'
+    # gloo cannot gather device tensors: the pre-flight then drops the gather and says so -- the fallback the RCCL run relies on
+    assert d['config']['gather'].startswith(('pixels', 'none (requested gather failed')), d['config']['gather']
+    assert len(d['host_ms_per_step_ranks']) == 2 and d['value'] > 0
+
+
+def test_bench_two_gpus_over_rccl():
+    """The same launch on two real GPUs: the nccl (= RCCL) backend, `dist.gather` of every step's pixels to rank 0 inside the timed
+    region (BASELINE configs[2]).  Skipped on one-GPU boxes -- the round-end multi-GPU run of the driver is then the first time this
+    branch executes; the gather is pre-flighted there and the line says so if it had to be dropped."""
+    d = _bench_two_ranks({}, 2)
+    assert d['n_gpus'] == 2 and d['config']['gather'].startswith('pixels'), d['config']['gather']

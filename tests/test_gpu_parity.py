@@ -123,6 +123,37 @@ def test_tiny_txt_prefill():
         gate(f'tiny_txt_prefill.fast_logits(graph={graph})', err, 0.15)
 
 
+@pytest.mark.parametrize('T', [20, 32, 48, 64])
+def test_causal_prefill_on_the_matrix_cores_vs_oracle(T):
+    """The causal prompt prefill of FAST precision at head size 64 (attention_prefill_mfma_kernel: one wave per (sample, head),
+    S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x16_bf16, layers.py:107-111) for prompt lengths that fill one tile, straddle
+    two and fill both -- rows beyond the prompt are clamped and masked, key tiles above the diagonal skipped.  Two body layers, so that
+    the second layer's keys depend on the first layer's attention output at EVERY prompt position (a wrong row anywhere in the
+    T x T attention changes the logits); teacher-forced on the oracle's codes, logits inside the bf16 gate, on a NaN-poisoned
+    workspace (cache rows beyond the prompt must never be read), batch 5 (the last workgroup has idle waves)."""
+    spec = Stage2Spec(embed_dim=128, n_layers=2, n_heads=2, n_layers_depth=1, vocab_top=256, vocab_bot=256, vocab_txt=512,
+                      ctx_len_img=64, ctx_len_txt=T, n_classes=0, cond=2, embedding=0)
+    weights = synth.stage2_weights(spec, 501 + T, 'fixture')
+    B, n = 5, 3
+    noise = synth.exp_noise(502, n, B, spec.vocab_top)
+    txt = synth.text_ids(503, B, T, spec.vocab_txt)
+    want = O.OracleStage2(spec, weights).sample(txt, B, n, noise, return_logits=True)
+    import os
+    os.environ['HQT_POISON_WORKSPACE'] = '1'
+    try:
+        eng = engine_s2(spec, weights, B, 8)
+    finally:
+        del os.environ['HQT_POISON_WORKSPACE']
+    ct, cb, lg = eng.sample(B, torch.from_numpy(txt), n, precision=PRECISION_EXACT, noise=torch.from_numpy(noise), return_logits=True)
+    assert np.abs(np_(lg) - want[2]).max() <= LOGIT_TOL and (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all()
+    ft, fb = torch.from_numpy(want[0]), torch.from_numpy(want[1])
+    for graph in (False, True):
+        _, _, lf = eng.sample(B, torch.from_numpy(txt), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise), force_top=ft, force_bot=fb,
+                              return_logits=True, use_graph=graph)
+        assert bool(torch.isfinite(lf).all())
+        gate(f'prefill_mfma.fast_logits(T={T},graph={graph})', np.abs(np_(lf) - want[2]).max(), 0.15)
+
+
 def test_ragged_batches_and_b1_vs_oracle(tiny_cls):
     """B = 1 (which the reference cannot run, hierarchical_ar.py:719) and an odd batch, against the oracle."""
     fx, spec, weights, eng = tiny_cls
