@@ -321,7 +321,7 @@ def main():
     sample_codes(0, not args.no_graph)  # untimed: the policy change re-captures lane 0's graph; keep that out of the pass below
 
     # ---- reference pass: the same steps one at a time on one lane (the reference harness's order), with per-phase events
-    n_serial = args.steps if inflight == 1 else min(args.steps, 3)
+    n_serial = args.steps if (inflight == 1 and merge == 1) else min(args.steps, 3)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n_serial)]
     keep = []
     torch.cuda.synchronize(dev)

@@ -1,16 +1,22 @@
 #!/bin/bash
-# Everything profiles/r02_* is made of, in one GPU-box call (outputs under gpurun_out/r02/; copy what is to be judged into profiles/).
-#   gpurun --timeout 3000 -- 'bash tools/collect_round_evidence.sh'
+# Everything profiles/r03_* is made of, in one GPU-box call (outputs under gpurun_out/r03/; copy what is to be judged into profiles/).
+#   gpurun --timeout 3300 -- 'bash tools/collect_round_evidence.sh'
 set -u
-O=gpurun_out/r02
+R=r03
+O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 PMCRUN="python3 bench.py --batch 512 --merge 1 --inflight 1 --positions 2 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph"
+# ---- the default line, and the same kernels one lane at a time under the profiler (the per-kernel averages the roofline record must agree with)
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
-python tools/prof_summary.py $O/stats 60 > $O/kernel_stats_bench_default.txt
-cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench_default.csv
-rm -rf $O/stats
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --inflight 1 --merge 8 --steps 24 --warmup 8 --no-cpu-baseline > $O/bench_one_lane_under_rocprof.json 2> $O/bench_one_lane_under_rocprof.err
+python tools/prof_summary.py $O/stats1 60 > $O/kernel_stats_one_lane_merge8.txt
+cp $(find $O/stats1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_one_lane_merge8.csv
+rm -rf $O/stats1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -- python3 bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.json 2> $O/bench_default_under_rocprof.err
+python tools/prof_summary.py $O/stats3 60 > $O/kernel_stats_bench_default.txt
+rm -rf $O/stats3
+# ---- counters: separate passes over a bounded run of the same 512-row kernels
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- $PMCRUN > /dev/null 2> $O/pmc_$c.err
   python tools/pmc_summary.py $O/pmc_$c > $O/pmc_${c}_rows512_positions2.txt
@@ -21,21 +27,36 @@ python tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma_raw.txt
 python tools/pmc_mfma.py $O/pmc_mfma_raw.txt $O/pmc_mfma_util_rows512_positions2.txt > /dev/null
 rm -rf $O/pmc_mfma
 python tools/pmc_traffic.py $O/pmc_FETCH_SIZE_rows512_positions2.txt $O/pmc_WRITE_SIZE_rows512_positions2.txt $O/pmc_latest.json
-timeout 600 python bench.py --sampler quality --no-cpu-baseline > $O/bench_quality_sampler.json 2>/dev/null
+# counters of a 2048-row pass (what a merge-32 schedule runs): the tile GEMMs where they are MFMA-bound
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma2k -- python3 bench.py --batch 2048 --merge 1 --inflight 1 --positions 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph --decode-precision fast > /dev/null 2> $O/pmc_mfma2k.err
+python tools/pmc_summary.py $O/pmc_mfma2k > $O/pmc_mfma2k_raw.txt
+python tools/pmc_mfma.py $O/pmc_mfma2k_raw.txt $O/pmc_mfma_util_rows2048_positions1.txt > /dev/null
+rm -rf $O/pmc_mfma2k $O/pmc_mfma2k_raw.txt
+# ---- other schedules and configurations of the same build
+timeout 600 python bench.py --merge 32 --inflight 2 --steps 128 --no-cpu-baseline > $O/bench_merge32_lanes2.json 2>/dev/null
+timeout 600 python bench.py --merge 48 --inflight 2 --no-cpu-baseline --no-roofline > $O/bench_merge48_lanes2.json 2>/dev/null
 timeout 600 python bench.py --merge 1 --inflight 3 --no-cpu-baseline --no-roofline > $O/bench_merge1_lanes3.json 2>/dev/null
-timeout 600 python bench.py --merge 4 --inflight 3 --no-cpu-baseline --no-roofline > $O/bench_merge4_lanes3.json 2>/dev/null
-timeout 600 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline --no-roofline > $O/bench_serial.json 2>/dev/null
-timeout 600 python bench.py --batch 256 --merge 1 --inflight 1 --steps 24 --no-cpu-baseline --no-roofline > $O/bench_batch256_inflight1.json 2>/dev/null
+timeout 600 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
+timeout 600 python bench.py --sampler quality --no-cpu-baseline > $O/bench_quality_sampler.json 2>/dev/null
 timeout 600 python bench.py --decode-precision fast --no-cpu-baseline --no-roofline > $O/bench_decode_fast.json 2>/dev/null
-timeout 600 python bench.py --config configs/imagenet-12l-level3.yaml --steps 48 --no-cpu-baseline --no-roofline > $O/bench_level3.json 2>/dev/null
-timeout 600 python bench.py --config configs/cc15m-12l-txt.yaml --steps 48 --no-cpu-baseline --no-roofline > $O/bench_text_cond.json 2>/dev/null
+timeout 900 python bench.py --config configs/imagenet-12l-level3.yaml --steps 48 > $O/bench_level3.json 2>/dev/null
+timeout 900 python bench.py --config configs/cc15m-12l-txt.yaml --steps 48 > $O/bench_text_cond.json 2>/dev/null
 timeout 300 python tools/bench_decode.py --precision split > $O/decode_split_batch64.json 2>/dev/null
 timeout 300 python tools/bench_decode.py --precision fast > $O/decode_fast_batch64.json 2>/dev/null
+timeout 300 python tools/bench_decoder.py --precision split > $O/decoder_only_1024_split.json 2>/dev/null
+timeout 300 python tools/bench_decoder.py --precision fast > $O/decoder_only_1024_fast.json 2>/dev/null
+timeout 300 python tools/bench_encode.py > $O/encode_batch64.json 2>/dev/null
 timeout 300 python tools/diag_overlap.py --rows 512 > $O/diag_overlap_rows512.json 2>/dev/null
-timeout 200 tools/micro/bench_split > $O/micro_split_conv_variants.txt 2>&1
-timeout 300 tools/micro/bench_stream > $O/micro_stream_gemm_variants.txt 2>&1
+timeout 300 python tools/diag_overlap.py --rows 2048 --lanes 2 --passes 4 > $O/diag_overlap_rows2048.json 2>/dev/null
+timeout 300 python tools/ar_pass_time.py --rows 64 512 1024 2048 3072 --policy 1 --breakdown > $O/ar_pass_time_by_rows.json 2>/dev/null
+timeout 300 python tools/ar_pass_time.py --rows 512 --policy 1 --breakdown --by-rows > $O/ar_pass_time_rows512_per_gemm.json 2>/dev/null
+# ---- micro-benchmarks
+timeout 300 tools/micro/bench_split > $O/micro_split_conv_variants.txt 2>&1
+timeout 300 tools/micro/bench_tile > $O/micro_tile_gemm.txt 2>&1
 timeout 200 tools/micro/bench_attn > $O/micro_attention.txt 2>&1
-ls -la $O
 timeout 100 tools/micro/bench_sampler > $O/micro_sampler.txt 2>&1
-timeout 200 tools/micro/bench_panel > $O/micro_panel_gemm_experiment.txt 2>&1
-ls $O | wc -l
+# ---- measured values behind every FAST gate
+rm -f $O/fast_gates.txt
+HQT_RECORD_GATES=$O/fast_gates.txt timeout 900 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1
+tail -3 $O/pytest_gpu.log
+ls -la $O | head -70
