@@ -44,7 +44,7 @@ enum { HQT_EMB_TRANSFORMER1 = 0, HQT_EMB_REDUCE = 1 };
  * softmax/normalisation/sampler (the counterpart of the reference's use_fp16=True autocast path).
  * SPLIT (stage-1 entry points: decode / encode) = fp32 tensors, fp32 GroupNorm / softmax / activations, and the
  * convolutions on the matrix cores with every fp32 operand carried as two fp16 values (hi, lo * 2^11): three
- * v_mfma_f32_32x32x16_f16 per product term, fp32 accumulation -- fp32-accurate (2^-22 per operand), what the reference's
+ * v_mfma_f32_16x16x32_f16 per product term, fp32 accumulation -- fp32-accurate (2^-22 per operand), what the reference's
  * fp32 decode (measure_throughput/__main__.py:108-113, outside autocast) computes up to summation order, at matrix-core
  * speed; layers whose shapes the split kernels do not take run the EXACT kernels. */
 enum { HQT_PRECISION_EXACT = 0, HQT_PRECISION_FAST = 1, HQT_PRECISION_SPLIT = 2 };
