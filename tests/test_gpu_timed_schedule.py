@@ -73,6 +73,43 @@ def test_merged_pass_kernels_vs_oracle_at_imagenet_width():
     eng.close()
 
 
+def test_tile_kernels_at_ragged_row_counts_vs_oracle():
+    """Row counts that are not a power of two -- 1280 rows in the body (10 row tiles of 128: one full group of 8 in the XCD-aware tile
+    order and one of 2), 5120 in depth sub-step 1 -- at D = 512 / 8 heads of 64 / V = 1024, where every GEMM of the pass takes the tile
+    kernels without split-K (fc2: K = 2048).  EXACT codes bit-identical and logits <= 2e-4, FAST teacher-forced logits gated, variants
+    asserted.  (The 512 / 2048-row test above covers the benchmark's own width, the 64 x 128 geometry and the split-K combine.)"""
+    spec = Stage2Spec(embed_dim=512, n_layers=1, n_heads=8, n_layers_depth=1, vocab_top=1024, vocab_bot=1024, vocab_txt=64,
+                      ctx_len_img=64, ctx_len_txt=16, n_classes=1000, cond=1, embedding=0)
+    weights = synth.stage2_weights(spec, 41, 'fixture')
+    B, n = 1280, 3
+    noise = synth.exp_noise(42, n, B, spec.vocab_top)
+    cond = (np.arange(B) * 13) % spec.n_classes
+    want = O.OracleStage2(spec, weights).sample(cond, B, n, noise, return_logits=True)
+    eng = Engine(spec, None, torch.device('cuda:0'), B, spec.ctx_len_img)
+    eng.load(stage2=weights)
+    eng.finalize()
+    eng.set_policy(POLICY_THROUGHPUT)
+    tn, tc = torch.from_numpy(noise), torch.from_numpy(cond)
+    ct, cb, lg = eng.sample(B, tc, n, precision=PRECISION_EXACT, noise=tn, return_logits=True, use_graph=False)
+    assert np.abs(np_(lg) - want[2]).max() <= LOGIT_TOL
+    assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all()
+    ft, fb = torch.from_numpy(want[0]), torch.from_numpy(want[1])
+    eng.timing(True)
+    eng.timing_reset()
+    for graph in (False, True):
+        _, _, lf = eng.sample(B, tc, n, precision=PRECISION_FAST, noise=tn, force_top=ft, force_bot=fb, return_logits=True, use_graph=graph)
+        gate(f'timed_schedule.fast_logits(rows=1280,graph={graph})', np.abs(np_(lf) - want[2]).max(), 0.12)
+        if not graph:
+            v = variants(eng)
+            eng.timing(False)
+            tile = {k: c for k, c in v.items() if k.startswith('variant:tile_gemm')}
+            stream = {k: c for k, c in v.items() if k.startswith('variant:stream_gemm')}
+            assert not stream, f'streaming GEMMs ran in a 1280-row pass: {stream}'
+            assert sum(tile.values()) == 14 * n and not any('splitk' in k for k in tile), v
+    eng.set_policy(POLICY_LATENCY)
+    eng.close()
+
+
 def _one_layer_model(seed):
     cfg = merge(get_base_config(False), {
         # the tiny stage 1 of configs/tiny-cls.yaml with the full 8192-entry codebook (the decode is not what this test is about)
