@@ -521,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void conv2x2_split_up16_kernel(GemmArgs g) 
                 if (ABL != 4) {
                     if (tap == 1 || tap == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(wh[slot][0]), "+v"(wl[slot][0]), "+v"(wh[slot][1]), "+v"(wl[slot][1]));
                     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wh[slot][0]), "+v"(wl[slot][0]), "+v"(wh[slot][1]), "+v"(wl[slot][1]));
+                    load_b(S + 1, nslot);                               // the slot tap s - 1 released takes the filters of tap s + 1: a whole tap of MFMAs ahead
                 }
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
@@ -549,7 +550,9 @@ __global__ __launch_bounds__(256, 2) void conv2x2_split_up16_kernel(GemmArgs g) 
                     // the piece written here goes in FRONT of the fragment reads: lgkmcnt(4) of the next pair then covers exactly those reads
                     if (pr >= 1 && tap >= 2 && ABL != 2) {
                         const int u = 3 * (tap - 2) + pr - 1;
-                        asm volatile("s_waitcnt vmcnt(4)" : "+v"(pst[u]));      // (already true: see above)
+                        // (already landed: see above; the count only has to be loose enough not to wait for anything younger -- the
+                        //  filters of the next tap, and at tap 2 the three pieces tap 1 fetched)
+                        if (tap == 2) asm volatile("s_waitcnt vmcnt(7)" : "+v"(pst[u])); else asm volatile("s_waitcnt vmcnt(4)" : "+v"(pst[u]));
                         if (u == 0) HQT_STORE_PIECE(cc ^ 1, 0); else if (u == 1) HQT_STORE_PIECE(cc ^ 1, 1); else if (u == 2) HQT_STORE_PIECE(cc ^ 1, 2);
                         else if (u == 3) HQT_STORE_PIECE(cc ^ 1, 3); else if (u == 4) HQT_STORE_PIECE(cc ^ 1, 4); else HQT_STORE_PIECE(cc ^ 1, 5);
                     }
@@ -561,7 +564,6 @@ __global__ __launch_bounds__(256, 2) void conv2x2_split_up16_kernel(GemmArgs g) 
                         if (pr == 2) { HQT_READ_A16(cc, ntapoff, 0); HQT_READ_A16(cc, ntapoff, 1); }
                         else { HQT_READ_A16(cc, ntapoff, 2); HQT_READ_A16(cc, ntapoff, 3); }
                     }
-                    if (pr == 0) load_b(S + 1, nslot);                  // the slot tap s - 1 released takes the filters of tap s + 1
                     if (pr >= 1 && tap < 2 && ABL != 2) load_piece(cn, 3 * tap + pr - 1);
                 }
             }
