@@ -171,7 +171,6 @@ struct GemmArgs {
     float* gn_part_out;
     int gn_out_groups;
     int tune;                // 0: latency-oriented tile choice, 1: throughput-oriented (hqt_set_policy)
-    int w_nt;                // streaming GEMM: 1 = fetch the weights with the non-temporal hint (read once), 0 = ordinary loads (re-read soon)
     // ---- SPLIT precision (split_kernels.h): A holds fp16 [row][hi K | lo K] planes, Bw the hi filters, Bw_lo the lo filters;
     //      C / resid are fp32.  gn_part_out_d: per-tile GroupNorm partials of the fp32 output as doubles (layout of gn_part_out).
     const void* Bw_lo;

@@ -118,7 +118,6 @@ struct hqt_handle {
     int resid_nparts = 0;                     // partial row statistics the last STORE_RESID GEMM left per row (run_linear)
     bool tile_gemm = true;                    // merged passes through the LDS-tiled MFMA kernels (HQT_NO_TILE_GEMM=1: streaming kernels at every row count)
     float* splitk = nullptr;                  // split-K partial slabs of the streaming GEMM
-    int cur_w_nt = 0;                         // GemmArgs.w_nt of the streaming GEMMs being issued (set per block)
     size_t splitk_elems = 0;
     struct { const float* slabs; int S; int rows; const float* bias; } pend = {nullptr, 0, 0, nullptr};   // folded in by the next LayerNorm
     StepState* state = nullptr;
@@ -845,7 +844,6 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     g.bias = l.b32;
     g.zero_page = h->zero_page;
     g.tune = h->policy;
-    g.w_nt = h->cur_w_nt;
     if (g.alpha == 0.0f) g.alpha = 1.0f;
     if (g.lda == 0) g.lda = l.K;
     // tools/ar_pass_time.py --by-rows: one timing slot per (GEMM, row count) instead of per GEMM
@@ -971,18 +969,8 @@ static int run_ln(hqt_handle* h, hipStream_t st, float* x, const float* g, const
 }
 
 // One transformer block over M = B*Tq rows (stage2/layers.py:324-328,371-375)
-// Non-temporal weight fetches (GemmArgs.w_nt).  HQT_W_NT = 0 (default): never, 1: the body blocks only, 2: every streamed weight.
-// Measured with 3 steps in flight: 1183 / 1173 / 1141 images/s -- ordinary loads let the lanes that trail through the same
-// weights hit the 256 MB Infinity Cache (and the depth blocks' second pass per position); one lane alone: AR 75.9 / 76.4 / 76.9 ms.
-// (The same hint on the attention kernel's K / V fetches made no measurable difference either way.)
-static int weights_nt(bool body) {
-    static const int mode = getenv("HQT_W_NT") ? atoi(getenv("HQT_W_NT")) : 0;
-    return mode == 2 || (mode == 1 && body) ? 1 : 0;
-}
-
 static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float* x, int Tq, void* kc, void* vc, int Tcache,
                      int t_base, const int* t_base_dev, int causal) {
-    h->cur_w_nt = weights_nt(bw.body);
     const int D = h->cfg.embed_dim, M = c.B * Tq;
     const int adt = c.md.act_dt();
     // FAST: GEMM A operands travel in the MFMA-fragment-packed layout when the streaming GEMM serves them
@@ -1023,7 +1011,6 @@ static bool dln_ok(hqt_handle* h, const SampleCtx& c, const BlockW& bw, int M) {
 }
 static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float* x32, bf16_t* xpk, float* parts, int* nparts,
                          int Tq, void* kc, void* vc, int Tcache, int t_base, const int* t_base_dev, int causal) {
-    h->cur_w_nt = weights_nt(bw.body);
     const int D = h->cfg.embed_dim, M = c.B * Tq, pk = packed_mb(M);
     GemmArgs g{};
     g.A = xpk; g.M = M; g.batch = 1; g.a_packed_mb = pk;

@@ -185,10 +185,10 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
             e_res[j] = *reinterpret_cast<const f32x4*>(g.store == STORE_RESID ? reinterpret_cast<const float*>(g.C) + (size_t)m * g.ldc + ncol : zsrc);
         }
     };
-    // Two copies of the run loop: weights fetched with the non-temporal hint (streamed once: the body's 340 MB per position) or as
-    // ordinary loads (re-read soon: the depth blocks run twice per position, and steps in flight on other lanes re-read what
-    // this one just pulled through the 256 MB Infinity Cache).  GemmArgs.w_nt picks; a runtime select per load would put the
-    // loads in branches.
+    // The weights are fetched with ORDINARY loads: the depth blocks run twice per position and steps in flight on other lanes re-read
+    // what this one just pulled through the 256 MB Infinity Cache (the non-temporal hint measured 1173 / 1141 vs 1183 images/s with
+    // 3 lanes, body blocks only / every weight; one lane alone 76.4 / 76.9 vs 75.9 ms).  WNT = true is the non-temporal form of the
+    // same loop, kept as a template argument for tools/micro/bench_stream.
     auto run_main = [&](auto nt_tag) {
     constexpr bool WNT = decltype(nt_tag)::value;
     for (; ks + U <= cnt; ks += U) {
@@ -279,8 +279,7 @@ __global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void str
     for (int u = 0; u < U; ++u) { multiply(u); __builtin_amdgcn_sched_barrier(0); }
     ks += U;
     };
-    if (PIPE) { if (g.w_nt) run_pipe(std::true_type{}); else run_pipe(std::false_type{}); }
-    else if (g.w_nt) run_main(std::true_type{}); else run_main(std::false_type{});
+    if (PIPE) run_pipe(std::false_type{}); else run_main(std::false_type{});
     if (first) {                                      // K too short for a full run: nothing was prefetched
         chain_wait(g.chain, polled);
     }
@@ -555,40 +554,11 @@ int stream_gemm_splitk(const GemmArgs& g) {
         if (wgs * S <= 256 && KS % (S * 8) == 0) return S;
     return 1;
 }
-// Tuning hook: HQT_GEMM_<class>="MBW,NT,NW,U" picks another instantiated variant for a shape class
-// (M64W / M64N / M256W / M256N: 64- or 256-row activations, wide (N >= 3072) or narrow weights).
-struct StreamCfg { int mbw, nt, nw, u; };
-static StreamCfg stream_cfg_env(const char* name) {
-    StreamCfg c{0, 0, 0, 0};
-    const char* v = getenv(name);
-    if (v) sscanf(v, "%d,%d,%d,%d", &c.mbw, &c.nt, &c.nw, &c.u);
-    return c;
-}
-template <typename TC>
-static hipError_t launch_stream_cfg(const StreamCfg& c, const GemmArgs& g, const bf16_t* wpk, hipStream_t st, bool& taken, int S = 1, float* slabs = nullptr) {
-    taken = true;
-    if (g.a_packed_mb % c.mbw != 0 || (g.N / 32) % c.nt != 0) { taken = false; return hipSuccess; }
-#define TRY(MBW, NT, NW, U, TC_) if (c.mbw == MBW && c.nt == NT && c.nw == NW && c.u == U) return launch_stream_t<MBW, NT, NW, U, TC>(g, wpk, S, slabs, st);
-    STREAM_CASES(TRY, TC)
-#undef TRY
-    taken = false;
-    return hipSuccess;
-}
 template <typename TC>
 static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
-    if (S == 1 && (g.a_packed_mb == 2 || g.a_packed_mb == 8)) {
-        static const StreamCfg cfgs[4] = {stream_cfg_env("HQT_GEMM_M64W"), stream_cfg_env("HQT_GEMM_M64N"),
-                                          stream_cfg_env("HQT_GEMM_M256W"), stream_cfg_env("HQT_GEMM_M256N")};
-        const StreamCfg& c = cfgs[(g.a_packed_mb == 8 ? 2 : 0) + (g.N >= 3072 ? 0 : 1)];
-        if (c.mbw > 0) {
-            bool taken = false;
-            const hipError_t e = launch_stream_cfg<TC>(c, g, wpk, st, taken);
-            if (taken) return e;
-        }
-    }
     if (S == 1 && g.tune == 1) {
         // throughput policy (several batches in flight): fewest CU-microseconds per GEMM.  Re-swept with cacheable weight loads
-        // (tools/sweep_gemm_policy.sh, 3 lanes): 64-row tiles over 6-step runs for the 64-row GEMMs, 64-row WEIGHT tiles for the
+        // (round-1 sweep, 3 lanes): 64-row tiles over 6-step runs for the 64-row GEMMs, 64-row WEIGHT tiles for the
         // narrow 256-row ones (proj / fc2 of depth sub-step 1): 1180 -> 1220 images/s; alone these choices cost 4-5 ms of AR.
         if (g.a_packed_mb == 2 && g.N >= 3072) return launch_stream_t<2, 1, 8, 6, TC>(g, wpk, 1, nullptr, st);
         if (g.a_packed_mb == 2) return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);   // (16-wave variants <1,1,16,6> etc.: no difference beyond the +-2 % run-to-run noise)

@@ -584,7 +584,7 @@ bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
 // Split-K factor: only the residual producers with a long K (fc2: K = 4 D) whose tiles would leave most of the 768 resident
 // slots empty; the slices leave fp32 slabs that resid_combine_kernel finishes (one extra launch: not worth it at K = D).
 TilePlan tile_gemm_plan(const GemmArgs& g) {
-    static const int max_s = getenv("HQT_TILE_SPLITK") ? atoi(getenv("HQT_TILE_SPLITK")) : 8;        // A/B runs: 1 = never split
+    constexpr int max_s = 8;
     static const int max_geom = getenv("HQT_TILE_GEOM") ? atoi(getenv("HQT_TILE_GEOM")) : 1;         // A/B runs: 0 = 128 x 128 tiles only
     TilePlan p{0, Tile128::BM, Tile128::BN, 1};
     const int KS = g.K / 16, tiles = ((g.M + p.bm - 1) / p.bm) * (g.N / p.bn);
