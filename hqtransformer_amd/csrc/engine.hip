@@ -1107,6 +1107,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
         Timed t(h, "sampler", c.st);
         SamplerArgs s{h->logits, B, V, 1, B, c.o.temperature_top, c.o.top_k_top, c.o.top_p_top, c.noise, 0,
                       h->state, h->rows, c.o.n_steps, c.out_top, c.logits_out};
+        s.fast_math = c.md.fast ? 1 : 0;
         // the draw and the embedding lookup of the drawn code in one kernel: the sampler's workgroup of sample b also writes the
         // four input rows of depth sub-step 1 (HQT_NO_FUSED_EMBED=1: separate depth_embed_kernel, for A/B runs)
         static const bool fuse = !getenv("HQT_NO_FUSED_EMBED");
@@ -1144,6 +1145,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
         Timed t(h, "sampler", c.st);
         SamplerArgs s{h->logits, 4 * B, V, 4, B, c.o.temperature_bot, c.o.top_k_bot, c.o.top_p_bot, c.noise, 1,
                       h->state, h->rows, c.o.n_steps, c.out_bot, c.logits_out};
+        s.fast_math = c.md.fast ? 1 : 0;
         HIPCHK(launch_sampler(s, c.st));
     }
     return HQT_OK;
@@ -1214,6 +1216,7 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
             Timed t(h, "sampler", c.st);
             SamplerArgs sa{h->logits, M, V, Tq, B, c.temperature[lv], c.top_k[lv], c.top_p[lv], c.noise, draw0[lv],
                            h->state, h->rows, c.o.n_steps, outs[lv], c.logits_out, 21};
+            sa.fast_math = c.md.fast ? 1 : 0;
             HIPCHK(launch_sampler(sa, c.st));
         }
     }

@@ -701,7 +701,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // NT threads per logits row: 1024 (16 waves, 4 per SIMD) hides the latency of the exp / log / divide / Philox chains that a
 // lone 4-wave workgroup per CU exposes (25 -> ~10 us per launch at V = 8192); 256 for small vocabularies.
-template <int NT>
+// FM: fast-math forms for FAST-precision calls.  The plain path (no top-k / top-p) is bound by the IEEE expf / logf / divisions of its
+// 8192 entries per row, not by memory (21.5 us per 512 rows); EXACT calls keep them: their draws are compared bit for bit with the oracle.
+template <int NT, bool FM>
 __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {   // 8 waves per SIMD = two 1024-thread rows per CU: the plain path is 30 % slower at 7 (tools/micro/bench_sampler)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // layout: double dsum[NT]; float redf[16]; int redi[16]; unsigned hist[256]; int sel[4]; float lp[V];
@@ -725,10 +727,11 @@ __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {
     const long long nidx = (((long long)step * draws + draw) * a.B + b) * V;
 
     // ---- temperature (logits /= T, hierarchical_ar.py:763,779) and raw-logit dump
+    const float inv_t = FM ? __builtin_amdgcn_rcpf(a.temperature) : 0.0f;
     for (int i = tid; i < V; i += NT) {
         const float v = lg[i];
         if (a.logits_out) a.logits_out[nidx + i] = v;
-        lp[i] = v / a.temperature;
+        lp[i] = FM ? v * inv_t : v / a.temperature;
     }
     __syncthreads();
 
@@ -784,9 +787,10 @@ __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {
     for (int i = tid; i < V; i += NT) m = fmaxf(m, lp[i]);
     m = block_reduce(m, OpMax(), redf);
     float s = 0.0f;
-    for (int i = tid; i < V; i += NT) { const float e = expf(lp[i] - m); lp[i] = e; s += e; }
+    for (int i = tid; i < V; i += NT) { const float e = FM ? __expf(lp[i] - m) : expf(lp[i] - m); lp[i] = e; s += e; }
     s = block_reduce(s, OpAdd(), redf);
-    for (int i = tid; i < V; i += NT) lp[i] = lp[i] / s;
+    const float inv_s = FM ? __builtin_amdgcn_rcpf(s) : 0.0f;
+    for (int i = tid; i < V; i += NT) lp[i] = FM ? lp[i] * inv_s : lp[i] / s;
     __syncthreads();
 
     // ---- top-p (sampling.py:22-37): descending sort, prefix sums accumulated in double and rounded
@@ -931,7 +935,10 @@ __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {
             uint32_t rnd[4];
             philox4x32_10((uint32_t)i4, (uint32_t)(step * draws + draw), (uint32_t)grow, (uint32_t)(grow >> 32), k0, k1, rnd);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = -logf(((float)(rnd[e] >> 8) + 0.5f) * (1.0f / 16777216.0f));
+            for (int e = 0; e < 4; ++e) {
+                const float u = ((float)(rnd[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                q[e] = FM ? -__logf(u) : -logf(u);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -939,7 +946,7 @@ __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {
             if (i < V) {
                 float p = lp[i];
                 if (use_p) p = p / renorm;
-                const float ratio = p / q[e];
+                const float ratio = FM ? p * __builtin_amdgcn_rcpf(q[e]) : p / q[e];
                 if (ratio > best) { best = ratio; besti = i; }      // ascending i per lane: first max wins
             }
         }
@@ -1016,9 +1023,11 @@ hipError_t sampler_configure(int V, bool use_top_p) {
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
     if (dev >= 0 && dev < 64 && smem <= limit[dev]) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sampler_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    for (const void* k : {reinterpret_cast<const void*>(sampler_kernel<256, false>), reinterpret_cast<const void*>(sampler_kernel<256, true>),
+                          reinterpret_cast<const void*>(sampler_kernel<1024, false>), reinterpret_cast<const void*>(sampler_kernel<1024, true>)}) {
+        e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
     if (e == hipSuccess && dev >= 0 && dev < 64) limit[dev] = smem;
     return e;
 }
@@ -1026,8 +1035,8 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
     int n2;
     const size_t smem = sampler_smem(a.V, a.top_p > 0.0f, n2);
     if (smem > 160 * 1024) return hipErrorInvalidValue;               // sampler_configure(V, top_p) ran in sample_run for this call's options
-    if (a.V >= 4096) sampler_kernel<1024><<<a.R, 1024, smem, st>>>(a, n2);
-    else sampler_kernel<256><<<a.R, 256, smem, st>>>(a, n2);
+    if (a.V >= 4096) { if (a.fast_math) sampler_kernel<1024, true><<<a.R, 1024, smem, st>>>(a, n2); else sampler_kernel<1024, false><<<a.R, 1024, smem, st>>>(a, n2); }
+    else { if (a.fast_math) sampler_kernel<256, true><<<a.R, 256, smem, st>>>(a, n2); else sampler_kernel<256, false><<<a.R, 256, smem, st>>>(a, n2); }
     return hipGetLastError();
 }
 

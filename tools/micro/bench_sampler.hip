@@ -17,9 +17,11 @@ int main() {
     RowKey* rows; CK(hipMalloc(&rows, B * sizeof(RowKey)));
     CK(launch_set_rows(rows, B, 1234, 0, st));
     int64_t* out; CK(hipMalloc(&out, (size_t)B * 64 * 4 * 8));
+    for (int fm = 0; fm < 2; ++fm)
     for (int mode = 0; mode < 3; ++mode) {
         for (int slots : {1, 4}) {
             SamplerArgs a{};
+            a.fast_math = fm;
             a.logits = logits; a.R = B * slots; a.V = V; a.slots = slots; a.B = B; a.temperature = 1.0f;
             a.top_k = mode >= 1 ? 2048 : 0; a.top_p = mode >= 2 ? 1.0f : 0.0f; a.draw0 = slots == 1 ? 0 : 1;
             a.state = state; a.rows = rows; a.n_steps = 64; a.out = out; a.draws = 5;
@@ -30,7 +32,7 @@ int main() {
             for (int r = 0; r < 20; ++r) CK(launch_sampler(a, st));
             CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("%-22s rows %4d : %8.2f us per launch\n", mode == 0 ? "plain" : (mode == 1 ? "top_k 2048" : "top_k 2048 + top_p 1"), a.R, 1000.f * ms / 20);
+            printf("%-22s %-10s rows %4d : %8.2f us per launch\n", mode == 0 ? "plain" : (mode == 1 ? "top_k 2048" : "top_k 2048 + top_p 1"), fm ? "fast-math" : "IEEE", a.R, 1000.f * ms / 20);
         }
     }
     return 0;
