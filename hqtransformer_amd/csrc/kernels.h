@@ -105,7 +105,7 @@ struct SamplerArgs {
     bf16_t* emb_xpk;             // optional packed copy (packed_off layout with emb_pk_mb row blocks)
     int emb_pk_mb;
     float* emb_parts;            // [4 B][2]
-    int fast_math;               // FAST-precision calls: v_exp / v_log / v_rcp forms of exp, log and the divisions (1-2 ulp each; EXACT keeps the IEEE forms the oracle is bit-compared with)
+    int fast_math;               // FAST-precision calls: v_exp / v_log / v_rcp forms of exp, log and the divisions (1-2 ulp each; EXACT keeps the IEEE forms: its draws are the parity gate, compared bit for bit)
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
 // depth sub-step 2 of the three-level model (hqtransformer.py:537-551): token i (raster (H1 H2 W1 W2)) =

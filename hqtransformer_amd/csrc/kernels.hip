@@ -702,7 +702,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // NT threads per logits row: 1024 (16 waves, 4 per SIMD) hides the latency of the exp / log / divide / Philox chains that a
 // lone 4-wave workgroup per CU exposes (25 -> ~10 us per launch at V = 8192); 256 for small vocabularies.
 // FM: fast-math forms for FAST-precision calls.  The plain path (no top-k / top-p) is bound by the IEEE expf / logf / divisions of its
-// 8192 entries per row, not by memory (21.5 us per 512 rows); EXACT calls keep them: their draws are compared bit for bit with the oracle.
+// 8192 entries per row, not by memory (21.5 us per 512 rows); EXACT calls keep them: their draws are the parity gate, compared bit for bit with the CPU restatement of the reference.
 template <int NT, bool FM>
 __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {   // 8 waves per SIMD = two 1024-thread rows per CU: the plain path is 30 % slower at 7 (tools/micro/bench_sampler)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
