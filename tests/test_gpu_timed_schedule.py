@@ -154,3 +154,40 @@ def test_inflight_sampler_merge8_lanes3_vs_oracle():
     gate('timed_schedule.inflight_merge8_lanes3.fast_vs_exact_first_position', first, 0.985, '>=')
     same = np.mean([((a[0] == b[0]).mean() + (a[1] == b[1]).mean()) / 2 for a, b in zip(res[False], res[True])])
     gate('timed_schedule.inflight_merge8_lanes3.fast_vs_exact_all_positions', same, 0.25, '>=')
+
+
+def test_full_benchmark_model_merged_pass_properties():
+    """The whole 12 + 4-layer ImageNet model (530.8 M parameters, random-init 'bench' weights) in ONE 512-row pass, exactly what a
+    merge-8 pass of bench.py runs -- beyond what the CPU restatement finishes in a test, so the size-independent properties:
+    (1) the FAST pass is bit-reproducible run to run and graph vs eager; (2) a row's draws do not depend on the pass it sits in: rows of
+    the 512-row EXACT pass equal the same steps run as 64-row calls (per-row Philox keys); (3) FAST and EXACT draw the same codes at
+    position 0 (inputs identical: the class embedding) for >= 98.5 % of the 512 x 5 draws, and their teacher-forced logits agree
+    inside the gate of the benchmark-size test (tests/test_gpu_parity.py::test_fast_vs_exact_at_the_benchmark_model_size)."""
+    import os
+    from hqtransformer_amd.config import load_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = ImageGPT2(load_config(os.path.join(root, 'configs', 'imagenet-12l.yaml')), seed=0).to('cuda').eval()
+    s2 = m.stage2.spec
+    assert (s2.n_layers, s2.n_layers_depth, s2.embed_dim) == (12, 4, 1536)
+    steps, B, n = 8, 64, 2
+    rows = steps * B
+    cls = torch.tensor([int((37 * k + 5) % s2.n_classes) for k in range(steps) for _ in range(B)])
+    seeds = [1000 + 17 * k for k in range(steps) for _ in range(B)]
+    offs = [i for _ in range(steps) for i in range(B)]
+    eng = m.stage2.engine(rows, 64)
+    eng.set_policy(POLICY_THROUGHPUT)
+    ex = eng.sample(rows, cls, n, precision=PRECISION_EXACT, row_seeds=seeds, row_offsets=offs, return_logits=True, use_graph=False)
+    runs = [eng.sample(rows, cls, n, precision=PRECISION_FAST, row_seeds=seeds, row_offsets=offs, use_graph=g) for g in (True, True, False)]
+    torch.cuda.synchronize()
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]), 'FAST 512-row pass is not reproducible (graph / eager / run to run)'
+    # (2) step 5 alone, as the unmerged 64-row call of the reference harness
+    k = 5
+    alone = eng.sample(B, cls[k * B:(k + 1) * B], n, precision=PRECISION_EXACT, seed=seeds[k * B], sample_offset=0, use_graph=False)
+    assert torch.equal(alone[0], ex[0][k * B:(k + 1) * B]) and torch.equal(alone[1], ex[1][k * B:(k + 1) * B]), 'a step draws differently inside a merged pass'
+    # (3) FAST vs EXACT
+    first = ((runs[0][0][:, 0] == ex[0][:, 0]).float().mean() + 4 * (runs[0][1][:, 0] == ex[1][:, 0]).float().mean()) / 5
+    gate('timed_schedule.full_model_rows512.fast_vs_exact_first_position', float(first), 0.985, '>=')
+    _, _, lf = eng.sample(rows, cls, n, precision=PRECISION_FAST, row_seeds=seeds, row_offsets=offs, force_top=ex[0], force_bot=ex[1], return_logits=True)
+    gate('timed_schedule.full_model_rows512.fast_logits', float((lf - ex[2]).abs().max()), 0.06)
+    eng.set_policy(POLICY_LATENCY)
