@@ -191,3 +191,42 @@ def test_full_benchmark_model_merged_pass_properties():
     _, _, lf = eng.sample(rows, cls, n, precision=PRECISION_FAST, row_seeds=seeds, row_offsets=offs, force_top=ex[0], force_bot=ex[1], return_logits=True)
     gate('timed_schedule.full_model_rows512.fast_logits', float((lf - ex[2]).abs().max()), 0.06)
     eng.set_policy(POLICY_LATENCY)
+
+
+@pytest.mark.parametrize('cfg_name', ['cc15m-12l-txt.yaml', 'imagenet-12l-level3.yaml'])
+def test_other_full_size_models_fast_vs_exact(cfg_name):
+    """BASELINE configs[4] (text-to-image: 64-token prompt prefill through attention_prefill_mfma_kernel and the tiled GEMMs, then
+    decode steps over 64 + t cached keys) and the three-level model, at their FULL size (12 + 4 layers, D = 1536) in a merged pass
+    of 128 rows: FAST reproducible run to run, FAST vs EXACT draws at position 0 under the same Philox keys, and teacher-forced FAST
+    logits against EXACT inside the benchmark-size gate.  (Their layer-level parity against the CPU restatement: tests/test_gpu_parity.py.)"""
+    import os
+    from hqtransformer_amd.config import load_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = ImageGPT2(load_config(os.path.join(root, 'configs', cfg_name)), seed=0).to('cuda').eval()
+    s2 = m.stage2.spec
+    three = s2.levels == 3
+    rows, n = 128, 2
+    if s2.cond == 2:
+        cond = torch.from_numpy(synth.text_ids(7, rows, s2.ctx_len_txt, s2.vocab_txt))
+    else:
+        cond = torch.from_numpy(synth.class_ids(7, rows, s2.n_classes))
+    seeds = [500 + (i // 64) for i in range(rows)]
+    offs = [i % 64 for i in range(rows)]
+    eng = m.stage2.engine(rows, 64)
+    eng.set_policy(POLICY_THROUGHPUT)
+    run = eng.sample3 if three else eng.sample
+    ex = run(rows, cond, n, precision=PRECISION_EXACT, row_seeds=seeds, row_offsets=offs, return_logits=True, use_graph=False)
+    fa = [run(rows, cond, n, precision=PRECISION_FAST, row_seeds=seeds, row_offsets=offs, use_graph=g) for g in (True, False)]
+    torch.cuda.synchronize()
+    nl = 3 if three else 2
+    for lv in range(nl):
+        assert torch.equal(fa[0][lv], fa[1][lv]), f'FAST not reproducible (level {lv})'
+    same = [float((fa[0][lv][:, 0] == ex[lv][:, 0]).float().mean()) for lv in range(nl)]
+    w = [1, 4, 16][:nl]
+    gate(f'timed_schedule.{cfg_name}.fast_vs_exact_first_position', sum(a * b for a, b in zip(same, w)) / sum(w), 0.98, '>=')
+    if three:
+        lf = run(rows, cond, n, precision=PRECISION_FAST, row_seeds=seeds, row_offsets=offs, force=[ex[0], ex[1], ex[2]], return_logits=True)[3]
+    else:
+        lf = run(rows, cond, n, precision=PRECISION_FAST, row_seeds=seeds, row_offsets=offs, force_top=ex[0], force_bot=ex[1], return_logits=True)[2]
+    gate(f'timed_schedule.{cfg_name}.fast_logits', float((lf - ex[nl]).abs().max()), 0.08)
+    eng.set_policy(POLICY_LATENCY)
