@@ -58,6 +58,9 @@ hipError_t launch_split_f32(const float* src, half_t* hi, half_t* lo, size_t n, 
 static inline int sp_chunk_pix(int HW) { int c = HW / 32; return c < 64 ? 64 : (c > 1024 ? 1024 : c); }
 static inline bool sp_fixed_ok(int C) { return C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0; }
 
+#ifndef SP_INFLIGHT
+#define SP_INFLIGHT 8
+#endif
 template <bool GN>
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C, int groups,
@@ -98,16 +101,17 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
         *reinterpret_cast<u32x4*>(dst + C) = vl;
     };
     int p = p0 + pl;
-    for (; p + 3 * rpi < p1; p += 4 * rpi) {
-        float4 r0[4], r1[4];
+    constexpr int UF = SP_INFLIGHT;                   // pixels in flight per thread (32 bytes each): 2 / 4 / 8 / 16 -> 5.0 / 5.0 / 5.4 / 5.0 TB/s (tools/micro/bench_pack)
+    for (; p + (UF - 1) * rpi < p1; p += UF * rpi) {
+        float4 r0[UF], r1[UF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UF; ++u) {
             const float* s = xb + (long long)(p + u * rpi) * C;
             r0[u] = *reinterpret_cast<const float4*>(s);
             r1[u] = *reinterpret_cast<const float4*>(s + 4);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) emit(r0[u], r1[u], p + u * rpi);
+        for (int u = 0; u < UF; ++u) emit(r0[u], r1[u], p + u * rpi);
     }
     for (; p < p1; p += rpi) {
         const float* s = xb + (long long)p * C;
