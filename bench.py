@@ -105,7 +105,8 @@ def cpu_baseline(cfg, s2, s1, batch):
     if threadpool_limits is not None and avail > 16:
         for n in sorted({avail, min(avail, 128), min(avail, 64), min(avail, 32), min(avail, 16), min(avail, 8)}, reverse=True):
             with threadpool_limits(limits=n):
-                orc2.sample(cond, batch, 1, noise[:1]) if n == avail else None       # first touch of the weights outside the timing
+                if not sweep:                                # first touch of the weights outside the timing
+                    orc2.sample(cond, batch, 1, noise[:1])
                 t0 = time.perf_counter()
                 orc2.sample(cond, batch, 1, noise[:1])
                 sweep[n] = round(time.perf_counter() - t0, 3)
