@@ -303,7 +303,7 @@ def main():
            [pipe.submit(B, cond_of(args.warmup + k), seed=1 + args.warmup + k, max_seq_len=n_pos, use_fp16=fast,
                         sample_offset=rank * B, use_graph=not args.no_graph, after=after, precision=dec_prec,
                         order_after_current=not os.environ.get('HQT_BENCH_NO_ORDER'), **samp_kw) for k in range(args.steps)]
-    host_submit_s = time.perf_counter() - t0      # when the last step was handed to HIP (host-bound if this is the whole region)
+    host_submit_s = time.perf_counter() - t0      # when the last step was handed to HIP (wall: includes waiting for room in the HIP queues)
     pipe.drain()
     barrier()
     elapsed_lanes = time.perf_counter() - t0
@@ -311,6 +311,16 @@ def main():
         t = torch.tensor([elapsed_lanes], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_lanes = float(t.item())
+    # what the host itself spends per step: one more pass submitted into EMPTY queues (untimed), so that nothing throttles the submitting thread
+    host_free_s = 0.0
+    if not debug_short:
+        t1 = time.perf_counter()
+        for j in range(merge):
+            pipe.submit(B, cond_of(j), seed=3000 + j, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
+                        use_graph=not args.no_graph, after=None, precision=dec_prec, **samp_kw)
+        pipe.flush()
+        host_free_s = (time.perf_counter() - t1) / merge
+        pipe.drain()
     host_ms_ranks = [round(1000 * host_submit_s / args.steps, 3)]
     if dist is not None:
         t = torch.tensor([host_submit_s], dtype=torch.float64, device=cdev)
@@ -383,6 +393,10 @@ def main():
                        'merge': (f'{merge} consecutive batch-{B} steps execute as ONE device pass of {merge * B} rows (own class id, Philox seed and global row indices per step: '
                                  f'the draws of a step do not depend on what it is merged with); the reference harness runs one batch-{B} step at a time -- that order is the `serial` record') if merge > 1 else 'none'},
             'host_ms_per_step': max(host_ms_ranks), 'host_ms_per_step_ranks': host_ms_ranks,
+            'host_ms_per_step_unthrottled': round(1000 * host_free_s, 3),
+            'host_ms_note': 'host_ms_per_step = wall time until the last step of the timed region was handed to HIP / steps -- the runtime blocks (spins) the submitting thread '
+                            'when its queues are full, so a value close to ms_per_step means the DEVICE paces the run; host_ms_per_step_unthrottled = the same submission '
+                            'into empty queues (one untimed pass, rank 0): what the host itself costs per step',
             'env_switches': {k: v for k, v in sorted(os.environ.items()) if k.startswith('HQT_')},
             'serial': {'value': round(serial_value, 2), 'ms_per_step': round(serial_ms, 3), 'steps': n_serial,
                        'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
