@@ -65,10 +65,13 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-graph', action='store_true')
-    p.add_argument('--inflight', type=int, default=3, help='batches in flight per GPU: consecutive steps are round-robined over this many '
-                   'lanes (own HIP stream, KV cache and activations; shared weights).  1 = the serial order of the reference harness')
-    p.add_argument('--merge', type=int, default=8, help='execute this many queued steps as ONE pass of merge x batch rows (every step keeps its own class id, '
-                   'Philox seed and global row indices: per step the same draws as unmerged; the weights are streamed once for all of them)')
+    p.add_argument('--inflight', type=int, default=None, help='passes in flight per GPU: consecutive passes are round-robined over this many '
+                   'lanes (own HIP stream, KV cache and activations; shared weights).  1 = one pass at a time.  Default: see --merge')
+    p.add_argument('--merge', type=int, default=None, help='execute this many queued steps as ONE device pass of merge x batch rows (every step keeps its own class id, '
+                   'Philox seed and global row indices: per step the same draws as unmerged; the weights are streamed once for all of them).  '
+                   'Default (neither --merge nor --inflight given): the K timed steps are split over 2 lanes in passes of up to 32 steps '
+                   '(merge = min(32, ceil(K / 2))): K = 20 -> 2 passes of 10, K = 96 -> 3 passes of 32; text-conditional and three-level configs: 8 x 3 lanes.  '
+                   'With only one of the two given the other defaults to --merge 8 / --inflight 3')
     p.add_argument('--overlap', action='store_true', help='EXPERIMENT: run the decode of batch k on a second stream underneath the AR '
                    'loop of batch k+1 (measured slower on MI355X: the decoder starves the latency-bound AR kernels)')
     p.add_argument('--positions', type=int, default=0, help='DEBUG ONLY (counter collection): sample this many top positions '
@@ -273,8 +276,11 @@ def main():
     # ---- the timed region: K steps, round-robined over `inflight` lanes (hqtransformer_amd/pipeline.py).  Every step is
     #      one complete batch-B pass (64-position AR loop + decode + clamp [+ gather]); lanes only change the schedule.
     from hqtransformer_amd.pipeline import InflightSampler
-    inflight = max(1, args.inflight)
-    merge = max(1, args.merge)
+    if args.merge is None and args.inflight is None and not txt_cond and not three:
+        inflight, merge = 2, min(32, max(1, (args.steps + 1) // 2))
+    else:
+        inflight = max(1, args.inflight if args.inflight is not None else 3)
+        merge = max(1, args.merge if args.merge is not None else 8)
     if args.positions:
         merge = 1                                  # debug runs (counter collection) sample a few positions of one pass
     rem = args.steps % merge                       # K need not be a multiple: the last pass of the timed region then holds `rem` steps
@@ -378,6 +384,8 @@ def main():
                                    f'batch {B}/GPU, {n_pos} top positions, ' + (f'top_k={tk}, top_p={tp}, T={T} (quality-mode sampler)' if quality else 'top_k=top_p=None, T=[1,1]'),
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
                        # the schedule, in numbers: a device pass executes `merge` steps at once, `inflight` passes are resident per GPU
+                       'schedule': ('chosen from K: the timed steps are split over 2 lanes in passes of up to 32 steps (merge = min(32, ceil(K / 2)))'
+                                    if (args.merge is None and args.inflight is None and not txt_cond and not three) else 'as given (--merge / --inflight; defaults 8 / 3)'),
                        'rows_per_pass': merge * B, 'images_in_flight_per_gpu': merge * B * inflight,
                        'step_latency_ms': round(1000 * elapsed / args.steps * merge * inflight, 1),
                        'step_latency_note': 'time from a step entering its pass to its pixels: one pass per lane, lanes share the GPU (ms_per_step x merge x lanes); '
