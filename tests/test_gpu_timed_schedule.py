@@ -1,5 +1,6 @@
-"""Parity at the schedule bench.py times: ImageNet width (D = 1536, 24 heads of 64, V = 8192), merged passes of 512 rows in the body
-and 2048 rows in depth sub-step 1, hipGraph, throughput policy -- the LDS-tiled MFMA GEMMs (csrc/tile_gemm.hip) with their
+"""Parity at the schedules bench.py times: ImageNet width (D = 1536, 24 heads of 64, V = 8192), merged passes of 2048 rows in the body
+and 8192 rows in depth sub-step 1 on 2 lanes (the default: merge 32) and of 512 / 2048 rows on 3 lanes (merge 8: the text / three-level
+lines and the driver-independent comparison), hipGraph, throughput policy -- the LDS-tiled MFMA GEMMs (csrc/tile_gemm.hip) with their
 deferred-LayerNorm prologues, fused [query; key; value] / packed / residual epilogues and split-K combine, against the CPU oracle
 (stage2/layers.py:61-195,313-315; hierarchical_ar.py:428-563,667-789).  One body + one depth layer keeps the oracle in seconds; the
 GEMM shapes, row counts and kernel variants are the benchmark's own (asserted from the engine's variant counters)."""
@@ -29,14 +30,14 @@ def variants(eng):
     return {k: v[0] for k, v in eng.timing_report().items() if k.startswith('variant:')}
 
 
-def test_merged_pass_kernels_vs_oracle_at_imagenet_width():
-    """A 512-row pass exactly as a merge-8 step of bench.py issues it (same engine call, same policy, graph and eager): EXACT codes
+@pytest.mark.parametrize('B,n', [(512, 3), (2048, 2)])
+def test_merged_pass_kernels_vs_oracle_at_imagenet_width(B, n):
+    """A 512-row pass exactly as a merge-8 step of bench.py issues it, and a 2048-row pass as a merge-32 step (the default schedule) does (same engine call, same policy, graph and eager): EXACT codes
     bit-identical and logits <= 2e-4 against the oracle, FAST teacher-forced logits inside the bf16 gate, and the launches counted
     per kernel variant: every body / depth GEMM of the FAST pass must have gone through the tile kernels."""
     spec = Stage2Spec(embed_dim=1536, n_layers=1, n_heads=24, n_layers_depth=1, vocab_top=8192, vocab_bot=8192, vocab_txt=64,
                       ctx_len_img=64, ctx_len_txt=16, n_classes=1000, cond=1, embedding=0)
     weights = synth.stage2_weights(spec, 31, 'fixture')
-    B, n = 512, 3
     noise = synth.exp_noise(32, n, B, spec.vocab_top)
     cond = (np.arange(B) * 7) % spec.n_classes
     want = O.OracleStage2(spec, weights).sample(cond, B, n, noise, return_logits=True)
@@ -55,18 +56,21 @@ def test_merged_pass_kernels_vs_oracle_at_imagenet_width():
         dt, db, lf = eng.sample(B, tc, n, precision=PRECISION_FAST, noise=tn, force_top=ft, force_bot=fb, return_logits=True, use_graph=graph)
         # logits of standard deviation 3.1 here (fixture-style weights; 0.8 with the benchmark's): measured 0.077 max / 0.0105 mean over
         # 63 M logits with the tile kernels, 0.081 / 0.0105 with the streaming kernels they replace (tools/fast_tile_error.py)
-        gate(f'timed_schedule.fast_logits(rows=512,graph={graph})', np.abs(np_(lf) - want[2]).max(), 0.12)
+        gate(f'timed_schedule.fast_logits(rows={B},graph={graph})', np.abs(np_(lf) - want[2]).max(), 0.12)
         agree = ((np_(dt) == want[0]).mean() + (np_(db) == want[1]).mean()) / 2
-        gate(f'timed_schedule.fast_code_agreement(rows=512,graph={graph})', agree, 0.99, '>=')
+        gate(f'timed_schedule.fast_code_agreement(rows={B},graph={graph})', agree, 0.99, '>=')
         if not graph:
             v = variants(eng)
             eng.timing(False)
             tile = {k: c for k, c in v.items() if k.startswith('variant:tile_gemm')}
             stream = {k: c for k, c in v.items() if k.startswith('variant:stream_gemm')}
             # per position: body qkv/proj/fc1/fc2 + 2 x depth qkv/proj/fc1/fc2 + 2 heads = 14 GEMMs; only the 512-row proj (K = D: one short
-            # K loop over 48 tiles) stays on the streaming kernel (body + depth sub-step 0)
-            assert set(stream) <= {'variant:stream_gemm:gemm_proj'} and sum(stream.values()) == 2 * n, f'streaming GEMMs in a 512-row pass: {stream}'
-            assert sum(tile.values()) == 12 * n, v
+            # K loop over 48 tiles) stays on the streaming kernel (body + depth sub-step 0); from 1024 rows nothing does
+            if B == 512:
+                assert set(stream) <= {'variant:stream_gemm:gemm_proj'} and sum(stream.values()) == 2 * n, f'streaming GEMMs in a 512-row pass: {stream}'
+                assert sum(tile.values()) == 12 * n, v
+            else:
+                assert not stream and sum(tile.values()) == 14 * n, v
             assert any('_dln:gemm_qkv' in k for k in tile) and any('_dln:gemm_fc1' in k for k in tile) and any('_dln:gemm_head' in k for k in tile), v
             assert any(k.endswith(':gemm_proj') for k in tile) and any(k.endswith(':gemm_fc2') for k in tile), v
     eng.set_policy(POLICY_LATENCY)
@@ -121,29 +125,31 @@ def _one_layer_model(seed):
     return ImageGPT2(cfg, seed=seed).to('cuda').eval()
 
 
-def test_inflight_sampler_merge8_lanes3_vs_oracle():
-    """The harness schedule itself: 24 steps of batch 64 through InflightSampler(merge=8, lanes=3) -- three passes of 512 rows, one
-    per lane, each row drawing with the Philox key of ITS step.  In EXACT arithmetic two of the eight steps of a pass are replayed
+@pytest.mark.parametrize('merge_k,lanes,check', [(8, 3, (3, 20)), (32, 2, (9, 62))])
+def test_inflight_sampler_at_the_timed_schedules_vs_oracle(merge_k, lanes, check):
+    """The harness schedule itself: steps of batch 64 through InflightSampler(merge=8, lanes=3) -- three passes of 512 rows, one
+    per lane -- and through InflightSampler(merge=32, lanes=2), bench.py's default -- two passes of 2048 rows --, each row drawing
+    with the Philox key of ITS step.  In EXACT arithmetic two of the eight steps of a pass are replayed
     by the oracle (Philox noise restated on the host, tests/helpers.py) and must match bit for bit; the FAST passes (what bench.py
     times) must draw the same codes as the EXACT ones under the same keys almost everywhere."""
     m = _one_layer_model(7)
     s2 = m.stage2.spec
     assert (s2.embed_dim, s2.n_layers, s2.n_layers_depth, s2.vocab_top) == (1536, 1, 1, 8192)
-    B, n, steps = 64, 64, 24
+    B, n, steps = 64, 64, merge_k * lanes
     cls = [int(c) for c in (np.arange(steps) * 37 + 5) % s2.n_classes]
     seeds = [1000 + 17 * k for k in range(steps)]
     offs = [64 * k for k in range(steps)]
     res = {}
     for fast in (False, True):
-        pipe = InflightSampler(m, lanes=3, merge=8)
+        pipe = InflightSampler(m, lanes=lanes, merge=merge_k)
         pend = [pipe.submit(B, cls[k], seed=seeds[k], max_seq_len=n, use_fp16=fast, precision='exact', sample_offset=offs[k]) for k in range(steps)]
         pipe.drain()
         torch.cuda.synchronize()
         res[fast] = [(np_(p.get()[0]), np_(p.get()[1])) for p in pend]
-        pipe.release(8 * B, n)
+        pipe.release(merge_k * B, n)
     w2 = {k: v.numpy() for k, v in m.stage2.state_dict().items()}
     orc = O.OracleStage2(s2, w2)
-    for k in (3, 20):                                        # a step inside the first pass (lane 0) and one inside the third (lane 2)
+    for k in check:                                          # a step inside the first pass (lane 0) and one inside the last (last lane)
         noise = philox_exp_noise([seeds[k]] * B, [offs[k] + i for i in range(B)], n, s2.vocab_top)
         want = orc.sample(np.full(B, cls[k]), B, n, noise)
         assert (res[False][k][0] == want[0]).all() and (res[False][k][1] == want[1]).all(), f'step {k}: merged EXACT codes differ from the oracle'
@@ -151,14 +157,15 @@ def test_inflight_sampler_merge8_lanes3_vs_oracle():
     # gate is taken at position 0 (the input is the class embedding in both runs: 24 x 64 x 5 independent draws); the whole
     # sequences only have to be far from unrelated (unrelated codes agree with probability 1 / 8192)
     first = np.mean([((a[0][:, 0] == b[0][:, 0]).mean() + 4 * (a[1][:, 0] == b[1][:, 0]).mean()) / 5 for a, b in zip(res[False], res[True])])
-    gate('timed_schedule.inflight_merge8_lanes3.fast_vs_exact_first_position', first, 0.985, '>=')
+    gate(f'timed_schedule.inflight_merge{merge_k}_lanes{lanes}.fast_vs_exact_first_position', first, 0.985, '>=')
     same = np.mean([((a[0] == b[0]).mean() + (a[1] == b[1]).mean()) / 2 for a, b in zip(res[False], res[True])])
-    gate('timed_schedule.inflight_merge8_lanes3.fast_vs_exact_all_positions', same, 0.25, '>=')
+    gate(f'timed_schedule.inflight_merge{merge_k}_lanes{lanes}.fast_vs_exact_all_positions', same, 0.25, '>=')
 
 
-def test_full_benchmark_model_merged_pass_properties():
-    """The whole 12 + 4-layer ImageNet model (530.8 M parameters, random-init 'bench' weights) in ONE 512-row pass, exactly what a
-    merge-8 pass of bench.py runs -- beyond what the CPU restatement finishes in a test, so the size-independent properties:
+@pytest.mark.parametrize('steps', [8, 32])
+def test_full_benchmark_model_merged_pass_properties(steps):
+    """The whole 12 + 4-layer ImageNet model (530.8 M parameters, random-init 'bench' weights) in ONE 512-row pass (merge 8) and ONE
+    2048-row pass (merge 32, the default), exactly what a pass of bench.py runs -- beyond what the CPU restatement finishes in a test, so the size-independent properties:
     (1) the FAST pass is bit-reproducible run to run and graph vs eager; (2) a row's draws do not depend on the pass it sits in: rows of
     the 512-row EXACT pass equal the same steps run as 64-row calls (per-row Philox keys); (3) FAST and EXACT draw the same codes at
     position 0 (inputs identical: the class embedding) for >= 98.5 % of the 512 x 5 draws, and their teacher-forced logits agree
@@ -169,7 +176,7 @@ def test_full_benchmark_model_merged_pass_properties():
     m = ImageGPT2(load_config(os.path.join(root, 'configs', 'imagenet-12l.yaml')), seed=0).to('cuda').eval()
     s2 = m.stage2.spec
     assert (s2.n_layers, s2.n_layers_depth, s2.embed_dim) == (12, 4, 1536)
-    steps, B, n = 8, 64, 2
+    B, n = 64, 2
     rows = steps * B
     cls = torch.tensor([int((37 * k + 5) % s2.n_classes) for k in range(steps) for _ in range(B)])
     seeds = [1000 + 17 * k for k in range(steps) for _ in range(B)]
@@ -180,16 +187,16 @@ def test_full_benchmark_model_merged_pass_properties():
     runs = [eng.sample(rows, cls, n, precision=PRECISION_FAST, row_seeds=seeds, row_offsets=offs, use_graph=g) for g in (True, True, False)]
     torch.cuda.synchronize()
     for r in runs[1:]:
-        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]), 'FAST 512-row pass is not reproducible (graph / eager / run to run)'
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]), f'FAST {rows}-row pass is not reproducible (graph / eager / run to run)'
     # (2) step 5 alone, as the unmerged 64-row call of the reference harness
     k = 5
     alone = eng.sample(B, cls[k * B:(k + 1) * B], n, precision=PRECISION_EXACT, seed=seeds[k * B], sample_offset=0, use_graph=False)
     assert torch.equal(alone[0], ex[0][k * B:(k + 1) * B]) and torch.equal(alone[1], ex[1][k * B:(k + 1) * B]), 'a step draws differently inside a merged pass'
     # (3) FAST vs EXACT
     first = ((runs[0][0][:, 0] == ex[0][:, 0]).float().mean() + 4 * (runs[0][1][:, 0] == ex[1][:, 0]).float().mean()) / 5
-    gate('timed_schedule.full_model_rows512.fast_vs_exact_first_position', float(first), 0.985, '>=')
+    gate(f'timed_schedule.full_model_rows{rows}.fast_vs_exact_first_position', float(first), 0.985, '>=')
     _, _, lf = eng.sample(rows, cls, n, precision=PRECISION_FAST, row_seeds=seeds, row_offsets=offs, force_top=ex[0], force_bot=ex[1], return_logits=True)
-    gate('timed_schedule.full_model_rows512.fast_logits', float((lf - ex[2]).abs().max()), 0.06)
+    gate(f'timed_schedule.full_model_rows{rows}.fast_logits', float((lf - ex[2]).abs().max()), 0.06)
     eng.set_policy(POLICY_LATENCY)
 
 
