@@ -177,6 +177,8 @@ struct GemmArgs {
     const void* Bw_frag16;   // optional: the same 3x3 filters packed in MFMA fragment order for v_mfma_f32_16x16x32_f16 (16-channel blocks; conv3x3_split_ring16_kernel)
     const void* Bw_up16;     // optional, upsampling convs: the four 2x2 phase filters (pre-summed taps), packed like Bw_frag16 (conv2x2_split_up16_kernel)
     double* gn_part_out_d;
+    int a_f32;               // split_gemm_kernel only: A is the fp32 tensor itself ([row][K], lda floats); the hi / lo split happens while the tile is staged
+    int* range_flag;         // a_f32: where an element outside the fp16 range is reported (hqt_range_check)
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

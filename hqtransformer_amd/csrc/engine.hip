@@ -1485,7 +1485,17 @@ static int s1_norm(S1Ctx& c, const void* src, int C, int hw, float* stats, const
 // a conv without GroupNorm in front (conv_in, upsample conv, nin_shortcut, proj_out, the 1x1 convs around the quantiser): SPLIT
 // needs the operand planes, the other modes read the tensor as it is
 static int s1_plain(S1Ctx& c, GemmArgs* g, const Lin& l) {
-    if (c.md.split && split_shape_ok(c.h, *g, l)) CHK(s1_split_pack(c, g, nullptr, nullptr, nullptr, 0));
+    if (!c.md.split) return HQT_OK;
+    if (g->conv_taps == 1) {                 // 1x1: the GEMM kernel splits the fp32 tensor while it stages the tile -- no operand pass
+        GemmArgs t = *g;
+        t.a_f32 = 1;
+        if (split_shape_ok(c.h, t, l)) {
+            g->a_f32 = 1; g->range_flag = c.h->range_flag;
+            g->Bw_lo = g->A;                 // non-NULL marks a SPLIT launch; run_linear substitutes the filter planes
+            return HQT_OK;
+        }
+    }
+    if (split_shape_ok(c.h, *g, l)) CHK(s1_split_pack(c, g, nullptr, nullptr, nullptr, 0));
     return HQT_OK;
 }
 

@@ -492,10 +492,15 @@ hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // 1x1 convolutions / plain GEMMs: C[m][n] = alpha sum_k A[m][k] W[n][k] (+bias) (+resid), 128 x 128 x 32 tiles, both
-// operands (two planes each) staged through registers into two LDS stages (64 KiB, two workgroups per CU: with K = 256 .. 512
-// a workgroup is mostly prologue and epilogue, which the second one covers), 4 waves x (64 x 64).
-// A rows are [m][hi K | lo K] (lda elements per row, lo at +a_lo_off); same source-side bank swizzle as conv_glds_kernel.
+// operands (two planes each) staged through registers into two LDS stages (64 KiB, two workgroups per CU), 4 waves x (64 x 64).
+// A rows are [m][hi K | lo K] (lda elements per row, lo at +a_lo_off) or, AF32, the fp32 tensor itself ([m][K], lda floats):
+// the hi / lo split (range-checked like the operand pass) then happens between the load and the LDS write, and the separate
+// 8-byte-per-element operand pass in front of a nin_shortcut / proj_out disappears.  Same source-side bank swizzle as conv_glds_kernel.
+// The loads run TWO k-tiles ahead of the MFMAs (two register slots; round 2 had one: a k-tile is 768 matrix cycles, a third of
+// a memory round trip, and the 16 k-tiles of a 512-channel 1x1 conv each waited for theirs: 23 % of the matrix peak).  Loads are
+// unconditional (clamped k-tile) so that the loop body is one basic block and the compiler's counted waits stay exact.
 // ---------------------------------------------------------------------------------------------
+template <bool AF32>
 __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo_off) {
     constexpr int BM = 128, BN = 128, BKG = 32, ROWB = 64, OPB = 128 * ROWB;        // 32-wide k-tiles: 64 KiB of LDS, two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];                   // [2 stages][A hi, A lo, B hi, B lo][128 rows of 64 B]
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
     xcd_tile(tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const half_t* Abase = reinterpret_cast<const half_t*>(g.A) + (long long)bz * g.a_batch_stride;
+    const float* Abase32 = reinterpret_cast<const float*>(g.A) + (long long)bz * g.a_batch_stride;
     const half_t* Bhi = reinterpret_cast<const half_t*>(g.Bw) + (long long)bz * g.b_batch_stride;
     const half_t* Blo = reinterpret_cast<const half_t*>(g.Bw_lo) + (long long)bz * g.b_batch_stride;
     const half_t* zero = reinterpret_cast<const half_t*>(g.zero_page);
@@ -520,26 +526,47 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         aoff[i] = (m0 + row < g.M) ? (long long)(m0 + row) * g.lda + ch : -1;
         boff[i] = (n0 + row < g.N) ? (long long)(n0 + row) * g.ldb + ch : -1;
     }
-    // Staging goes through registers (global_load_dwordx4, then ds_write_b128 after the k-tile's MFMAs): the 16 LDS-DMA pieces a wave
-    // issued per k-tile cost it 150-300 cycles EACH next to MFMAs (2x the k-tile's matrix time; split_stream_conv.hip), while a whole
-    // k-tile of ordinary loads stays in flight for free in the 512 registers a one-wave-per-SIMD kernel has.
-    u32x4 stg[2][4];
-    auto fetch = [&](int kt) {
-        const int k0 = kt * BKG;
+    const int KT = g.K / BKG;
+    u32x4 stg[2][2][4];                                 // [slot][piece][A hi | A lo | W hi | W lo]; AF32: [first | second four floats | W hi | W lo]
+    auto fetch = [&](int kt, u32x4 (&sl)[2][4]) {
+        const int k0 = min(kt, KT - 1) * BKG;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const half_t* s[4] = {aoff[i] >= 0 ? Abase + aoff[i] + k0 : zero, aoff[i] >= 0 ? Abase + aoff[i] + a_lo_off + k0 : zero,
-                                  boff[i] >= 0 ? Bhi + boff[i] + k0 : zero, boff[i] >= 0 ? Blo + boff[i] + k0 : zero};
-#pragma unroll
-            for (int op = 0; op < 4; ++op) stg[i][op] = *reinterpret_cast<const u32x4*>(s[op]);
+            if (AF32) {
+                const float* sa = aoff[i] >= 0 ? Abase32 + aoff[i] + k0 : reinterpret_cast<const float*>(zero);
+                sl[i][0] = *reinterpret_cast<const u32x4*>(sa);
+                sl[i][1] = *reinterpret_cast<const u32x4*>(sa + 4);
+            } else {
+                sl[i][0] = *reinterpret_cast<const u32x4*>(aoff[i] >= 0 ? Abase + aoff[i] + k0 : zero);
+                sl[i][1] = *reinterpret_cast<const u32x4*>(aoff[i] >= 0 ? Abase + aoff[i] + a_lo_off + k0 : zero);
+            }
+            sl[i][2] = *reinterpret_cast<const u32x4*>(boff[i] >= 0 ? Bhi + boff[i] + k0 : zero);
+            sl[i][3] = *reinterpret_cast<const u32x4*>(boff[i] >= 0 ? Blo + boff[i] + k0 : zero);
         }
     };
-    auto stash = [&](int buf) {
+    bool bad = false;
+    auto stash = [&](int buf, const u32x4 (&sl)[2][4]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            char* at = lds_raw + (size_t)buf * 4 * OPB + (wave * 2 + i) * 16 * ROWB + lane * 16;
+            if (AF32) {
+                half_t hi[8], lo[8];
 #pragma unroll
-            for (int op = 0; op < 4; ++op)
-                *reinterpret_cast<u32x4*>(LDS(buf, op) + (wave * 2 + i) * 16 * ROWB + lane * 16) = stg[i][op];
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned bits = sl[i][e >> 2][e & 3];      // (hipcc 7.2: __builtin_bit_cast straight on a vector ELEMENT reads element 0)
+                    split2_checked(__builtin_bit_cast(float, bits), hi[e], lo[e], bad);
+                }
+                const u32x4 vh = {pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])};
+                const u32x4 vl = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])};
+                *reinterpret_cast<u32x4*>(at) = vh;
+                *reinterpret_cast<u32x4*>(at + OPB) = vl;
+            } else {
+                *reinterpret_cast<u32x4*>(at) = sl[i][0];
+                *reinterpret_cast<u32x4*>(at + OPB) = sl[i][1];
+            }
+            *reinterpret_cast<u32x4*>(at + 2 * OPB) = sl[i][2];
+            *reinterpret_cast<u32x4*>(at + 3 * OPB) = sl[i][3];
+        }
     };
     f32x16 accm[2][2], accx[2][2];
 #pragma unroll
@@ -548,7 +575,6 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.0f; accx[i][j][r] = 0.0f; }
-    const int KT = g.K / BKG;
     const int fr = lane & 31, fh = lane >> 5;
     auto compute = [&](int buf) {
         const char *Ah = LDS(buf, 0), *Al = LDS(buf, 1), *Wh = LDS(buf, 2), *Wl = LDS(buf, 3);
@@ -580,16 +606,25 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                 }
         }
     };
-    fetch(0);
-    stash(0);
+    fetch(0, stg[0]);
+    fetch(1, stg[1]);
+    stash(0, stg[0]);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) fetch(kt + 1);                // in flight under this k-tile's MFMAs
-        compute(buf);
-        if (kt + 1 < KT) stash(buf ^ 1);               // the other stage: its readers passed the barrier below one k-tile ago
+    for (int kt = 0; kt < KT; kt += 2) {                // KT is even (K % 64 == 0)
+        fetch(kt + 2, stg[0]);                          // slot 0 went to LDS one k-tile ago; in flight under TWO k-tiles of MFMAs
+        __builtin_amdgcn_sched_barrier(0);              // (without the fences hipcc sinks the loads below the LDS writes of the other slot)
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stash(1, stg[1]);                               // k-tile kt + 1: its readers passed the barrier below one k-tile ago
+        __syncthreads();
+        fetch(kt + 3, stg[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        stash(0, stg[0]);                               // k-tile kt + 2 (past the end: a clamped duplicate nobody reads)
         __syncthreads();
     }
+    if (AF32 && bad && g.range_flag) atomicOr(g.range_flag, 1);
     // epilogue: a lane owns 4 consecutive columns of one row per register quad
     float* Cb = reinterpret_cast<float*>(g.C) + (long long)bz * g.c_batch_stride;
     const float* Rb = g.resid ? reinterpret_cast<const float*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
@@ -646,6 +681,7 @@ bool split_gemm_ok(const GemmArgs& g) {
     if (!g.zero_page || !g.Bw_lo || g.gn_stats || g.a_packed_mb || g.a_rows_per_group) return false;
     if (g.conv_taps > 1 || g.conv_stride2 || g.upsample) return false;
     if (g.K % 64 != 0 || g.ldb % 8 != 0) return false;
+    if (g.a_f32 && (g.conv_taps ? g.Cin : g.lda) % 4 != 0) return false;
     if (g.store != STORE_ROWS && g.store != STORE_NCHW) return false;
     if (g.store == STORE_ROWS && g.rows_per_group != 0) return false;
     if (g.store == STORE_NCHW && (g.resid || g.act != ACT_NONE)) return false;
@@ -653,10 +689,11 @@ bool split_gemm_ok(const GemmArgs& g) {
 }
 hipError_t launch_split_gemm(const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
-    if (g.conv_taps == 1) { g.lda = 2 * g.Cin; g.conv_taps = 0; }        // a 1x1 conv over [pixel][hi C | lo C] is a plain GEMM with lda = 2 C
+    if (g.conv_taps == 1) { g.lda = g.a_f32 ? g.Cin : 2 * g.Cin; g.conv_taps = 0; }   // a 1x1 conv over [pixel][hi C | lo C] (or [pixel][C] fp32) is a plain GEMM
     const int a_lo_off = g.lda / 2;
     const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
-    split_gemm_kernel<<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
+    if (g.a_f32) split_gemm_kernel<true><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
+    else split_gemm_kernel<false><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
     return hipGetLastError();
 }
 
@@ -667,5 +704,7 @@ hipError_t split_kernels_configure() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<true, 32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(32));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
 }

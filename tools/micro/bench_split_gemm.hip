@@ -1,0 +1,55 @@
+// Micro-benchmark: the SPLIT 1x1-conv / plain GEMM kernel (fp16 hi/lo operands, 3 MFMAs per term) on the HQ-VAE decoder's shapes at
+// batch 64: the attention blocks' q / k / v / proj (16384 x 512 x 512) and the two nin_shortcuts (262144 x 256 x 512, 1048576 x 128 x 256).
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/micro/bench_split_gemm.hip -o tools/micro/bench_split_gemm
+#include "../../hqtransformer_amd/csrc/split_conv.hip"
+#include "../../hqtransformer_amd/csrc/split_stream_conv.hip"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Shape { const char* name; int M, N, K; };
+
+static float timed(const GemmArgs& g, hipStream_t st, int reps) {
+    CK(launch_split_gemm(g, st));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    for (int r = 0; r < reps; ++r) CK(launch_split_gemm(g, st));
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return 1000.f * ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 64;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    CK(split_kernels_configure());
+    const Shape shapes[] = {
+        {"attn q/k/v/proj 16^2 512->512", B * 256, 512, 512}, {"attn qkv fused 16^2 512->1536", B * 256, 1536, 512},
+        {"nin_shortcut 64^2 512->256", B * 4096, 256, 512}, {"nin_shortcut 128^2 256->128", B * 16384, 128, 256},
+    };
+    const size_t amax = (size_t)B * 16384 * 256 * 2, cmax = (size_t)B * 16384 * 128, wmax = (size_t)1536 * 512;
+    half_t *A, *Wh, *Wl; float *C, *bias; void* zero;
+    CK(hipMalloc(&A, amax * 2)); CK(hipMalloc(&C, std::max(cmax, (size_t)B * 256 * 1536) * 4)); CK(hipMalloc(&Wh, wmax * 2)); CK(hipMalloc(&Wl, wmax * 2));
+    CK(hipMalloc(&bias, 1536 * 4)); CK(hipMalloc(&zero, 256));
+    {
+        std::vector<unsigned short> hbuf(1 << 22);
+        unsigned x = 12345u;
+        for (auto& v : hbuf) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3800u + ((x >> 16) & 0x07ffu) + ((x >> 8) & 0x8000u)); }
+        for (size_t off = 0; off < amax; off += hbuf.size()) CK(hipMemcpy(A + off, hbuf.data(), std::min(hbuf.size(), amax - off) * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(Wh, hbuf.data(), wmax * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(Wl, hbuf.data() + 77, wmax * 2, hipMemcpyHostToDevice));
+    }
+    CK(hipMemset(bias, 0, 1536 * 4)); CK(hipMemset(zero, 0, 256));
+    printf("%-34s %8s | %8s %8s %8s | %8s %8s\n", "shape (batch 64)", "GF x3", "us", "TF iss.", "of peak", "fp32-A us", "of peak");
+    for (const Shape& s : shapes) {
+        GemmArgs g{};
+        g.A = A; g.lda = 2 * s.K; g.Bw = Wh; g.Bw_lo = Wl; g.ldb = s.K; g.C = C; g.ldc = s.N; g.M = s.M; g.N = s.N; g.K = s.K; g.batch = 1;
+        g.bias = bias; g.alpha = 1.f; g.store = STORE_ROWS; g.zero_page = zero;
+        const double fl = 3 * 2.0 * s.M * s.N * s.K;
+        const float t = timed(g, st, 5);
+        GemmArgs gf = g; gf.a_f32 = 1; gf.lda = s.K;                       // A = the fp32 tensor, split while it is staged
+        const float tf = timed(gf, st, 5);
+        printf("%-34s %8.1f | %8.1f %8.1f %8.3f | %8.1f %8.3f\n", s.name, fl * 1e-9, t, fl / t * 1e-6, fl / t * 1e-6 / 2500.0, tf, fl / tf * 1e-6 / 2500.0);
+    }
+    return 0;
+}
