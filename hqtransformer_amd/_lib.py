@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'tile_gemm.hip', 'mfma_gemm.hip', 'split_conv.hip', 'split_stream_conv.hip']
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT = 0, 1, 2
 PRECISIONS = {'exact': PRECISION_EXACT, 'fast': PRECISION_FAST, 'split': PRECISION_SPLIT}
@@ -48,6 +48,7 @@ class hqt_config(C.Structure):
         ('s1_use_init_downsample', C.c_int32), ('s1_use_mid_block', C.c_int32), ('s1_use_attn', C.c_int32),
         ('max_batch', C.c_int32), ('max_steps', C.c_int32),
         ('code_levels', C.c_int32),
+        ('depth_decoding', C.c_int32),
     ]
 
 

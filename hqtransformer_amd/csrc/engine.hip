@@ -343,6 +343,8 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         const int hs = c.embed_dim / c.n_heads;
         if (hs % 8 || hs > 256 || (hs & (hs - 1))) return fail(HQT_ERR_INVALID, "head_dim %d unsupported (power of two in [8, 256])", hs);
         if (c.vocab_top != c.vocab_bot) return fail(HQT_ERR_INVALID, "vocab_top != vocab_bot");
+        if (c.depth_decoding < 0 || c.depth_decoding > HQT_DEPTH_PARALLEL_REDUCE || (c.depth_decoding && c.code_levels != 3))
+            return fail(HQT_ERR_INVALID, "depth_decoding %d: 0 'parallel-add', 1 'parallel', 2 'parallel-reduce' (three code levels only)", c.depth_decoding);
         if (c.vocab_top > HQT_MAX_V || c.vocab_top % 4) return fail(HQT_ERR_INVALID, "vocab size %d unsupported", c.vocab_top);
         if (c.cond_type == HQT_COND_CLASS && c.n_classes < 1) return fail(HQT_ERR_INVALID, "n_classes");
         if (c.max_steps < 1 || c.max_steps > c.ctx_len_img) return fail(HQT_ERR_INVALID, "max_steps must be in [1, ctx_len_img]");
@@ -748,11 +750,12 @@ static int finalize_impl(hqt_handle* h) {
         CHK(get_w(h, key2(h, "tok_emb_bot.weight"), {c.vocab_bot, c.embedding_type == HQT_EMB_REDUCE ? D / 4 : D}, &t));
         if (c.embedding_type == HQT_EMB_TRANSFORMER1) CHK(get_w(h, "stage2.pos_emb_emb.weight", {l3 ? 21 : 5, D}, &t));
         CHK(get_w(h, "stage2.pos_emb_top.weight", {c.ctx_len_img, D}, &t));
-        CHK(get_w(h, key2(h, "tok_emb_top_depth.weight"), {c.vocab_top, D}, &t));
+        const int dmul = (l3 && c.depth_decoding == HQT_DEPTH_PARALLEL_REDUCE) ? 4 : 1;      // 'reduce': [V, 4 D] depth tables (hqtransformer.py:108-116)
+        CHK(get_w(h, key2(h, "tok_emb_top_depth.weight"), {c.vocab_top, dmul * D}, &t));
         CHK(get_w(h, key2(h, "pos_emb_depth.weight"), {l3 ? 4 : 5, D}, &t));
         if (l3) {
             CHK(get_w(h, "stage2.tok_emb_levels.2.weight", {c.vocab_top, D}, &t));
-            CHK(get_w(h, "stage2.tok_emb_depth_levels.1.weight", {c.vocab_top, D}, &t));
+            CHK(get_w(h, "stage2.tok_emb_depth_levels.1.weight", {c.vocab_top, dmul * D}, &t));
             CHK(get_w(h, "stage2.pos_emb_depths.1.weight", {16, D}, &t));
             CHK(get_w(h, "stage2.ln_levels.2.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_levels.2.bias", {D}, &t));
         }
@@ -1172,6 +1175,7 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
     const Lin* heads[3] = {&h->head_top, &h->head_bot, &h->head_l2};
     const char* ln_names[3][2] = {{"ln_top.weight", "ln_top.bias"}, {"ln_bot.weight", "ln_bot.bias"}, {"ln_levels.2.weight", "ln_levels.2.bias"}};
     const int Tqs[3] = {1, 4, 16}, tbase[3] = {0, 1, 5}, draw0[3] = {0, 1, 5};
+    const int dmul = cf.depth_decoding == HQT_DEPTH_PARALLEL_REDUCE ? 4 : 1;
     int64_t* outs[3] = {c.out_top, c.out_bot, c.out_l2};
     const size_t dkv_layer = (size_t)cf.max_batch * 21 * D * esz;
     for (int lv = 0; lv < 3; ++lv) {
@@ -1187,12 +1191,13 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
         } else if (lv == 1) {     // emb(top code) + positions 0..3
             Timed t(h, "embed", c.st);
             HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
-                                      h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st, V));
-        } else {                  // parent's level-1 embedding + position i + emb(top code), 16 tokens
+                                      h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st, V, dmul * D));
+        } else {                  // parent's level-1 embedding + position i (+ emb(top code): 'add'), 16 tokens
             Timed t(h, "embed", c.st);
-            HIPCHK(launch_depth_embed_l2(c.feed_top, c.feed_bot, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"),
+            HIPCHK(launch_depth_embed_l2(c.feed_top, c.feed_bot, c.o.n_steps, h->state,
+                                         cf.depth_decoding == HQT_DEPTH_PARALLEL_ADD ? W(h, "tok_emb_top_depth.weight") : nullptr,
                                          h->w["stage2.tok_emb_depth_levels.1.weight"].d, h->w["stage2.pos_emb_depths.1.weight"].d,
-                                         h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st, V));
+                                         h->xd, B, D, dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st, V, dmul * D));
         }
         h->npartsd = 1;
         for (int l = 0; l < cf.n_layers_depth; ++l) {

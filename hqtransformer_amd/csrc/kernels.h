@@ -39,7 +39,7 @@ hipError_t launch_embed_text(const int64_t* cond, const float* tok, const float*
 
 // depth sub-step 1 input: x[b*4+s, :] = tok_top_depth[top[b, step]] + pos_depth[s]
 hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
-                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st, int V = 0);
+                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st, int V = 0, int tok_ld = 0);
 
 struct LNArgs {
     float* x;                    // [rows_in, D]; rewritten in place when split-K slabs are folded in
@@ -109,10 +109,11 @@ struct SamplerArgs {
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
 // depth sub-step 2 of the three-level model (hqtransformer.py:537-551): token i (raster (H1 H2 W1 W2)) =
-// tok1[codes1[b, step, parent(i)]] + pos[i] + tok0[codes0[b, step]], 16 rows per sample
+// tok1[codes1[b, step, parent(i)]] + pos[i] (+ tok0[codes0[b, step]]: 'add', tok0 non-NULL), 16 rows per sample; tok1_ld = 4 D:
+// the 'reduce' table, child (H2 W2) takes its D-slice of the parent's row
 hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state, const float* tok0,
                                  const float* tok1, const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts,
-                                 hipStream_t st, int V = 0);
+                                 hipStream_t st, int V = 0, int tok1_ld = 0);
 // raises the dynamic-LDS limit of the sampler for (V, top-p) outside any stream capture
 hipError_t sampler_configure(int V, bool use_top_p);
 

@@ -130,37 +130,47 @@ hipError_t launch_embed_text(const int64_t* cond, const float* tok, const float*
     return hipGetLastError();
 }
 
+// `tok_ld` = row length of the table: D, or 4 D for the 'reduce' head, where slot s of a code takes the D-slice s of its row
+// (hqtransformer.py:108-116,532-533)
 __global__ __launch_bounds__(256) void depth_embed_kernel(const int64_t* codes_top, int n_steps, const StepState* state,
                                                           const float* tok, const float* pos, float* x, int D, bf16_t* xpk,
-                                                          int pk_mb, float* parts, int V) {
+                                                          int pk_mb, float* parts, int V, int tok_ld) {
     __shared__ float red[4];
     const int row = blockIdx.x, b = row >> 2, s = row & 3;
     const long long code = clamp_idx(codes_top[(long long)b * n_steps + state->step], V);
-    for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long long)row * D + d] = tok[code * D + d] + pos[(long long)s * D + d];
+    const float* e = tok + code * tok_ld + (tok_ld > D ? s * D : 0);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long long)row * D + d] = e[d] + pos[(long long)s * D + d];
     if (xpk) { __syncthreads(); emit_packed_row(x + (long long)row * D, row, D, xpk, pk_mb, parts, red); }
 }
 hipError_t launch_depth_embed(const int64_t* codes_top, int n_steps, const StepState* state, const float* tok,
-                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st, int V) {
-    depth_embed_kernel<<<B * 4, 256, 0, st>>>(codes_top, n_steps, state, tok, pos, x, D, xpk, pk_mb, parts, V);
+                              const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st, int V, int tok_ld) {
+    depth_embed_kernel<<<B * 4, 256, 0, st>>>(codes_top, n_steps, state, tok, pos, x, D, xpk, pk_mb, parts, V, tok_ld > 0 ? tok_ld : D);
     return hipGetLastError();
 }
 
+// Level-2 tokens of the three-level head, (H1 H2 W1 W2) raster: token i carries its parent's level-1 embedding (the D-slice of child
+// (H2 W2) when the table is [V, 4 D]: 'reduce'), position i and -- `tok0` non-NULL: 'add' -- the top code's embedding (hqtransformer.py:537-551)
 __global__ __launch_bounds__(256) void depth_embed_l2_kernel(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state,
                                                              const float* tok0, const float* tok1, const float* pos, float* x, int D,
-                                                             bf16_t* xpk, int pk_mb, float* parts, int V) {
+                                                             bf16_t* xpk, int pk_mb, float* parts, int V, int tok1_ld) {
     __shared__ float red[4];
     const int row = blockIdx.x, b = row >> 4, i = row & 15;
     const int parent = (i >> 3) * 2 + ((i & 3) >> 1);                  // (H1 H2 W1 W2) raster -> (H1 W1)
+    const int child = ((i >> 2) & 1) * 2 + (i & 1);                    //                      -> (H2 W2)
     const long long c0 = clamp_idx(codes0[(long long)b * n_steps + state->step], V);
     const long long c1 = clamp_idx(codes1[((long long)b * n_steps + state->step) * 4 + parent], V);
-    for (int d = threadIdx.x; d < D; d += blockDim.x)
-        x[(long long)row * D + d] = (tok1[c1 * D + d] + pos[(long long)i * D + d]) + tok0[c0 * D + d];
+    const float* e1 = tok1 + c1 * tok1_ld + (tok1_ld > D ? child * D : 0);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float v = e1[d] + pos[(long long)i * D + d];
+        if (tok0) v += tok0[c0 * D + d];
+        x[(long long)row * D + d] = v;
+    }
     if (xpk) { __syncthreads(); emit_packed_row(x + (long long)row * D, row, D, xpk, pk_mb, parts, red); }
 }
 hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state, const float* tok0,
                                  const float* tok1, const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts,
-                                 hipStream_t st, int V) {
-    depth_embed_l2_kernel<<<B * 16, 256, 0, st>>>(codes0, codes1, n_steps, state, tok0, tok1, pos, x, D, xpk, pk_mb, parts, V);
+                                 hipStream_t st, int V, int tok1_ld) {
+    depth_embed_l2_kernel<<<B * 16, 256, 0, st>>>(codes0, codes1, n_steps, state, tok0, tok1, pos, x, D, xpk, pk_mb, parts, V, tok1_ld > 0 ? tok1_ld : D);
     return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import PRECISION_EXACT, PRECISION_FAST, hqt_config, hqt_encode_out, hqt_sample_opts, hqt_sample_opts_l3
-from .spec import Stage1Spec, Stage2Spec
+from .spec import DEPTH_DECODINGS, Stage1Spec, Stage2Spec
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -31,6 +31,7 @@ def make_config(s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], max_batch: i
         c.vocab_top, c.vocab_bot, c.vocab_txt = s2.vocab_top, s2.vocab_bot, s2.vocab_txt
         c.ctx_len_img, c.ctx_len_txt, c.n_classes = s2.ctx_len_img, s2.ctx_len_txt, s2.n_classes
         c.cond_type, c.embedding_type, c.gelu_approx = s2.cond, s2.embedding, int(s2.gelu_approx)
+        c.depth_decoding = DEPTH_DECODINGS.index(getattr(s2, 'depth_decoding', 'parallel-add'))
     if (s2 is not None and getattr(s2, 'levels', 2) == 3) or (s1 is not None and getattr(s1, 'code_levels', 2) == 3):
         c.code_levels = 3
     if s1 is not None:

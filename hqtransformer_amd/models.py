@@ -115,7 +115,7 @@ class _Stage:
 
 class HQTransformerStage2(_Stage):
     """Counterpart of ``iHQGPT`` (``hqvae/models/stage2/hierarchical_ar.py:23-216``) for model_type 'parallel' and, with
-    ``spec.levels == 3``, of the three-level ``HQTransformer`` 'parallel-add' (``hqvae/models/stage2/hqtransformer.py``)."""
+    ``spec.levels == 3``, of the three-level ``HQTransformer`` ('parallel-add', 'parallel', 'parallel-reduce': ``spec.depth_decoding``; ``hqvae/models/stage2/hqtransformer.py``)."""
 
     def __init__(self, spec: Stage2Spec, seed: int = 0):
         super().__init__(stage2_param_shapes(spec), synth.stage2_weights(spec, seed, 'bench'))

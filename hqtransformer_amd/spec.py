@@ -13,6 +13,8 @@ from typing import Dict, List, Tuple
 
 COND_NONE, COND_CLS, COND_TXT = 0, 1, 2
 EMB_TRANSFORMER1, EMB_REDUCE = 0, 1
+# HQTransformer.decoding_type values whose three-level SAMPLING works in the reference and is built here (index = hqt_config.depth_decoding)
+DEPTH_DECODINGS = ('parallel-add', 'parallel', 'parallel-reduce')
 
 
 @dataclass
@@ -31,7 +33,8 @@ class Stage2Spec:
     embedding: int            # EMB_*
     gelu_approx: bool = False
     ratio_bot2top: int = 4
-    levels: int = 2           # code levels: 2 = iHQGPT (1 + 4 codes per position), 3 = HQTransformer 'parallel-add' (1 + 4 + 16)
+    levels: int = 2           # code levels: 2 = iHQGPT (1 + 4 codes per position), 3 = HQTransformer 'parallel*' (1 + 4 + 16)
+    depth_decoding: str = 'parallel-add'      # three levels: HQTransformer.decoding_type, one of DEPTH_DECODINGS (hqtransformer.py:105-157,526-551)
 
     @property
     def codes_per_pos(self) -> int:  # hqtransformer.py:187-194
@@ -76,8 +79,10 @@ def stage2_spec_from_config(cfg) -> Stage2Spec:
         vs = list(s2.vocab_sizes_img)
         if len(vs) != 3 or len(set(vs)) != 1:
             raise NotImplementedError('multilevel-hq: three levels with one vocabulary size are built')
-        if s2.decoding_type != 'parallel-add':
-            raise NotImplementedError(f"decoding_type '{s2.decoding_type}': only 'parallel-add' is built (the released level-3 config)")
+        if s2.decoding_type not in DEPTH_DECODINGS:
+            raise NotImplementedError(f"decoding_type '{s2.decoding_type}': {', '.join(DEPTH_DECODINGS)} are built ('parallel-add' is the released "
+                                      "level-3 config; 'top2mid2bot' is a 21-step causal head; 'tree', 'old-parallel' and "
+                                      "'parallel-add-reduce' cannot sample three levels in the reference either: hqtransformer.py:537-549)")
         levels = 3
     elif 'hq-transformer' not in s2.type:
         raise ValueError(f"stage2.type '{s2.type}' is not on the HQ-Transformer sampling path")
@@ -111,7 +116,8 @@ def stage2_spec_from_config(cfg) -> Stage2Spec:
                       n_layers_depth=n_layers_depth, vocab_top=vocab, vocab_bot=vocab,
                       vocab_txt=s2.vocab_size_txt, ctx_len_img=hp.ctx_len_img, ctx_len_txt=hp.ctx_len_txt,
                       n_classes=(hp.n_classes or 0), cond=cond, embedding=emb,
-                      gelu_approx=bool(hp.gelu_use_approx), ratio_bot2top=(s2.ratio_bot2top or 4))
+                      gelu_approx=bool(hp.gelu_use_approx), ratio_bot2top=(s2.ratio_bot2top or 4),
+                      depth_decoding=(s2.decoding_type if levels == 3 else 'parallel-add'))
 
 
 def stage1_spec_from_config(cfg) -> Stage1Spec:
@@ -170,8 +176,9 @@ def stage2_param_shapes(s: Stage2Spec) -> 'OrderedDict[str, Tuple[int, ...]]':
             _block_shapes(f'blocks.{i}', D, out)
         out['ln_f.weight'] = (D,)
         out['ln_f.bias'] = (D,)
-        for li in range(3):
-            out[f'tok_emb_depth_levels.{li}.weight'] = (s.vocab_top, D)
+        for li in range(3):                 # 'reduce': one D-slice of a wider row per child position (hqtransformer.py:108-116)
+            mult = (16 if li == 2 else 4) if 'reduce' in s.depth_decoding else 1
+            out[f'tok_emb_depth_levels.{li}.weight'] = (s.vocab_top, mult * D)
         out['pos_emb_depths.0.weight'] = (4, D)
         out['pos_emb_depths.1.weight'] = (16, D)
         for j in range(s.n_layers_depth):

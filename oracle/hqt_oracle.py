@@ -205,7 +205,7 @@ class OracleStage2:
 
 
 class OracleStage2L3(OracleStage2):
-    """HQTransformer 'parallel-add' sampling, three code levels: hqtransformer.py:409-635 and
+    """HQTransformer 'parallel-add' / 'parallel' / 'parallel-reduce' sampling, three code levels: hqtransformer.py:409-635 and
     sampling.py:240-307.  Per top position 1 + 4 + 16 codes; the depth transformer runs three sub-steps over 1, 4 and 16
     tokens, each seeing every earlier and current token (the 'parallel' mask of layers.py:154-178 is all-ones on the
     rows a sampling sub-step evaluates); 'transformer1' has no embedding blocks (hqtransformer.py:36-54), so the body
@@ -213,6 +213,7 @@ class OracleStage2L3(OracleStage2):
 
     # raster order of the 16 level-2 tokens: index (H1 H2 W1 W2) -> parent cell (H1 W1), child (H2 W2)
     _L2_PARENT = np.array([(i // 8) * 2 + (i % 4) // 2 for i in range(16)])
+    _L2_CHILD = np.array([((i // 4) % 2) * 2 + i % 2 for i in range(16)])
 
     def _embed3(self, c0: np.ndarray, c1: np.ndarray, c2: np.ndarray, pos: int) -> np.ndarray:
         """hqtransformer.py:466-488: mean over the 21 embedded codes (+ position of the embedding slot; + top position)."""
@@ -268,7 +269,11 @@ class OracleStage2L3(OracleStage2):
             c0[:, cnt] = d0
             fed0 = force[0][:, cnt] if force is not None else d0
             # level 1: four tokens = emb(top code) + positions 0..3 (:526-536 with cnt == 1)
-            x1 = (w['tok_emb_depth_levels.0.weight'][fed0][:, None, :] + w['pos_emb_depths.0.weight'][None, :4]).astype(F32)
+            dd = getattr(s, 'depth_decoding', 'parallel-add')
+            D = s.embed_dim
+            e0 = w['tok_emb_depth_levels.0.weight'][fed0]                                # [B, D]; 'reduce': [B, 4 D], one D-slice per slot (:532-533)
+            e0 = e0.reshape(B, 4, D) if 'reduce' in dd else e0[:, None, :]
+            x1 = (e0 + w['pos_emb_depths.0.weight'][None, :4]).astype(F32)
             l1 = depth(x1, 1)                                                            # [B, 4, V]
             d1 = np.zeros((B, 4), np.int64)
             for k in range(4):
@@ -278,8 +283,14 @@ class OracleStage2L3(OracleStage2):
             # level 2: sixteen tokens in (H1 H2 W1 W2) raster order; token i carries its parent's level-1 embedding,
             # position i of pos_emb_depths[1], and the top code's embedding ('add', :537-551)
             e1 = w['tok_emb_depth_levels.1.weight'][fed1]                                # [B, 4, D], parents in (H1 W1) order
-            x2 = (e1[:, self._L2_PARENT, :] + w['pos_emb_depths.1.weight'][None, :16] +
-                  w['tok_emb_depth_levels.0.weight'][fed0][:, None, :]).astype(F32)
+            if 'reduce' in dd:                                                           # [B, 4, 4 D]: child (H2 W2) of parent p takes slice 2 H2 + W2 (:538-539)
+                e1 = e1.reshape(B, 4, 4, D)[:, self._L2_PARENT, self._L2_CHILD, :]
+            else:
+                e1 = e1[:, self._L2_PARENT, :]
+            x2 = e1 + w['pos_emb_depths.1.weight'][None, :16]
+            if 'add' in dd:                                                              # + the top code's embedding (:549-551)
+                x2 = x2 + w['tok_emb_depth_levels.0.weight'][fed0][:, None, :]
+            x2 = x2.astype(F32)
             l2 = depth(x2, 2)                                                            # [B, 16, V]
             for k in range(16):
                 c2[:, cnt, k], _ = sample_filtered(l2[:, k], noise[cnt, 5 + k], temperature[2], top_k[2], top_p[2])

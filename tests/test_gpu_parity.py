@@ -478,6 +478,32 @@ def test_l3_sampling_vs_reference_fixture_and_oracle():
         gate(f'l3_tiny.fast_logits(graph={graph})', err, 0.12)
 
 
+@pytest.mark.parametrize('name', ['g7_l3_tiny_cls_parallel.npz', 'g7_l3_tiny_cls_parallel_reduce.npz'])
+def test_l3_other_decoding_types_vs_reference_fixture(name):
+    """hqt_config.depth_decoding 1 / 2: HQTransformer 'parallel' and 'parallel-reduce' (hqtransformer.py:105-157,526-551) through
+    hqt_sample_l3 against fixtures G7b generated from the reference: EXACT codes bit-exact and logits <= 2e-4, eager and graph; FAST
+    teacher-forced logits inside the gate of the 'parallel-add' test."""
+    fx = load(name)
+    spec = Stage2Spec(**json.loads(str(fx['spec'])))
+    weights = synth.stage2_weights(spec, int(fx['weight_seed']), 'fixture')
+    B, n, cls = int(fx['B']), int(fx['n_steps']), int(fx['cond'])
+    noise = np.maximum(np.random.default_rng([int(fx['noise_seed']), 0x9e3779b9]).standard_exponential((n, 21, B, spec.vocab_top), dtype=np.float32),
+                       np.float32(1e-30))
+    tk, tp, T = json.loads(str(fx['settings']))[0]
+    eng = engine_s2(spec, weights, 4)
+    for graph in (False, True):
+        c0, c1, c2, lg = eng.sample3(B, torch.full((B,), cls), n, precision=PRECISION_EXACT, top_k=tk, top_p=tp, temperature=T,
+                                     noise=torch.from_numpy(noise), return_logits=True, use_graph=graph)
+        assert np.abs(np_(lg)[fx['keep_steps']] - fx['logits_0']).max() <= LOGIT_TOL
+        assert (np_(c0) == fx['codes0_0']).all() and (np_(c1) == fx['codes1_0']).all() and (np_(c2) == fx['codes2_0']).all()
+    force = [torch.from_numpy(fx[f'codes{i}_0'].copy()) for i in range(3)]
+    ex = eng.sample3(B, torch.full((B,), cls), 16, precision=PRECISION_EXACT, noise=torch.from_numpy(noise[:16]),
+                     force=[f[:, :16] for f in force], return_logits=True, use_graph=False)
+    fa = eng.sample3(B, torch.full((B,), cls), 16, precision=PRECISION_FAST, noise=torch.from_numpy(noise[:16]),
+                     force=[f[:, :16] for f in force], return_logits=True, use_graph=True)
+    gate(f'l3_tiny.{spec.depth_decoding}.fast_logits', (fa[3] - ex[3]).abs().max().item(), 0.12)
+
+
 def test_l3_wide_batch_vs_oracle():
     """B = 64 at D = 256: the third level runs 1024-row GEMMs (tiled MFMA path in FAST), levels 0 / 1 the streaming GEMMs."""
     spec = Stage2Spec(embed_dim=256, n_layers=1, n_heads=4, n_layers_depth=1, vocab_top=512, vocab_bot=512, vocab_txt=64,

@@ -176,6 +176,28 @@ def test_l3_sampling_bit_exact(si):
     assert float(fx[f'margin_{si}']) > 1.00005         # every draw is decided by a margin an fp32-accurate implementation resolves
 
 
+@pytest.mark.parametrize('name', ['g7_l3_tiny_cls_parallel.npz', 'g7_l3_tiny_cls_parallel_reduce.npz'])
+def test_l3_other_decoding_types_bit_exact(name):
+    """G7b: the two other HQTransformer.decoding_type values whose three-level sampling runs in the reference -- 'parallel' (level-2
+    tokens without the top code's embedding) and 'parallel-reduce' ([V, 4 D] depth tables, one D-slice per child position) --,
+    24 positions, B = 3, top-k / top-p / temperature per level (hqtransformer.py:105-157,526-551)."""
+    from hqtransformer_amd.spec import DEPTH_DECODINGS, Stage2Spec
+    from oracle.hqt_oracle import OracleStage2L3
+    fx = load(name)
+    spec = Stage2Spec(**json.loads(str(fx['spec'])))
+    assert spec.depth_decoding in DEPTH_DECODINGS and spec.depth_decoding != 'parallel-add'
+    assert {k: tuple(v) for k, v in json.loads(str(fx['ref_shapes'])).items()} == dict(stage2_param_shapes(spec))
+    orc = OracleStage2L3(spec, synth.stage2_weights(spec, int(fx['weight_seed']), 'fixture'))
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = np.maximum(np.random.default_rng([int(fx['noise_seed']), 0x9e3779b9]).standard_exponential((n, 21, B, spec.vocab_top), dtype=np.float32),
+                       np.float32(1e-30))
+    tk, tp, T = json.loads(str(fx['settings']))[0]
+    c0, c1, c2, lg = orc.sample(np.full(B, int(fx['cond'])), B, n, noise, tk, tp, T, return_logits=True)
+    assert np.abs(lg[fx['keep_steps']] - fx['logits_0']).max() <= 2e-4
+    assert (c0 == fx['codes0_0']).all() and (c1 == fx['codes1_0']).all() and (c2 == fx['codes2_0']).all()
+    assert float(fx['margin_0']) > 1.00005
+
+
 def test_l3_decode_pixels():
     """G8: HQVAEGenerator.decode_code([top, mid, bottom]) -- additive pixel-shuffle pyramid + decoder."""
     from hqtransformer_amd.spec import Stage1Spec

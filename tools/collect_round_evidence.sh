@@ -9,9 +9,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 PMCRUN="python3 bench.py --batch 512 --merge 1 --inflight 1 --positions 2 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph"
 # ---- the default line, and the same kernels one lane at a time under the profiler (the per-kernel averages the roofline record must agree with)
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --inflight 1 --merge 8 --steps 24 --warmup 8 --no-cpu-baseline > $O/bench_one_lane_under_rocprof.json 2> $O/bench_one_lane_under_rocprof.err
-python tools/prof_summary.py $O/stats1 60 > $O/kernel_stats_one_lane_merge8.txt
-cp $(find $O/stats1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_one_lane_merge8.csv
+# the driver's own invocation (K = 20: the schedule rule gives 2 lanes x passes of 10 steps)
+timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_steps20.json 2> $O/bench_driver_steps20.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --inflight 1 --merge 32 --steps 64 --warmup 8 --no-cpu-baseline > $O/bench_one_lane_under_rocprof.json 2> $O/bench_one_lane_under_rocprof.err
+python tools/prof_summary.py $O/stats1 60 > $O/kernel_stats_one_lane_merge32.txt
+cp $(find $O/stats1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_one_lane_merge32.csv
 rm -rf $O/stats1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -- python3 bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.json 2> $O/bench_default_under_rocprof.err
 python tools/prof_summary.py $O/stats3 60 > $O/kernel_stats_bench_default.txt
@@ -33,7 +35,7 @@ python tools/pmc_summary.py $O/pmc_mfma2k > $O/pmc_mfma2k_raw.txt
 python tools/pmc_mfma.py $O/pmc_mfma2k_raw.txt $O/pmc_mfma_util_rows2048_positions1.txt > /dev/null
 rm -rf $O/pmc_mfma2k $O/pmc_mfma2k_raw.txt
 # ---- other schedules and configurations of the same build
-timeout 600 python bench.py --merge 32 --inflight 2 --steps 128 --no-cpu-baseline > $O/bench_merge32_lanes2.json 2>/dev/null
+timeout 600 python bench.py --merge 8 --inflight 3 --no-cpu-baseline > $O/bench_merge8_lanes3.json 2>/dev/null
 timeout 600 python bench.py --merge 48 --inflight 2 --no-cpu-baseline --no-roofline > $O/bench_merge48_lanes2.json 2>/dev/null
 timeout 600 python bench.py --merge 1 --inflight 3 --no-cpu-baseline --no-roofline > $O/bench_merge1_lanes3.json 2>/dev/null
 timeout 600 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
@@ -52,6 +54,7 @@ timeout 300 python tools/ar_pass_time.py --rows 64 512 1024 2048 3072 --policy 1
 timeout 300 python tools/ar_pass_time.py --rows 512 --policy 1 --breakdown --by-rows > $O/ar_pass_time_rows512_per_gemm.json 2>/dev/null
 # ---- micro-benchmarks
 timeout 300 tools/micro/bench_split > $O/micro_split_conv_variants.txt 2>&1
+timeout 100 tools/micro/bench_split_gemm > $O/micro_split_gemm_1x1.txt 2>&1
 timeout 300 tools/micro/bench_tile > $O/micro_tile_gemm.txt 2>&1
 timeout 200 tools/micro/bench_attn > $O/micro_attention.txt 2>&1
 timeout 100 tools/micro/bench_sampler > $O/micro_sampler.txt 2>&1

@@ -2,11 +2,12 @@
 """Fixtures G7/G8: the three-level path of the reference.
 
 Container-only, like tools/gen_golden.py (whose import shims it reuses): builds the reference's ``HQTransformer``
-('parallel-add', transformer1 embedding) and ``HQVAEGenerator`` (code_levels = 3) with weights derived from
+('parallel-add' -- and, for G7b, 'parallel' and 'parallel-reduce' --, transformer1 embedding) and ``HQVAEGenerator`` (code_levels = 3) with weights derived from
 numpy.default_rng by state-dict name (hqtransformer_amd/synth.py, 'fixture' profile), runs ``sampling_hqtransformer`` with
 torch.multinomial replaced by argmax(p / q) on external Exp(1) noise, and ``decode_code([t, m, b])``; stores only inputs
 and outputs:
   tests/golden/g7_l3_tiny_cls.npz   codes of all three levels for 64 positions, B = 3, two sampler settings, logits of 4 positions
+  tests/golden/g7_l3_tiny_cls_parallel.npz, g7_l3_tiny_cls_parallel_reduce.npz   the same for the two other decoding types, 24 positions
   tests/golden/g8_l3_decode.npz     3-level decode_code pixels (all levels; top only; bottom only) on a 64-pixel decoder
 """
 import json
@@ -44,7 +45,7 @@ def build_stage2_l3(spec: Stage2Spec, seed: int):
         import copy
         hp_dec = copy.deepcopy(hp)
         hp_dec.n_layers = spec.n_layers_depth
-    m = HQTransformer([spec.vocab_top] * 3, spec.vocab_txt, 'parallel-add', spec.cond == 1, spec.cond == 2, hp, hp_dec)
+    m = HQTransformer([spec.vocab_top] * 3, spec.vocab_txt, spec.depth_decoding, spec.cond == 1, spec.cond == 2, hp, hp_dec)
     sd = {k: torch.from_numpy(v) for k, v in synth.stage2_weights(spec, seed, 'fixture').items()}
     ref_shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     mine = {k: tuple(v.shape) for k, v in sd.items()}
@@ -121,6 +122,24 @@ def main():
         print('G7 setting', si, 'shapes', [c.shape for c in codes], 'min winner/runner-up ratio', margin)
     np.savez_compressed(os.path.join(G.OUT, 'g7_l3_tiny_cls.npz'), **out)
     print('g7_l3_tiny_cls ok', os.path.getsize(os.path.join(G.OUT, 'g7_l3_tiny_cls.npz')), 'bytes')
+
+    # ---------------------------------------------------------------- G7b: the other decoding types whose three-level sampling runs in the reference
+    for dd in ('parallel', 'parallel-reduce'):
+        vspec = Stage2Spec(embed_dim=128, n_layers=2, n_heads=4, n_layers_depth=2, vocab_top=512, vocab_bot=512, vocab_txt=64,
+                           ctx_len_img=64, ctx_len_txt=16, n_classes=10, cond=1, embedding=0, levels=3, depth_decoding=dd)
+        vmodel, vshapes = build_stage2_l3(vspec, 71)
+        vB, vn = 3, 24
+        vnoise = np.maximum(np.random.default_rng([72, 0x9e3779b9]).standard_exponential((vn, 21, vB, vspec.vocab_top), dtype=np.float32), np.float32(1e-30))
+        vset = ((60, 40, 30), (1.0, 0.95, None), (1.0, 0.9, 0.8))
+        vkeep = [0, 1, 23]
+        codes, lg, margin = run_sampling_l3(vmodel, vB, 4, vn, vnoise, *vset)
+        scale = np.array([vset[2][0]] + [vset[2][1]] * 4 + [vset[2][2]] * 16, np.float32)[None, :, None, None]
+        name = 'g7_l3_tiny_cls_' + dd.replace('-', '_') + '.npz'
+        np.savez_compressed(os.path.join(G.OUT, name), spec=G.spec_json(vspec), weight_seed=np.int64(71), noise_seed=np.int64(72), B=np.int64(vB),
+                            n_steps=np.int64(vn), cond=np.int64(4), settings=json.dumps([vset]), keep_steps=np.array(vkeep), codes0_0=codes[0], codes1_0=codes[1],
+                            codes2_0=codes[2], logits_0=(lg * scale)[vkeep], margin_0=np.float64(margin),
+                            ref_shapes=json.dumps({k: list(v) for k, v in vshapes.items()}))
+        print(name, 'ok', [c.shape for c in codes], 'min winner/runner-up ratio', margin, os.path.getsize(os.path.join(G.OUT, name)), 'bytes')
 
     # ---------------------------------------------------------------- G8: 3-level decode_code
     s1 = Stage1Spec(ch=32, ch_mult=[1, 2, 4], num_res_blocks=1, attn_resolutions=[8], resolution=64, z_channels=32, embed_dim=16,
