@@ -659,6 +659,130 @@ __global__ __launch_bounds__(256) void attention_prefill_mfma_kernel(AttnArgs a)
 #endif
 }
 
+// The same few-query case with head size 64 and at most 8 keys (depth sub-step 1: 4 queries x 5 keys), from 64 samples: EIGHT heads per
+// wave.  A head is the 8 lanes that cover one 128-byte key / value row, and all its keys sit in that group's registers, so a wave holds
+// 8 x (NK keys + NK values + Tq queries) x 16 bytes in flight instead of one head's, an eighth of the waves are dispatched (at 2048
+// samples 6 144 instead of 49 152: the launch was paced by occupancy rounds of one-round-trip waves; 73.6 -> 21.2 us, 8.0 -> 5.3 us at 64
+// samples: tools/micro/bench_attn), and every lane stores.  Scores, maxima and exponentials are the very operations of attention_fewq_kernel; the sums over the keys are taken in the
+// order of its cross-lane tree (slot ^ 1, ^ 2, ^ 4), so the results are bit-identical.
+template <typename T, int NK, int TQ>
+__global__ __launch_bounds__(256) void attention_fewq8_kernel(AttnArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gid = (blockIdx.x * 4 + wave) * 8 + (lane >> 3);          // (sample, head) of this 8-lane group
+    const bool live = gid < a.B * a.n_heads;
+    const int g = live ? gid : a.B * a.n_heads - 1;
+    const int h = g % a.n_heads, b = g / a.n_heads, c = lane & 7;
+    constexpr int hs = 64;
+    const int D = a.n_heads * hs;
+    const T* kc = reinterpret_cast<const T*>(a.kcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
+    const T* vc = reinterpret_cast<const T*>(a.vcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
+    const T* qp = reinterpret_cast<const T*>(a.q) + (long long)b * a.Tq * D + h * hs + c * 8;
+    typedef typename std::conditional<sizeof(T) == 2, uint4, float4>::type raw_t;
+    constexpr int NRAW = sizeof(T) == 2 ? 1 : 2;
+    raw_t kbuf[NK][NRAW], vbuf[NK][NRAW], qbuf[TQ][NRAW];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const raw_t* ks = reinterpret_cast<const raw_t*>(kc + (long long)j * D);
+        const raw_t* vs = reinterpret_cast<const raw_t*>(vc + (long long)j * D);
+#pragma unroll
+        for (int e = 0; e < NRAW; ++e) { kbuf[j][e] = ks[e]; vbuf[j][e] = vs[e]; }
+    }
+#pragma unroll
+    for (int qi = 0; qi < TQ; ++qi) {
+        const raw_t* qs = reinterpret_cast<const raw_t*>(qp + (long long)min(qi, a.Tq - 1) * D);
+#pragma unroll
+        for (int e = 0; e < NRAW; ++e) qbuf[qi][e] = qs[e];
+    }
+    auto unpack = [](const raw_t* r, float (&f)[8]) {
+        if (sizeof(T) == 2) {
+            const uint4 t = *reinterpret_cast<const uint4*>(r);
+            const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); f[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
+        } else {
+            const float4 a0 = *reinterpret_cast<const float4*>(r), a1 = *reinterpret_cast<const float4*>(r + 1);
+            f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
+        }
+    };
+    const float scale = 0.125f;                                        // 1 / sqrt(64), exact
+    float kf[NK][8];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        unpack(kbuf[j], kf[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kf[j][i] *= scale;                 // scale on K, as layers.py:102
+    }
+#pragma unroll
+    for (int qi = 0; qi < TQ; ++qi) {
+        if (qi >= a.Tq) break;
+        const int nkeys = a.causal ? a.t_base + qi + 1 : a.t_base + a.Tq;
+        float qv[8];
+        unpack(qbuf[qi], qv);
+        float sc[8], gmax = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = -INFINITY;
+            if (j < NK) {
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s = fmaf(qv[i], kf[j][i], s);
+                s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+                if (j < nkeys) sc[j] = s;
+            }
+            gmax = fmaxf(gmax, sc[j]);
+        }
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = j < NK ? expf(sc[j] - gmax) : 0.0f;      // 0 for masked keys
+        const float run_sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+        const float inv = 1.0f / run_sum;
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+                float vv[8];
+                unpack(vbuf[j], vv);
+                p[j] = fmaf(e[j], vv[i], 0.0f);
+            }
+            acc[i] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) * inv;
+        }
+        if (live) {
+            const int row = b * a.Tq + qi, col = h * hs + c * 8;
+            T* o = a.out_packed_mb ? reinterpret_cast<T*>(a.out) + packed_off(row, col, a.out_packed_mb)
+                                   : reinterpret_cast<T*>(a.out) + (long long)row * D + col;
+            if (sizeof(T) == 2) {
+                uint4 pk;
+                pk.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+                pk.z = (unsigned)f32_to_bf16(acc[4]) | ((unsigned)f32_to_bf16(acc[5]) << 16);
+                pk.w = (unsigned)f32_to_bf16(acc[6]) | ((unsigned)f32_to_bf16(acc[7]) << 16);
+                *reinterpret_cast<uint4*>(o) = pk;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st1<T>(o + i, acc[i]);
+            }
+        }
+    }
+}
+template <typename T>
+static hipError_t launch_fewq8(const AttnArgs& a, hipStream_t st) {
+    const int groups = a.B * a.n_heads, grid = (groups + 31) / 32;
+    switch (a.t_base + a.Tq) {
+    case 2: attention_fewq8_kernel<T, 2, 4><<<grid, 256, 0, st>>>(a); break;
+    case 3: attention_fewq8_kernel<T, 3, 4><<<grid, 256, 0, st>>>(a); break;
+    case 4: attention_fewq8_kernel<T, 4, 4><<<grid, 256, 0, st>>>(a); break;
+    case 5: attention_fewq8_kernel<T, 5, 4><<<grid, 256, 0, st>>>(a); break;
+    case 6: attention_fewq8_kernel<T, 6, 4><<<grid, 256, 0, st>>>(a); break;
+    case 7: attention_fewq8_kernel<T, 7, 4><<<grid, 256, 0, st>>>(a); break;
+    default: attention_fewq8_kernel<T, 8, 4><<<grid, 256, 0, st>>>(a); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
     const int chunks = a.head_dim / 8;
     if (a.head_dim % 8 != 0 || chunks > 64 || (chunks & (chunks - 1)) != 0) return hipErrorInvalidValue;
@@ -666,6 +790,10 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
     if (a.Tq > 1 && a.Tq <= 16 && !a.t_base_dev && !a.dbg && a.t_base + a.Tq <= 2 * (64 / chunks)) {
         static const bool off = getenv("HQT_NO_FEWQ_ATTN") != nullptr;          // A/B switch
         if (!off) {
+            // head size 64, <= 4 queries over <= 8 keys, 64+ samples: eight heads per wave (attention_fewq8_kernel; HQT_NO_FEWQ8=1: A/B switch)
+            static const bool off8 = getenv("HQT_NO_FEWQ8") != nullptr;
+            if (!off8 && a.head_dim == 64 && a.Tq <= 4 && a.t_base + a.Tq <= 8 && a.B >= 64)
+                return a.dtype == DT_BF16 ? launch_fewq8<bf16_t>(a, st) : launch_fewq8<float>(a, st);
             const int g2 = (a.B * a.n_heads + 3) / 4, one = a.t_base + a.Tq <= 64 / chunks;
             if (a.dtype == DT_BF16) { if (one) attention_fewq_kernel<bf16_t, 1><<<g2, 256, 0, st>>>(a); else attention_fewq_kernel<bf16_t, 2><<<g2, 256, 0, st>>>(a); }
             else { if (one) attention_fewq_kernel<float, 1><<<g2, 256, 0, st>>>(a); else attention_fewq_kernel<float, 2><<<g2, 256, 0, st>>>(a); }
@@ -1011,6 +1139,118 @@ __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {
     }
 }
 
+// FAST draws without a cut-off (top_k = top_p = None: the H1 harness settings): at 2048 samples per pass the bottom codes are 8192 rows
+// x 8192 logits per position.  argmax_i p_i / q_i does not need p normalised, so the row never
+// leaves the registers: 4 waves per row, thread t owns the float4 groups t, t + 256, ... (the Philox counter of a group is its index,
+// as in sampler_kernel), one pass for the maximum, one for exp(l - max) / q and the running best, two 4-wave barriers in all -- against
+// five block-wide reductions over 16 waves and four trips through a 32-KB LDS row in the general kernel (8192 rows: 239 -> 93 us, 2048
+// rows: 65 -> 31 us, tools/micro/bench_sampler).  Same v_exp / v_log / v_rcp forms as sampler_kernel<.., true>; the ratio lacks the factor 1 / sum, which cannot
+// change the winner except between ratios that differ in the last bit.
+template <int G4>
+__global__ __launch_bounds__(256) void sampler_plain_fast_kernel(SamplerArgs a) {
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    const int V = a.V, tid = threadIdx.x;
+    const int r = blockIdx.x, b = r / a.slots, slot = r % a.slots;
+    const int step = a.state->step;
+    const int draw = a.draw0 + slot;
+    const float* lg = a.logits + (long long)r * V;
+    const int draws = a.draws > 0 ? a.draws : 5;
+    const long long nidx = (((long long)step * draws + draw) * a.B + b) * V;
+    const float inv_t = __builtin_amdgcn_rcpf(a.temperature);
+    float4 v[G4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < G4; ++k) {
+        const int i4 = tid + 256 * k;
+        if (i4 * 4 < V) {                                 // V % 4 == 0
+            v[k] = *reinterpret_cast<const float4*>(lg + i4 * 4);
+            if (a.logits_out) *reinterpret_cast<float4*>(a.logits_out + nidx + i4 * 4) = v[k];
+            v[k].x *= inv_t; v[k].y *= inv_t; v[k].z *= inv_t; v[k].w *= inv_t;
+            m = fmaxf(fmaxf(m, fmaxf(v[k].x, v[k].y)), fmaxf(v[k].z, v[k].w));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) redf[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    float best = -1.0f;
+    int besti = 0;
+    const uint64_t seed = a.rows[b].seed;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint64_t grow = (uint64_t)a.rows[b].global_row;
+#pragma unroll
+    for (int k = 0; k < G4; ++k) {
+        const int i4 = tid + 256 * k;
+        if (i4 * 4 < V) {
+            float q[4];
+            if (a.noise) {
+                const float4 n4 = *reinterpret_cast<const float4*>(a.noise + nidx + i4 * 4);
+                q[0] = n4.x; q[1] = n4.y; q[2] = n4.z; q[3] = n4.w;
+            } else {
+                uint32_t rnd[4];
+                philox4x32_10((uint32_t)i4, (uint32_t)(step * draws + draw), (uint32_t)grow, (uint32_t)(grow >> 32), k0, k1, rnd);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = -__logf(((float)(rnd[e] >> 8) + 0.5f) * (1.0f / 16777216.0f));
+            }
+            const float l[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ratio = __expf(l[e] - m) * __builtin_amdgcn_rcpf(q[e]);
+                if (ratio > best) { best = ratio; besti = i4 * 4 + e; }         // ascending index per thread: the first maximum wins
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(besti, off, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    __syncthreads();                                      // redf has been read by everyone
+    if ((tid & 63) == 0) { redf[tid >> 6] = best; redi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (redf[w] > best || (redf[w] == best && redi[w] < besti)) { best = redf[w]; besti = redi[w]; }
+        a.out[((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
+        if (a.emb_tok) redi[0] = a.emb_feed ? (int)clamp_idx(a.emb_feed[((long long)b * a.n_steps + step) * a.slots + slot], a.V) : besti;
+    }
+    if (!a.emb_tok) return;                              // workgroup-uniform
+    // ---- fused embedding lookup, as in sampler_kernel: the four input rows of depth sub-step 1 for the top code just drawn
+    __shared__ float reds[4], redq[4];
+    __syncthreads();
+    const long long code = redi[0];
+    const int D = a.emb_D;
+#pragma unroll 1
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int row = b * 4 + s4;
+        float rs = 0.0f, rq = 0.0f;
+        for (int d = tid; d < D; d += 256) {
+            const float x = a.emb_tok[code * D + d] + a.emb_pos[(long long)s4 * D + d];
+            a.emb_x[(long long)row * D + d] = x;
+            if (a.emb_xpk) {
+                const bf16_t hb = f32_to_bf16(x);
+                a.emb_xpk[packed_off(row, d, a.emb_pk_mb)] = hb;
+                const float rr = bf16_to_f32(hb);
+                rs += rr; rq += rr * rr;
+            }
+        }
+        if (a.emb_xpk) {                                 // fixed-order reduction: lanes, then waves 0 .. 3
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { rs += __shfl_xor(rs, off, 64); rq += __shfl_xor(rq, off, 64); }
+            __syncthreads();
+            if ((tid & 63) == 0) { reds[tid >> 6] = rs; redq[tid >> 6] = rq; }
+            __syncthreads();
+            if (tid == 0) {
+                a.emb_parts[2 * row] = ((reds[0] + reds[1]) + reds[2]) + reds[3];
+                a.emb_parts[2 * row + 1] = ((redq[0] + redq[1]) + redq[2]) + redq[3];
+            }
+        }
+    }
+}
+
 static size_t sampler_smem(int V, bool use_p, int& n2) {
     n2 = 256;
     while (n2 < V) n2 <<= 1;
@@ -1045,6 +1285,14 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
     int n2;
     const size_t smem = sampler_smem(a.V, a.top_p > 0.0f, n2);
     if (smem > 160 * 1024) return hipErrorInvalidValue;               // sampler_configure(V, top_p) ran in sample_run for this call's options
+    // FAST, no cut-offs, V <= 8192: the register-resident kernel (HQT_NO_PLAIN_SAMPLER=1: A/B switch)
+    static const bool no_plain = getenv("HQT_NO_PLAIN_SAMPLER") != nullptr;
+    if (!no_plain && a.fast_math && !(a.top_k > 0 && a.top_k < a.V) && !(a.top_p > 0.0f) && a.V % 4 == 0 && a.V <= 8192 && a.V >= 1024) {
+        if (a.V <= 2048) sampler_plain_fast_kernel<2><<<a.R, 256, 0, st>>>(a);
+        else if (a.V <= 4096) sampler_plain_fast_kernel<4><<<a.R, 256, 0, st>>>(a);
+        else sampler_plain_fast_kernel<8><<<a.R, 256, 0, st>>>(a);
+        return hipGetLastError();
+    }
     if (a.V >= 4096) { if (a.fast_math) sampler_kernel<1024, true><<<a.R, 1024, smem, st>>>(a, n2); else sampler_kernel<1024, false><<<a.R, 1024, smem, st>>>(a, n2); }
     else { if (a.fast_math) sampler_kernel<256, true><<<a.R, 256, smem, st>>>(a, n2); else sampler_kernel<256, false><<<a.R, 256, smem, st>>>(a, n2); }
     return hipGetLastError();

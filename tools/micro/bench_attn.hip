@@ -98,7 +98,7 @@ static float graph_time(hipStream_t st, int reps, F body) {
 int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
     const int D = 1536, nh = 24, hs = 64, Tmax = 64, L = 12;
-    for (int B : {64, 256, 512}) {
+    for (int B : {64, 256, 512, 2048}) {
         bf16_t *q, *o; CK(hipMalloc(&q, (size_t)B * D * 2)); CK(hipMalloc(&o, (size_t)B * D * 2)); CK(hipMemset(q, 0, (size_t)B * D * 2));
         std::vector<bf16_t*> kc(L), vc(L);
         const size_t bytes = (size_t)B * Tmax * D * 2;
@@ -122,7 +122,10 @@ int main() {
             bf16_t *q4, *o4; CK(hipMalloc(&q4, (size_t)B * 4 * D * 2)); CK(hipMalloc(&o4, (size_t)B * 4 * D * 2)); CK(hipMemset(q4, 0, (size_t)B * 4 * D * 2));
             AttnArgs at{q4, nullptr, nullptr, o4, B, 4, nh, hs, 5, 1, nullptr, 1, DT_BF16, 0, nullptr};
             const float t0 = graph_time(st, 5, [&] { for (int l = 0; l < L; ++l) { AttnArgs a = at; a.kcache = kc[l]; a.vcache = vc[l]; CK(launch_attention(a, st)); } }) / L;
-            printf("B=%3d depth sub-step 1 (4 queries x <= 5 keys, %d waves): %.2f us\n", B, B * nh * 4, t0);
+            // one head per wave (attention_fewq_kernel) beside the dispatch's choice (eight heads per wave from 256 samples: attention_fewq8_kernel)
+            const float t1 = graph_time(st, 5, [&] { for (int l = 0; l < L; ++l) { AttnArgs a = at; a.kcache = kc[l]; a.vcache = vc[l];
+                attention_fewq_kernel<bf16_t, 1><<<(B * nh + 3) / 4, 256, 0, st>>>(a); } }) / L;
+            printf("B=%4d depth sub-step 1 (4 queries x <= 5 keys): dispatch %.2f us | one head per wave (%d waves) %.2f us\n", B, t0, B * nh, t1);
             CK(hipFree(q4)); CK(hipFree(o4));
         }
         for (int l = 0; l < L; ++l) { CK(hipFree(kc[l])); CK(hipFree(vc[l])); }

@@ -5,7 +5,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
-    const int V = 8192, B = 512;
+    const int V = 8192, B = 2048;
     float* logits; CK(hipMalloc(&logits, (size_t)4 * B * V * 4));
     {
         std::vector<float> h((size_t)4 * B * V);
@@ -19,7 +19,9 @@ int main() {
     int64_t* out; CK(hipMalloc(&out, (size_t)B * 64 * 4 * 8));
     for (int fm = 0; fm < 2; ++fm)
     for (int mode = 0; mode < 3; ++mode) {
-        for (int slots : {1, 4}) {
+        for (int slots : {1, 4})
+        for (int B : {512, 2048}) {
+            if (slots == 1 && B != 512) continue;
             SamplerArgs a{};
             a.fast_math = fm;
             a.logits = logits; a.R = B * slots; a.V = V; a.slots = slots; a.B = B; a.temperature = 1.0f;
