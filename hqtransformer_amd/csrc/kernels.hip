@@ -768,6 +768,125 @@ __global__ __launch_bounds__(256) void attention_fewq8_kernel(AttnArgs a) {
         }
     }
 }
+// One query per sample over the body's KV cache (a decode step of the AR loop), head size 64: EIGHT heads per wave, like
+// attention_fewq8_kernel.  The 8 lanes of a head walk its keys in chunks of CH rows (K and V of a chunk in flight together; the bf16
+// kernel fetches chunk i + 1 before it works on chunk i), scores by 8 FMAs and a 3-step shuffle inside the lane group, online softmax
+// across chunks in registers, every lane stores its 8 outputs.  Against attention_kernel (one head per wave, 8 keys per pass across the
+// lane groups) a launch dispatches an eighth of the waves -- with one key cached that kernel took 14 us at 512 samples and 57 us at
+// 2048 for 3 / 12 MB: occupancy rounds of one-round-trip waves, under every launch of the pass -- and a key row of 8 neighbouring heads
+// is one contiguous kilobyte.  The sums run over the keys in index order (attention_kernel: a tree across lane groups), so results
+// differ from that kernel's in the last bits (FAST passes only: see launch_attention).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_heads8_kernel(AttnArgs a) {
+    constexpr int hs = 64, CH = sizeof(T) == 2 ? 8 : 4, NRAW = sizeof(T) == 2 ? 1 : 2;
+    constexpr bool PREFETCH = sizeof(T) == 2;
+    typedef typename std::conditional<sizeof(T) == 2, uint4, float4>::type raw_t;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gid = (blockIdx.x * 4 + wave) * 8 + (lane >> 3);
+    const bool live = gid < a.B * a.n_heads;
+    const int g = live ? gid : a.B * a.n_heads - 1;
+    const int h = g % a.n_heads, b = g / a.n_heads, c = lane & 7;
+    const int D = a.n_heads * hs;
+    const T* kc = reinterpret_cast<const T*>(a.kcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
+    const T* vc = reinterpret_cast<const T*>(a.vcache) + (long long)b * a.Tmax * D + h * hs + c * 8;
+    auto unpack = [](const raw_t* r, float (&f)[8]) {
+        if (sizeof(T) == 2) {
+            const uint4 t = *reinterpret_cast<const uint4*>(r);
+            const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32((bf16_t)(w[i] & 0xffffu)); f[2 * i + 1] = bf16_to_f32((bf16_t)(w[i] >> 16)); }
+        } else {
+            const float4 a0 = *reinterpret_cast<const float4*>(r), a1 = *reinterpret_cast<const float4*>(r + 1);
+            f[0] = a0.x; f[1] = a0.y; f[2] = a0.z; f[3] = a0.w; f[4] = a1.x; f[5] = a1.y; f[6] = a1.z; f[7] = a1.w;
+        }
+    };
+    raw_t qraw[NRAW];
+    {
+        const raw_t* qs = reinterpret_cast<const raw_t*>(reinterpret_cast<const T*>(a.q) + (long long)b * D + h * hs + c * 8);
+#pragma unroll
+        for (int e = 0; e < NRAW; ++e) qraw[e] = qs[e];                 // independent of the step state: in flight while t_base arrives
+    }
+    const int nkeys = a.t_base + (a.t_base_dev ? *a.t_base_dev : 0) + 1;       // Tq == 1: causal or not, the query sees every cached key and itself
+    raw_t kb[2][CH][NRAW], vb[2][CH][NRAW];
+    auto fetch = [&](int j0, int slot) {
+#pragma unroll
+        for (int p = 0; p < CH; ++p) {
+            const long long j = min(j0 + p, nkeys - 1);                 // clamped: unconditional loads, all in flight at once
+            const raw_t* ks = reinterpret_cast<const raw_t*>(kc + j * D);
+            const raw_t* vs = reinterpret_cast<const raw_t*>(vc + j * D);
+#pragma unroll
+            for (int e = 0; e < NRAW; ++e) { kb[slot][p][e] = ks[e]; vb[slot][p][e] = vs[e]; }
+        }
+    };
+    float qv[8];
+    float run_max = -INFINITY, run_sum = 0.0f, acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+    auto work = [&](int j0, int slot) {
+        float sc[CH], cmax = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < CH; ++p) {
+            float kv[8];
+            unpack(kb[slot][p], kv);
+            float sdot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sdot = fmaf(qv[i], kv[i] * 0.125f, sdot);     // scale 1 / sqrt(64) on K, as layers.py:102
+            sdot += __shfl_xor(sdot, 4, 64); sdot += __shfl_xor(sdot, 2, 64); sdot += __shfl_xor(sdot, 1, 64);
+            sc[p] = (j0 + p < nkeys) ? sdot : -INFINITY;
+            cmax = fmaxf(cmax, sc[p]);
+        }
+        const float new_max = fmaxf(run_max, cmax);                     // finite: key j0 is valid
+        const float rescale = expf(run_max - new_max);                  // 0 for the first chunk
+        run_sum *= rescale;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] *= rescale;
+#pragma unroll
+        for (int p = 0; p < CH; ++p) {
+            const float e = expf(sc[p] - new_max);                      // 0 for masked rows
+            run_sum += e;
+            float vv[8];
+            unpack(vb[slot][p], vv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(e, vv[i], acc[i]);
+        }
+        run_max = new_max;
+    };
+    fetch(0, 0);
+    unpack(qraw, qv);
+    if (PREFETCH) {
+        for (int j0 = 0; j0 < nkeys; j0 += 2 * CH) {                    // two chunks per trip: static register slots
+            if (j0 + CH < nkeys) fetch(j0 + CH, 1);
+            work(j0, 0);
+            if (j0 + CH >= nkeys) break;
+            if (j0 + 2 * CH < nkeys) fetch(j0 + 2 * CH, 0);
+            work(j0 + CH, 1);
+        }
+    } else {
+        for (int j0 = 0; j0 < nkeys; j0 += CH) {
+            if (j0 > 0) fetch(j0, 0);
+            work(j0, 0);
+        }
+    }
+    const float inv = 1.0f / run_sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] *= inv;
+    if (live) {
+        const int col = h * hs + c * 8;
+        T* o = a.out_packed_mb ? reinterpret_cast<T*>(a.out) + packed_off(b, col, a.out_packed_mb)
+                               : reinterpret_cast<T*>(a.out) + (long long)b * D + col;
+        if (sizeof(T) == 2) {
+            uint4 pk;
+            pk.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+            pk.z = (unsigned)f32_to_bf16(acc[4]) | ((unsigned)f32_to_bf16(acc[5]) << 16);
+            pk.w = (unsigned)f32_to_bf16(acc[6]) | ((unsigned)f32_to_bf16(acc[7]) << 16);
+            *reinterpret_cast<uint4*>(o) = pk;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st1<T>(o + i, acc[i]);
+        }
+    }
+}
 template <typename T>
 static hipError_t launch_fewq8(const AttnArgs& a, hipStream_t st) {
     const int groups = a.B * a.n_heads, grid = (groups + 31) / 32;
@@ -806,6 +925,15 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
         const int g2 = (a.B * a.n_heads + 3) / 4;
         if (a.Tq <= 32) attention_prefill_mfma_kernel<1><<<g2, 256, 0, st>>>(a);
         else attention_prefill_mfma_kernel<2><<<g2, 256, 0, st>>>(a);
+        return hipGetLastError();
+    }
+    // one query per sample, head size 64 (the decode steps of a merged FAST pass): eight heads per wave (HQT_NO_HEADS8=1: A/B switch)
+    static const bool no_h8 = getenv("HQT_NO_HEADS8") != nullptr;
+    // FAST only, from 256 samples: below that the launch is a handful of waves and the chunk-by-chunk walk loses to attention_kernel's
+    // single round trip from 32 keys on (64 samples x 64 keys: 19.1 vs 9.3 us); EXACT keeps ONE kernel for every row count, so that a
+    // row's draws do not depend on the pass it sits in (hqt.h: merged steps).
+    if (!no_h8 && a.Tq == 1 && a.head_dim == 64 && !a.dbg && a.dtype == DT_BF16 && a.B >= 256) {
+        attention_heads8_kernel<bf16_t><<<(a.B * a.n_heads + 31) / 32, 256, 0, st>>>(a);
         return hipGetLastError();
     }
     const int grid = (a.B * a.n_heads * a.Tq + 3) / 4;
