@@ -231,12 +231,15 @@ def main():
     def sample_codes(i, graph, nb=None):
         """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels).  nb: rows of the pass (default: one step's batch)."""
         nb = nb or B
+        cond = cond_of(i)
+        if txt_cond and nb > B:          # a text batch is as long as its prompt tensor (sampling.py:187-190): a pass of nb rows = nb / B prompt batches
+            cond = torch.cat([cond_of(i + j) for j in range(nb // B)], 0)
         if three:
-            c = sampling_hqtransformer(model.stage2, num_candidates=nb, cond=cond_of(i), top_k=[tk] * 3, top_p=[tp] * 3,
+            c = sampling_hqtransformer(model.stage2, num_candidates=nb, cond=cond, top_k=[tk] * 3, top_p=[tp] * 3,
                                        softmax_temperature=[T] * 3, use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i,
                                        sample_offset=rank * B, use_graph=graph)
             return c[0], c[1:]
-        return sampling_ihqgpt(model.stage2, num_candidates=nb, cond=cond_of(i), top_k_top=tk, top_p_top=tp, top_k_bot=tk,
+        return sampling_ihqgpt(model.stage2, num_candidates=nb, cond=cond, top_k_top=tk, top_p_top=tp, top_k_bot=tk,
                                top_p_bot=tp, softmax_temperature=[T, T], use_fp16=fast, is_tqdm=False, max_seq_len=n_pos,
                                model_stage1=None, seed=1 + i, sample_offset=rank * B, use_graph=graph)
 
@@ -503,6 +506,9 @@ def main():
                         'note': 'achieved / frac = ALGORITHMIC FLOPs (2 x MACs of the reference\'s nn.Conv2d calls, stage1/modules/layers.py) per launch / average launch duration, against the dense '
                                 'f16/bf16 MFMA peak; achieved_issued / frac_issued count the MFMA work actually issued (SPLIT: three fp16 MFMAs per product term)'})
         fam.sort(key=lambda f: -f['total_ms'])
+        for f in fam:               # a fraction above the peak means the FLOPs and the timed launches are not the same work: refuse to print it
+            if not (0.0 < f['frac'] <= 1.0 and f.get('frac_issued', f['frac']) <= 1.0):
+                raise RuntimeError(f"roofline record out of range ({f['kernel'][:40]}...: frac {f['frac']}, issued {f.get('frac_issued')}): the measured pass and its FLOP count disagree")
         if fam:
             out['roofline'] = fam[0]
             out['roofline_other'] = fam[1:]

@@ -29,7 +29,7 @@ def test_roofline_and_cpu_baseline_objects():
     d = latest()
     for r in [d['roofline']] + list(d.get('roofline_other', [])):
         assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
-        assert abs(r['frac'] - r['achieved'] / r['peak']) < 2e-3
+        assert abs(r['frac'] - r['achieved'] / r['peak']) < 2e-3 and 0.0 < r['frac'] <= 1.0
         assert r['traffic'] is None or r['traffic'] > 0
         assert r['launches'] > 0 and r['avg_launch_us'] > 0
     c = d['cpu_baseline']
