@@ -321,15 +321,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_lanes = float(t.item())
     # what the host itself spends per step: one more pass submitted into EMPTY queues (untimed), so that nothing throttles the submitting thread
-    host_free_s = 0.0
+    # (at most 8 steps: a pass of 32 steps is > 4000 launches, more than the HIP queues take without blocking the submitter -- measured 26 ms
+    # "per step" that way, all of it waiting; the first, untimed round captures the graph of that row count)
+    host_free_s, host_free_steps = 0.0, min(merge, 8)
     if not debug_short:
-        t1 = time.perf_counter()
-        for j in range(merge):
-            pipe.submit(B, cond_of(j), seed=3000 + j, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
-                        use_graph=not args.no_graph, after=None, precision=dec_prec, **samp_kw)
-        pipe.flush()
-        host_free_s = (time.perf_counter() - t1) / merge
-        pipe.drain()
+        for timed_round in (False, True):
+            t1 = time.perf_counter()
+            for j in range(host_free_steps):
+                pipe.submit(B, cond_of(j), seed=3000 + j, max_seq_len=n_pos, use_fp16=fast, sample_offset=rank * B,
+                            use_graph=not args.no_graph, after=None, precision=dec_prec, **samp_kw)
+            pipe.flush()
+            host_free_s = (time.perf_counter() - t1) / host_free_steps
+            pipe.drain()
     host_ms_ranks = [round(1000 * host_submit_s / args.steps, 3)]
     if dist is not None:
         t = torch.tensor([host_submit_s], dtype=torch.float64, device=cdev)
@@ -407,7 +410,7 @@ def main():
             'host_ms_per_step_unthrottled': round(1000 * host_free_s, 3),
             'host_ms_note': 'host_ms_per_step = wall time until the last step of the timed region was handed to HIP / steps -- the runtime blocks (spins) the submitting thread '
                             'when its queues are full, so a value close to ms_per_step means the DEVICE paces the run; host_ms_per_step_unthrottled = the same submission '
-                            'into empty queues (one untimed pass, rank 0): what the host itself costs per step',
+                            f'into empty queues (one untimed pass of {host_free_steps} steps, rank 0): what the host itself costs per step',
             'env_switches': {k: v for k, v in sorted(os.environ.items()) if k.startswith('HQT_')},
             'serial': {'value': round(serial_value, 2), 'ms_per_step': round(serial_ms, 3), 'steps': n_serial,
                        'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
