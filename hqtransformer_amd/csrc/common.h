@@ -178,7 +178,8 @@ struct GemmArgs {
     const void* Bw_up16;     // optional, upsampling convs: the four 2x2 phase filters (pre-summed taps), packed like Bw_frag16 (conv2x2_split_up16_kernel)
     double* gn_part_out_d;
     int a_f32;               // split_gemm_kernel only: A is the fp32 tensor itself ([row][K], lda floats); the hi / lo split happens while the tile is staged
-    int* range_flag;         // a_f32: where an element outside the fp16 range is reported (hqt_range_check)
+    int b_f32;               // split_gemm_kernel only, with a_f32: Bw is an fp32 tensor too ([n][K], ldb floats; Bw_lo unused)
+    int* range_flag;         // a_f32 / b_f32: where an element outside the fp16 range is reported (hqt_range_check)
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

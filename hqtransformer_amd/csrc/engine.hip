@@ -1504,6 +1504,17 @@ static int s1_plain(S1Ctx& c, GemmArgs* g, const Lin& l) {
     return HQT_OK;
 }
 
+// SPLIT: a product of two fp32 ACTIVATION tensors (the attention block's q k^T and softmax v) on the matrix cores -- both operands are
+// split while their tiles are staged (split_gemm_kernel<true, true>); shapes it does not take stay on the fp32 vector-ALU kernel
+static bool s1_split_product(hqt_handle* h, const Mode& md, GemmArgs& sg) {
+    if (!md.split) return false;
+    GemmArgs t = sg;
+    t.a_f32 = 1; t.b_f32 = 1; t.range_flag = h->range_flag;
+    if (!split_gemm_ok(t)) return false;
+    sg = t;
+    return true;
+}
+
 // kinds 0 conv3, 1 ResnetBlock, 2 AttnBlock, 3 upsample conv, 5 Downsample conv (shared by Decoder.forward and Encoder.forward)
 static int s1_layer(S1Ctx& c, const DecLayer& l) {
     hqt_handle* h = c.h;
@@ -1561,6 +1572,7 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
             sg.M = hw; sg.N = hw; sg.K = C; sg.batch = n; sg.alpha = 1.0f / sqrtf((float)C); sg.store = STORE_ROWS;
             sg.zero_page = h->zero_page;          // lets the LDS-DMA kernel take the batched product
             if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
+            else if (s1_split_product(h, md, sg)) HIPCHK(launch_split_gemm(sg, st));
             else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
         }
         { Timed t(h, "softmax", st); HIPCHK(launch_softmax_rows(h->as, adt, n * hw, hw, st)); }
@@ -1573,6 +1585,7 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
             sg.M = hw; sg.N = C; sg.K = hw; sg.batch = n; sg.alpha = 1.0f; sg.store = STORE_ROWS;
             sg.zero_page = h->zero_page;
             if (md.fast && mfma_gemm_ok(sg, adt, adt, adt)) HIPCHK(launch_mfma_gemm(sg, adt, adt, adt, st));
+            else if (s1_split_product(h, md, sg)) HIPCHK(launch_split_gemm(sg, st));
             else HIPCHK(launch_gemm_generic(sg, adt, adt, adt, st));
         }
         g = conv_args(h->ao, n, res, C, 1, 0, t1, C);

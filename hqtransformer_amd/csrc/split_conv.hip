@@ -495,12 +495,13 @@ hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st) {
 // operands (two planes each) staged through registers into two LDS stages (64 KiB, two workgroups per CU), 4 waves x (64 x 64).
 // A rows are [m][hi K | lo K] (lda elements per row, lo at +a_lo_off) or, AF32, the fp32 tensor itself ([m][K], lda floats):
 // the hi / lo split (range-checked like the operand pass) then happens between the load and the LDS write, and the separate
-// 8-byte-per-element operand pass in front of a nin_shortcut / proj_out disappears.  Same source-side bank swizzle as conv_glds_kernel.
+// 8-byte-per-element operand pass in front of a nin_shortcut / proj_out disappears.  BF32: the same for the B operand (the decoder
+// attention's q k^T and softmax v products: both operands are activations).  Same source-side bank swizzle as conv_glds_kernel.
 // The loads run TWO k-tiles ahead of the MFMAs (two register slots; round 2 had one: a k-tile is 768 matrix cycles, a third of
 // a memory round trip, and the 16 k-tiles of a 512-channel 1x1 conv each waited for theirs: 23 % of the matrix peak).  Loads are
 // unconditional (clamped k-tile) so that the loop body is one basic block and the compiler's counted waits stay exact.
 // ---------------------------------------------------------------------------------------------
-template <bool AF32>
+template <bool AF32, bool BF32>
 __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo_off) {
     constexpr int BM = 128, BN = 128, BKG = 32, ROWB = 64, OPB = 128 * ROWB;        // 32-wide k-tiles: 64 KiB of LDS, two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];                   // [2 stages][A hi, A lo, B hi, B lo][128 rows of 64 B]
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
     const float* Abase32 = reinterpret_cast<const float*>(g.A) + (long long)bz * g.a_batch_stride;
     const half_t* Bhi = reinterpret_cast<const half_t*>(g.Bw) + (long long)bz * g.b_batch_stride;
     const half_t* Blo = reinterpret_cast<const half_t*>(g.Bw_lo) + (long long)bz * g.b_batch_stride;
+    const float* Bbase32 = reinterpret_cast<const float*>(g.Bw) + (long long)bz * g.b_batch_stride;     // BF32: B is an fp32 tensor too ([n][K], ldb floats)
     const half_t* zero = reinterpret_cast<const half_t*>(g.zero_page);
     // a 1-KiB piece = 16 rows x 4 chunks of 16 B; chunk c of row r lives at position c ^ ((r >> 2) & 3): the 16 rows a ds_read_b128
     // lane group covers (lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) then fall on 16 different 16-B slots of the 256-B LDS row
@@ -540,8 +542,14 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                 sl[i][0] = *reinterpret_cast<const u32x4*>(aoff[i] >= 0 ? Abase + aoff[i] + k0 : zero);
                 sl[i][1] = *reinterpret_cast<const u32x4*>(aoff[i] >= 0 ? Abase + aoff[i] + a_lo_off + k0 : zero);
             }
-            sl[i][2] = *reinterpret_cast<const u32x4*>(boff[i] >= 0 ? Bhi + boff[i] + k0 : zero);
-            sl[i][3] = *reinterpret_cast<const u32x4*>(boff[i] >= 0 ? Blo + boff[i] + k0 : zero);
+            if (BF32) {
+                const float* sb = boff[i] >= 0 ? Bbase32 + boff[i] + k0 : reinterpret_cast<const float*>(zero);
+                sl[i][2] = *reinterpret_cast<const u32x4*>(sb);
+                sl[i][3] = *reinterpret_cast<const u32x4*>(sb + 4);
+            } else {
+                sl[i][2] = *reinterpret_cast<const u32x4*>(boff[i] >= 0 ? Bhi + boff[i] + k0 : zero);
+                sl[i][3] = *reinterpret_cast<const u32x4*>(boff[i] >= 0 ? Blo + boff[i] + k0 : zero);
+            }
         }
     };
     bool bad = false;
@@ -564,8 +572,21 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                 *reinterpret_cast<u32x4*>(at) = sl[i][0];
                 *reinterpret_cast<u32x4*>(at + OPB) = sl[i][1];
             }
-            *reinterpret_cast<u32x4*>(at + 2 * OPB) = sl[i][2];
-            *reinterpret_cast<u32x4*>(at + 3 * OPB) = sl[i][3];
+            if (BF32) {
+                half_t hi[8], lo[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned bits = sl[i][2 + (e >> 2)][e & 3];
+                    split2_checked(__builtin_bit_cast(float, bits), hi[e], lo[e], bad);
+                }
+                const u32x4 vh = {pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])};
+                const u32x4 vl = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])};
+                *reinterpret_cast<u32x4*>(at + 2 * OPB) = vh;
+                *reinterpret_cast<u32x4*>(at + 3 * OPB) = vl;
+            } else {
+                *reinterpret_cast<u32x4*>(at + 2 * OPB) = sl[i][2];
+                *reinterpret_cast<u32x4*>(at + 3 * OPB) = sl[i][3];
+            }
         }
     };
     f32x16 accm[2][2], accx[2][2];
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         stash(0, stg[0]);                               // k-tile kt + 2 (past the end: a clamped duplicate nobody reads)
         __syncthreads();
     }
-    if (AF32 && bad && g.range_flag) atomicOr(g.range_flag, 1);
+    if ((AF32 || BF32) && bad && g.range_flag) atomicOr(g.range_flag, 1);
     // epilogue: a lane owns 4 consecutive columns of one row per register quad
     float* Cb = reinterpret_cast<float*>(g.C) + (long long)bz * g.c_batch_stride;
     const float* Rb = g.resid ? reinterpret_cast<const float*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
@@ -678,10 +699,11 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
 }
 
 bool split_gemm_ok(const GemmArgs& g) {
-    if (!g.zero_page || !g.Bw_lo || g.gn_stats || g.a_packed_mb || g.a_rows_per_group) return false;
+    if (!g.zero_page || (!g.Bw_lo && !g.b_f32) || g.gn_stats || g.a_packed_mb || g.a_rows_per_group) return false;
     if (g.conv_taps > 1 || g.conv_stride2 || g.upsample) return false;
     if (g.K % 64 != 0 || g.ldb % 8 != 0) return false;
     if (g.a_f32 && (g.conv_taps ? g.Cin : g.lda) % 4 != 0) return false;
+    if (g.b_f32 && (!g.a_f32 || g.ldb % 4 != 0)) return false;
     if (g.store != STORE_ROWS && g.store != STORE_NCHW) return false;
     if (g.store == STORE_ROWS && g.rows_per_group != 0) return false;
     if (g.store == STORE_NCHW && (g.resid || g.act != ACT_NONE)) return false;
@@ -692,8 +714,9 @@ hipError_t launch_split_gemm(const GemmArgs& g0, hipStream_t st) {
     if (g.conv_taps == 1) { g.lda = g.a_f32 ? g.Cin : 2 * g.Cin; g.conv_taps = 0; }   // a 1x1 conv over [pixel][hi C | lo C] (or [pixel][C] fp32) is a plain GEMM
     const int a_lo_off = g.lda / 2;
     const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
-    if (g.a_f32) split_gemm_kernel<true><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
-    else split_gemm_kernel<false><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
+    if (g.a_f32 && g.b_f32) split_gemm_kernel<true, true><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
+    else if (g.a_f32) split_gemm_kernel<true, false><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
+    else split_gemm_kernel<false, false><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
     return hipGetLastError();
 }
 
@@ -704,7 +727,9 @@ hipError_t split_kernels_configure() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_kernel<true, 32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, split_conv3_lds(32));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64);
 }
