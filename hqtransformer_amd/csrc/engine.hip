@@ -343,8 +343,8 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
         const int hs = c.embed_dim / c.n_heads;
         if (hs % 8 || hs > 256 || (hs & (hs - 1))) return fail(HQT_ERR_INVALID, "head_dim %d unsupported (power of two in [8, 256])", hs);
         if (c.vocab_top != c.vocab_bot) return fail(HQT_ERR_INVALID, "vocab_top != vocab_bot");
-        if (c.depth_decoding < 0 || c.depth_decoding > HQT_DEPTH_PARALLEL_REDUCE || (c.depth_decoding && c.code_levels != 3))
-            return fail(HQT_ERR_INVALID, "depth_decoding %d: 0 'parallel-add', 1 'parallel', 2 'parallel-reduce' (three code levels only)", c.depth_decoding);
+        if (c.depth_decoding < 0 || c.depth_decoding > HQT_DEPTH_TOP2MID2BOT || (c.depth_decoding && c.code_levels != 3))
+            return fail(HQT_ERR_INVALID, "depth_decoding %d: 0 'parallel-add', 1 'parallel', 2 'parallel-reduce', 3 'top2mid2bot' (three code levels only)", c.depth_decoding);
         if (c.vocab_top > HQT_MAX_V || c.vocab_top % 4) return fail(HQT_ERR_INVALID, "vocab size %d unsupported", c.vocab_top);
         if (c.cond_type == HQT_COND_CLASS && c.n_classes < 1) return fail(HQT_ERR_INVALID, "n_classes");
         if (c.max_steps < 1 || c.max_steps > c.ctx_len_img) return fail(HQT_ERR_INVALID, "max_steps must be in [1, ctx_len_img]");
@@ -751,12 +751,15 @@ static int finalize_impl(hqt_handle* h) {
         if (c.embedding_type == HQT_EMB_TRANSFORMER1) CHK(get_w(h, "stage2.pos_emb_emb.weight", {l3 ? 21 : 5, D}, &t));
         CHK(get_w(h, "stage2.pos_emb_top.weight", {c.ctx_len_img, D}, &t));
         const int dmul = (l3 && c.depth_decoding == HQT_DEPTH_PARALLEL_REDUCE) ? 4 : 1;      // 'reduce': [V, 4 D] depth tables (hqtransformer.py:108-116)
-        CHK(get_w(h, key2(h, "tok_emb_top_depth.weight"), {c.vocab_top, dmul * D}, &t));
-        CHK(get_w(h, key2(h, "pos_emb_depth.weight"), {l3 ? 4 : 5, D}, &t));
+        const bool causal_head = l3 && c.depth_decoding == HQT_DEPTH_TOP2MID2BOT;            // its sub-step inputs come from tok_emb_levels (hqtransformer.py:718-725)
+        if (!causal_head) CHK(get_w(h, key2(h, "tok_emb_top_depth.weight"), {c.vocab_top, dmul * D}, &t));
+        CHK(get_w(h, key2(h, "pos_emb_depth.weight"), {causal_head ? 21 : (l3 ? 4 : 5), D}, &t));
         if (l3) {
             CHK(get_w(h, "stage2.tok_emb_levels.2.weight", {c.vocab_top, D}, &t));
-            CHK(get_w(h, "stage2.tok_emb_depth_levels.1.weight", {c.vocab_top, dmul * D}, &t));
-            CHK(get_w(h, "stage2.pos_emb_depths.1.weight", {16, D}, &t));
+            if (!causal_head) {
+                CHK(get_w(h, "stage2.tok_emb_depth_levels.1.weight", {c.vocab_top, dmul * D}, &t));
+                CHK(get_w(h, "stage2.pos_emb_depths.1.weight", {16, D}, &t));
+            }
             CHK(get_w(h, "stage2.ln_levels.2.weight", {D}, &t)); CHK(get_w(h, "stage2.ln_levels.2.bias", {D}, &t));
         }
         {
@@ -1174,20 +1177,37 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
     }
     const Lin* heads[3] = {&h->head_top, &h->head_bot, &h->head_l2};
     const char* ln_names[3][2] = {{"ln_top.weight", "ln_top.bias"}, {"ln_bot.weight", "ln_bot.bias"}, {"ln_levels.2.weight", "ln_levels.2.bias"}};
-    const int Tqs[3] = {1, 4, 16}, tbase[3] = {0, 1, 5}, draw0[3] = {0, 1, 5};
     const int dmul = cf.depth_decoding == HQT_DEPTH_PARALLEL_REDUCE ? 4 : 1;
+    // 'top2mid2bot' (hqtransformer.py:700-800): 21 causal sub-steps of ONE token -- sub-step cnt >= 1 is fed the code drawn by cnt - 1
+    // through tok_emb_levels[cnt == 1 ? 0 : (cnt < 5 ? 1 : 2)] (:718-723: the table follows the sub-step being computed, so the last middle
+    // code is embedded with the level-2 table, as there) + pos_emb_depths.0[cnt - 1]; head of level (cnt == 0 ? 0 : cnt < 5 ? 1 : 2)
+    const bool causal_head = cf.depth_decoding == HQT_DEPTH_TOP2MID2BOT;
+    const int nsub = causal_head ? 21 : 3;
     int64_t* outs[3] = {c.out_top, c.out_bot, c.out_l2};
+    const int64_t* feeds[3] = {c.feed_top, c.feed_bot, c.feed_l2};
     const size_t dkv_layer = (size_t)cf.max_batch * 21 * D * esz;
-    for (int lv = 0; lv < 3; ++lv) {
-        const int Tq = Tqs[lv], M = B * Tq;
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int lv = causal_head ? (sub == 0 ? 0 : (sub < 5 ? 1 : 2)) : sub;
+        const int Tq = causal_head ? 1 : (lv == 0 ? 1 : (lv == 1 ? 4 : 16));
+        const int tbase = causal_head ? sub : (lv == 0 ? 0 : (lv == 1 ? 1 : 5));
+        const int draw0 = tbase;
+        const int M = B * Tq;
         const bool dln = dln_ok(h, c, h->depth[0], M) && heads[lv]->wpk_ln;
         const int pk = (c.md.fast && M <= PACKED_MAX_ROWS && heads[lv]->wpk) ? packed_mb(M) : 0;
-        if (lv == 0) {            // ln_f on the last token of each sample, + sos_depth -> depth input of level 0
+        if (sub == 0) {           // ln_f on the last token of each sample, + sos_depth -> depth input of level 0
             Timed t(h, "layernorm", c.st);
             LNArgs ln{h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, 1e-5f, DT_F32, 0,
                       h->pend.slabs, h->pend.S, h->pend.rows, h->pend.bias, dln ? h->xdpk : nullptr, dln ? packed_mb(B) : 0, h->partsd};
             h->pend.slabs = nullptr; h->pend.S = 0;
             HIPCHK(launch_layernorm(ln, c.st));
+        } else if (causal_head) { // the previous sub-step's code, embedded by the spatial tables, + its position in the 21-token sequence
+            Timed t(h, "embed", c.st);
+            const int prev = sub - 1, plv = prev == 0 ? 0 : (prev < 5 ? 1 : 2);
+            const int tbl = sub == 1 ? 0 : (sub < 5 ? 1 : 2);
+            const float* tok = tbl == 0 ? W(h, "tok_emb_top.weight") : (tbl == 1 ? W(h, "tok_emb_bot.weight") : h->w["stage2.tok_emb_levels.2.weight"].d);
+            HIPCHK(launch_depth_embed_causal(feeds[plv], plv == 0 ? 1 : (plv == 1 ? 4 : 16), plv == 0 ? 0 : (plv == 1 ? prev - 1 : prev - 5), c.o.n_steps,
+                                             h->state, tok, W(h, "pos_emb_depth.weight") + (size_t)prev * D, h->xd, B, D,
+                                             dln ? h->xdpk : nullptr, dln ? packed_mb(M) : 0, h->partsd, c.st, V));
         } else if (lv == 1) {     // emb(top code) + positions 0..3
             Timed t(h, "embed", c.st);
             HIPCHK(launch_depth_embed(c.feed_top, c.o.n_steps, h->state, W(h, "tok_emb_top_depth.weight"), W(h, "pos_emb_depth.weight"),
@@ -1203,8 +1223,8 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
         for (int l = 0; l < cf.n_layers_depth; ++l) {
             void* kc = (char*)h->dk + l * dkv_layer;
             void* vc = (char*)h->dv + l * dkv_layer;
-            if (dln) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, Tq, kc, vc, 21, tbase[lv], nullptr, 0));
-            else CHK(run_block(h, c, h->depth[l], h->xd, Tq, kc, vc, 21, tbase[lv], nullptr, 0));
+            if (dln) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, Tq, kc, vc, 21, tbase, nullptr, 0));
+            else CHK(run_block(h, c, h->depth[l], h->xd, Tq, kc, vc, 21, tbase, nullptr, 0));
         }
         GemmArgs g{};
         if (dln) {                // ln_levels[lv] folded into head_levels[lv]
@@ -1219,8 +1239,9 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
         CHK(run_linear(h, c.md, g, *heads[lv], adt, DT_F32, c.st, "gemm_head"));
         {
             Timed t(h, "sampler", c.st);
-            SamplerArgs sa{h->logits, M, V, Tq, B, c.temperature[lv], c.top_k[lv], c.top_p[lv], c.noise, draw0[lv],
+            SamplerArgs sa{h->logits, M, V, Tq, B, c.temperature[lv], c.top_k[lv], c.top_p[lv], c.noise, draw0,
                            h->state, h->rows, c.o.n_steps, outs[lv], c.logits_out, 21};
+            if (causal_head && lv > 0) { sa.out_stride = lv == 1 ? 4 : 16; sa.out_slot = lv == 1 ? sub - 1 : sub - 5; }
             sa.fast_math = c.md.fast ? 1 : 0;
             HIPCHK(launch_sampler(sa, c.st));
         }

@@ -105,6 +105,8 @@ struct SamplerArgs {
     bf16_t* emb_xpk;             // optional packed copy (packed_off layout with emb_pk_mb row blocks)
     int emb_pk_mb;
     float* emb_parts;            // [4 B][2]
+    int out_stride, out_slot;    // out_stride > 0: the drawn code goes to out[(b * n_steps + step) * out_stride + out_slot] (slots == 1: one sub-step of the
+                                 // 21-step causal head writes ONE slot of a 4- or 16-wide code group)
     int fast_math;               // FAST-precision calls: v_exp / v_log / v_rcp forms of exp, log and the divisions (1-2 ulp each; EXACT keeps the IEEE forms: its draws are the parity gate, compared bit for bit)
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
@@ -114,6 +116,9 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);
 hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, int n_steps, const StepState* state, const float* tok0,
                                  const float* tok1, const float* pos, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts,
                                  hipStream_t st, int V = 0, int tok1_ld = 0);
+// 'top2mid2bot' head (hqtransformer.py:700-735): input of causal sub-step cnt >= 1 = tok[codes[(b * n_steps + step) * stride + slot]] + pos_row
+hipError_t launch_depth_embed_causal(const int64_t* codes, int stride, int slot, int n_steps, const StepState* state, const float* tok,
+                                     const float* pos_row, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st, int V);
 // raises the dynamic-LDS limit of the sampler for (V, top-p) outside any stream capture
 hipError_t sampler_configure(int V, bool use_top_p);
 

@@ -174,6 +174,21 @@ hipError_t launch_depth_embed_l2(const int64_t* codes0, const int64_t* codes1, i
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void depth_embed_causal_kernel(const int64_t* codes, int stride, int slot, int n_steps, const StepState* state,
+                                                                 const float* tok, const float* pos_row, float* x, int D, bf16_t* xpk,
+                                                                 int pk_mb, float* parts, int V) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const long long code = clamp_idx(codes[((long long)b * n_steps + state->step) * stride + slot], V);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) x[(long long)b * D + d] = tok[code * D + d] + pos_row[d];
+    if (xpk) { __syncthreads(); emit_packed_row(x + (long long)b * D, b, D, xpk, pk_mb, parts, red); }
+}
+hipError_t launch_depth_embed_causal(const int64_t* codes, int stride, int slot, int n_steps, const StepState* state, const float* tok,
+                                     const float* pos_row, float* x, int B, int D, bf16_t* xpk, int pk_mb, float* parts, hipStream_t st, int V) {
+    depth_embed_causal_kernel<<<B, 256, 0, st>>>(codes, stride, slot, n_steps, state, tok, pos_row, x, D, xpk, pk_mb, parts, V);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-5), two-pass, one workgroup per row
 // ---------------------------------------------------------------------------------------------
@@ -1230,7 +1245,7 @@ __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {
     if (tid == 0) {
         for (int w = 1; w < NT / 64; ++w)
             if (redf[w] > best || (redf[w] == best && redi[w] < besti)) { best = redf[w]; besti = redi[w]; }
-        a.out[((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
+        a.out[a.out_stride > 0 ? ((long long)b * a.n_steps + step) * a.out_stride + a.out_slot : ((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
         if (a.emb_tok) sel[0] = a.emb_feed ? (int)clamp_idx(a.emb_feed[((long long)b * a.n_steps + step) * a.slots + slot], a.V) : besti;
     }
     if (!a.emb_tok) return;                              // workgroup-uniform
@@ -1342,7 +1357,7 @@ __global__ __launch_bounds__(256) void sampler_plain_fast_kernel(SamplerArgs a) 
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
             if (redf[w] > best || (redf[w] == best && redi[w] < besti)) { best = redf[w]; besti = redi[w]; }
-        a.out[((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
+        a.out[a.out_stride > 0 ? ((long long)b * a.n_steps + step) * a.out_stride + a.out_slot : ((long long)b * a.n_steps + step) * a.slots + slot] = (int64_t)besti;
         if (a.emb_tok) redi[0] = a.emb_feed ? (int)clamp_idx(a.emb_feed[((long long)b * a.n_steps + step) * a.slots + slot], a.V) : besti;
     }
     if (!a.emb_tok) return;                              // workgroup-uniform

@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 COND_NONE, COND_CLS, COND_TXT = 0, 1, 2
 EMB_TRANSFORMER1, EMB_REDUCE = 0, 1
 # HQTransformer.decoding_type values whose three-level SAMPLING works in the reference and is built here (index = hqt_config.depth_decoding)
-DEPTH_DECODINGS = ('parallel-add', 'parallel', 'parallel-reduce')
+DEPTH_DECODINGS = ('parallel-add', 'parallel', 'parallel-reduce', 'top2mid2bot')
 
 
 @dataclass
@@ -81,8 +81,8 @@ def stage2_spec_from_config(cfg) -> Stage2Spec:
             raise NotImplementedError('multilevel-hq: three levels with one vocabulary size are built')
         if s2.decoding_type not in DEPTH_DECODINGS:
             raise NotImplementedError(f"decoding_type '{s2.decoding_type}': {', '.join(DEPTH_DECODINGS)} are built ('parallel-add' is the released "
-                                      "level-3 config; 'top2mid2bot' is a 21-step causal head; 'tree', 'old-parallel' and "
-                                      "'parallel-add-reduce' cannot sample three levels in the reference either: hqtransformer.py:537-549)")
+                                      "level-3 config; 'tree', 'old-parallel' and 'parallel-add-reduce' cannot sample three levels in the "
+                                      "reference either: hqtransformer.py:537-549)")
         levels = 3
     elif 'hq-transformer' not in s2.type:
         raise ValueError(f"stage2.type '{s2.type}' is not on the HQ-Transformer sampling path")
@@ -179,8 +179,11 @@ def stage2_param_shapes(s: Stage2Spec) -> 'OrderedDict[str, Tuple[int, ...]]':
         for li in range(3):                 # 'reduce': one D-slice of a wider row per child position (hqtransformer.py:108-116)
             mult = (16 if li == 2 else 4) if 'reduce' in s.depth_decoding else 1
             out[f'tok_emb_depth_levels.{li}.weight'] = (s.vocab_top, mult * D)
-        out['pos_emb_depths.0.weight'] = (4, D)
-        out['pos_emb_depths.1.weight'] = (16, D)
+        if s.depth_decoding == 'top2mid2bot':   # one table over the 21-token causal sequence (hqtransformer.py:131-135)
+            out['pos_emb_depths.0.weight'] = (1 + 4 + 16, D)
+        else:
+            out['pos_emb_depths.0.weight'] = (4, D)
+            out['pos_emb_depths.1.weight'] = (16, D)
         for j in range(s.n_layers_depth):
             _block_shapes(f'depths.{j}', D, out)
         for li in range(3):

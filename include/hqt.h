@@ -83,13 +83,15 @@ typedef struct {
     /* three levels only: HQTransformer.decoding_type (hqtransformer.py:105-157: tables of the depth head; :526-551: what the
      * depth sub-steps are fed).  0 'parallel-add' (the released level-3 config), 1 'parallel' (level-2 tokens without the top
      * code's embedding), 2 'parallel-reduce' (tok_emb_depth_levels.{0,1} are [V, 4 D]: child position c of a code takes slice c).
-     * The other values of the reference ('tree', 'old-parallel', 'parallel-add-reduce') cannot sample three levels there either;
-     * 'top2mid2bot' (a causal head of 21 sequential sub-steps) is not built. */
+     * 3 'top2mid2bot': a causal head of 21 sequential one-token sub-steps (hqtransformer.py:700-800; pos_emb_depths.0 is [21, D],
+     * the sub-step inputs come from tok_emb_levels).  The other values of the reference ('tree', 'old-parallel',
+     * 'parallel-add-reduce') cannot sample three levels there either. */
     int32_t depth_decoding;
 } hqt_config;
 #define HQT_DEPTH_PARALLEL_ADD 0
 #define HQT_DEPTH_PARALLEL 1
 #define HQT_DEPTH_PARALLEL_REDUCE 2
+#define HQT_DEPTH_TOP2MID2BOT 3
 
 /* Sampling options = the keyword arguments of sampling_ihqgpt (hqvae/utils/sampling.py:164-177).
  * top_k <= 0 means None (no cut-off), top_p <= 0 means None. */

@@ -263,6 +263,26 @@ class OracleStage2L3(OracleStage2):
                     xd = self._block(f'depths.{j}', xd, dcache, causal_new=False)
                 return linear(layer_norm(xd, w[f'ln_levels.{level}.weight'], w[f'ln_levels.{level}.bias']), w[f'head_levels.{level}.weight'])
 
+            if getattr(s, 'depth_decoding', 'parallel-add') == 'top2mid2bot':
+                # sampling_depth_causal (hqtransformer.py:700-800): 21 causal sub-steps of one token.  Sub-step cnt >= 1 is fed the code of
+                # cnt - 1 through tok_emb_levels[0 if cnt == 1 else 1 if cnt < 5 else 2] (:718-723 -- the table follows the sub-step being
+                # computed) + pos_emb_depths.0[cnt - 1]; head / sampler settings of level 0 (cnt 0), 1 (cnt 1..4), 2 (cnt 5..20)
+                seq = np.zeros((B, 21), np.int64)
+                fseq = (np.concatenate([force[0][:, cnt, None], force[1][:, cnt], force[2][:, cnt]], axis=1) if force is not None else None)
+                for sub in range(21):
+                    lv = 0 if sub == 0 else (1 if sub < 5 else 2)
+                    if sub == 0:
+                        xd = (hs + w['sos_depth']).astype(F32)
+                    else:
+                        tbl = 0 if sub == 1 else (1 if sub < 5 else 2)
+                        prev = (fseq if fseq is not None else seq)[:, sub - 1]
+                        xd = (w[f'tok_emb_levels.{tbl}.weight'][prev] + w['pos_emb_depths.0.weight'][sub - 1])[:, None, :].astype(F32)
+                    lg = depth(xd, lv)[:, 0]
+                    seq[:, sub], _ = sample_filtered(lg, noise[cnt, sub], temperature[lv], top_k[lv], top_p[lv])
+                    if return_logits:
+                        logits_out[cnt, sub] = lg
+                c0[:, cnt], c1[:, cnt], c2[:, cnt] = seq[:, 0], seq[:, 1:5], seq[:, 5:21]
+                continue
             # level 0 (hqtransformer.py:518-524)
             l0 = depth((hs + w['sos_depth']).astype(F32), 0)[:, 0]
             d0, _ = sample_filtered(l0, noise[cnt, 0], temperature[0], top_k[0], top_p[0])

@@ -478,9 +478,10 @@ def test_l3_sampling_vs_reference_fixture_and_oracle():
         gate(f'l3_tiny.fast_logits(graph={graph})', err, 0.12)
 
 
-@pytest.mark.parametrize('name', ['g7_l3_tiny_cls_parallel.npz', 'g7_l3_tiny_cls_parallel_reduce.npz'])
+@pytest.mark.parametrize('name', ['g7_l3_tiny_cls_parallel.npz', 'g7_l3_tiny_cls_parallel_reduce.npz', 'g7_l3_tiny_cls_top2mid2bot.npz'])
 def test_l3_other_decoding_types_vs_reference_fixture(name):
-    """hqt_config.depth_decoding 1 / 2: HQTransformer 'parallel' and 'parallel-reduce' (hqtransformer.py:105-157,526-551) through
+    """hqt_config.depth_decoding 1 / 2 / 3: HQTransformer 'parallel', 'parallel-reduce' (hqtransformer.py:105-157,526-551) and the causal
+    21-sub-step head 'top2mid2bot' (:700-800) through
     hqt_sample_l3 against fixtures G7b generated from the reference: EXACT codes bit-exact and logits <= 2e-4, eager and graph; FAST
     teacher-forced logits inside the gate of the 'parallel-add' test."""
     fx = load(name)

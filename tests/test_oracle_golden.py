@@ -176,10 +176,11 @@ def test_l3_sampling_bit_exact(si):
     assert float(fx[f'margin_{si}']) > 1.00005         # every draw is decided by a margin an fp32-accurate implementation resolves
 
 
-@pytest.mark.parametrize('name', ['g7_l3_tiny_cls_parallel.npz', 'g7_l3_tiny_cls_parallel_reduce.npz'])
+@pytest.mark.parametrize('name', ['g7_l3_tiny_cls_parallel.npz', 'g7_l3_tiny_cls_parallel_reduce.npz', 'g7_l3_tiny_cls_top2mid2bot.npz'])
 def test_l3_other_decoding_types_bit_exact(name):
-    """G7b: the two other HQTransformer.decoding_type values whose three-level sampling runs in the reference -- 'parallel' (level-2
-    tokens without the top code's embedding) and 'parallel-reduce' ([V, 4 D] depth tables, one D-slice per child position) --,
+    """G7b: the three other HQTransformer.decoding_type values whose three-level sampling runs in the reference -- 'parallel' (level-2
+    tokens without the top code's embedding), 'parallel-reduce' ([V, 4 D] depth tables, one D-slice per child position) and
+    'top2mid2bot' (a causal head of 21 one-token sub-steps fed through the spatial tables, hqtransformer.py:700-800) --,
     24 positions, B = 3, top-k / top-p / temperature per level (hqtransformer.py:105-157,526-551)."""
     from hqtransformer_amd.spec import DEPTH_DECODINGS, Stage2Spec
     from oracle.hqt_oracle import OracleStage2L3

@@ -2,12 +2,12 @@
 """Fixtures G7/G8: the three-level path of the reference.
 
 Container-only, like tools/gen_golden.py (whose import shims it reuses): builds the reference's ``HQTransformer``
-('parallel-add' -- and, for G7b, 'parallel' and 'parallel-reduce' --, transformer1 embedding) and ``HQVAEGenerator`` (code_levels = 3) with weights derived from
+('parallel-add' -- and, for G7b, 'parallel', 'parallel-reduce' and 'top2mid2bot' --, transformer1 embedding) and ``HQVAEGenerator`` (code_levels = 3) with weights derived from
 numpy.default_rng by state-dict name (hqtransformer_amd/synth.py, 'fixture' profile), runs ``sampling_hqtransformer`` with
 torch.multinomial replaced by argmax(p / q) on external Exp(1) noise, and ``decode_code([t, m, b])``; stores only inputs
 and outputs:
   tests/golden/g7_l3_tiny_cls.npz   codes of all three levels for 64 positions, B = 3, two sampler settings, logits of 4 positions
-  tests/golden/g7_l3_tiny_cls_parallel.npz, g7_l3_tiny_cls_parallel_reduce.npz   the same for the two other decoding types, 24 positions
+  tests/golden/g7_l3_tiny_cls_parallel.npz, g7_l3_tiny_cls_parallel_reduce.npz, g7_l3_tiny_cls_top2mid2bot.npz   the same for the three other decoding types, 24 positions
   tests/golden/g8_l3_decode.npz     3-level decode_code pixels (all levels; top only; bottom only) on a 64-pixel decoder
 """
 import json
@@ -124,7 +124,7 @@ def main():
     print('g7_l3_tiny_cls ok', os.path.getsize(os.path.join(G.OUT, 'g7_l3_tiny_cls.npz')), 'bytes')
 
     # ---------------------------------------------------------------- G7b: the other decoding types whose three-level sampling runs in the reference
-    for dd in ('parallel', 'parallel-reduce'):
+    for dd in ('parallel', 'parallel-reduce', 'top2mid2bot'):
         vspec = Stage2Spec(embed_dim=128, n_layers=2, n_heads=4, n_layers_depth=2, vocab_top=512, vocab_bot=512, vocab_txt=64,
                            ctx_len_img=64, ctx_len_txt=16, n_classes=10, cond=1, embedding=0, levels=3, depth_decoding=dd)
         vmodel, vshapes = build_stage2_l3(vspec, 71)
