@@ -158,6 +158,18 @@ def pmc_traffic(family):
         return None
 
 
+def default_schedule(steps, merge=None, inflight=None, wide=False):
+    """(lanes, steps per pass) of the timed region.  Neither given (class-conditional two-level workload): the K timed steps are split over
+    2 lanes in passes of up to 32 steps -- larger passes stream the AR weights less often per image (85.5 ms of AR per 64
+    images in 64-row passes, 13.3 in 2048-row passes), 32 bounds the latency of a step and the KV cache of a lane, and two passes must exist
+    for the lanes to overlap anything.  The text and three-level workloads (`wide`: a 64-token prefill / 16-fold depth rows per step) take
+    3 lanes and passes of up to 16 steps (measured: 8 x 3 1308 / 811, 16 x 3 1346 / 837, 24 x 2 1328 / 727 images/s).  A flag that is given
+    is kept; the other one then takes round 2's default (8 steps per pass, 3 lanes)."""
+    if merge is None and inflight is None:
+        return (3, min(16, max(1, (steps + 2) // 3))) if wide else (2, min(32, max(1, (steps + 1) // 2)))
+    return max(1, inflight if inflight is not None else 3), max(1, merge if merge is not None else 8)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -279,11 +291,7 @@ def main():
     # ---- the timed region: K steps, round-robined over `inflight` lanes (hqtransformer_amd/pipeline.py).  Every step is
     #      one complete batch-B pass (64-position AR loop + decode + clamp [+ gather]); lanes only change the schedule.
     from hqtransformer_amd.pipeline import InflightSampler
-    if args.merge is None and args.inflight is None and not txt_cond and not three:
-        inflight, merge = 2, min(32, max(1, (args.steps + 1) // 2))
-    else:
-        inflight = max(1, args.inflight if args.inflight is not None else 3)
-        merge = max(1, args.merge if args.merge is not None else 8)
+    inflight, merge = default_schedule(args.steps, args.merge, args.inflight, txt_cond or three)
     if args.positions:
         merge = 1                                  # debug runs (counter collection) sample a few positions of one pass
     rem = args.steps % merge                       # K need not be a multiple: the last pass of the timed region then holds `rem` steps
@@ -390,8 +398,9 @@ def main():
                                    f'batch {B}/GPU, {n_pos} top positions, ' + (f'top_k={tk}, top_p={tp}, T={T} (quality-mode sampler)' if quality else 'top_k=top_p=None, T=[1,1]'),
                        'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
                        # the schedule, in numbers: a device pass executes `merge` steps at once, `inflight` passes are resident per GPU
-                       'schedule': ('chosen from K: the timed steps are split over 2 lanes in passes of up to 32 steps (merge = min(32, ceil(K / 2)))'
-                                    if (args.merge is None and args.inflight is None and not txt_cond and not three) else 'as given (--merge / --inflight; defaults 8 / 3)'),
+                       'schedule': (('chosen from K: the timed steps are split over 3 lanes in passes of up to 16 steps (merge = min(16, ceil(K / 3)))' if (txt_cond or three) else
+                                     'chosen from K: the timed steps are split over 2 lanes in passes of up to 32 steps (merge = min(32, ceil(K / 2)))')
+                                    if (args.merge is None and args.inflight is None) else 'as given (--merge / --inflight; defaults 8 / 3)'),
                        'rows_per_pass': merge * B, 'images_in_flight_per_gpu': merge * B * inflight,
                        'step_latency_ms': round(1000 * elapsed / args.steps * merge * inflight, 1),
                        'step_latency_note': 'time from a step entering its pass to its pixels: one pass per lane, lanes share the GPU (ms_per_step x merge x lanes); '

@@ -47,3 +47,15 @@ def test_roofline_and_cpu_baseline_objects():
     cfg = d['config']
     if 'rows_per_pass' in cfg:                                        # the schedule in numbers (round 3 on)
         assert cfg['rows_per_pass'] % cfg['per_gpu_batch'] == 0 and cfg['images_in_flight_per_gpu'] % cfg['rows_per_pass'] == 0 and cfg['step_latency_ms'] > 0
+
+
+def test_default_schedule_rule():
+    """bench.py picks lanes and steps per pass from K when neither is given; explicit flags are kept."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ds = mod.default_schedule
+    assert ds(96) == (2, 32) and ds(20) == (2, 10) and ds(7) == (2, 4) and ds(1) == (2, 1) and ds(1000) == (2, 32)
+    assert ds(96, merge=8) == (3, 8) and ds(96, inflight=1) == (1, 8) and ds(96, 48, 2) == (2, 48)
+    assert ds(48, wide=True) == (3, 16) and ds(96, wide=True) == (3, 16) and ds(20, wide=True) == (3, 7) and ds(48, 8, None, True) == (3, 8)
