@@ -627,10 +627,17 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                 }
         }
     };
+#ifdef HQT_SPLIT_GEMM_STAMPS                            // tools/micro only: cycles of the prologue / main loop / epilogue of every workgroup's wave 0
+    long long st_[4];
+    st_[0] = clock64();
+#endif
     fetch(0, stg[0]);
     fetch(1, stg[1]);
     stash(0, stg[0]);
     __syncthreads();
+#ifdef HQT_SPLIT_GEMM_STAMPS
+    st_[1] = clock64();
+#endif
     for (int kt = 0; kt < KT; kt += 2) {                // KT is even (K % 64 == 0)
         fetch(kt + 2, stg[0]);                          // slot 0 went to LDS one k-tile ago; in flight under TWO k-tiles of MFMAs
         __builtin_amdgcn_sched_barrier(0);              // (without the fences hipcc sinks the loads below the LDS writes of the other slot)
@@ -646,20 +653,41 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         __syncthreads();
     }
     if ((AF32 || BF32) && bad && g.range_flag) atomicOr(g.range_flag, 1);
-    // epilogue: a lane owns 4 consecutive columns of one row per register quad
+#ifdef HQT_SPLIT_GEMM_STAMPS
+    st_[2] = clock64();
+#endif
+    // epilogue: a lane owns 4 consecutive columns of one row per register quad.  The bias of the tile's 128 columns goes through the
+    // (now dead) LDS stages: as one scalar load in front of every store, each a dependent L2 round trip, the epilogue took 32 k cycles
+    // of a workgroup's 80 k (tools/micro/bench_split_gemm, in-kernel stamps); 14-25 k since.
     float* Cb = reinterpret_cast<float*>(g.C) + (long long)bz * g.c_batch_stride;
     const float* Rb = g.resid ? reinterpret_cast<const float*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
     const bool plain = g.store == STORE_ROWS && g.rows_per_group == 0 && (g.N & 3) == 0 && (g.ldc & 3) == 0;
+    float* lbias = reinterpret_cast<float*>(lds_raw);
+    if (tid < BN) lbias[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.0f;     // every wave passed the loop's last barrier: the stages are free
+    __syncthreads();
+    // (Staging the tile through LDS for whole-row stores, as the 3x3 kernels do, measured SLOWER here: 46.6 vs 38.5 us for the 512-channel
+    // convs -- two more barriers and half the waves idle per half-tile cost more than the 32-byte store pieces.)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + fr;
         if (m >= g.M) continue;
+        f32x4 rv[2][4];
+        if (plain && Rb) {                                    // the residual quads of a row block are fetched together, before anything is stored
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int n4 = n0 + wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                    rv[j][q4] = *reinterpret_cast<const f32x4*>(Rb + (long long)m * g.ldc + min(n4, g.N - 4));
+                }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                const int n4 = n0 + wn * 64 + j * 32 + 8 * q4 + 4 * fh;
+                const int nl = wn * 64 + j * 32 + 8 * q4 + 4 * fh, n4 = n0 + nl;
                 if (n4 >= g.N) continue;
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(lbias + nl);
                 float s[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s[e] = accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV;
@@ -667,11 +695,10 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                     const long long idx = (long long)m * g.ldc + n4;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(s[e] * g.alpha + (g.bias ? g.bias[n4 + e] : 0.0f), g.act);
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(s[e] * g.alpha + bq[e], g.act);
                     if (Rb) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(Rb + idx);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                        for (int e = 0; e < 4; ++e) v[e] += rv[j][q4][e];
                     }
                     const f32x4 o = {v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(Cb + idx) = o;
@@ -680,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (n4 + e < g.N) {
-                            float x = s[e] * g.alpha + (g.bias ? g.bias[n4 + e] : 0.0f);
+                            float x = s[e] * g.alpha + bq[e];
                             if (g.clamp01) x = fminf(fmaxf(0.5f * x + 0.5f, 0.0f), 1.0f);
                             Cb[((long long)img * g.N + n4 + e) * g.rows_per_image + pix] = x;
                         }
@@ -689,13 +716,20 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                     for (int e = 0; e < 4; ++e)
                         if (n4 + e < g.N) {
                             const long long idx = (long long)m * g.ldc + n4 + e;
-                            float x = apply_act(s[e] * g.alpha + (g.bias ? g.bias[n4 + e] : 0.0f), g.act);
+                            float x = apply_act(s[e] * g.alpha + bq[e], g.act);
                             if (Rb) x += Rb[idx];
                             Cb[idx] = x;
                         }
                 }
             }
     }
+#ifdef HQT_SPLIT_GEMM_STAMPS
+    if (g.am_best && tid == 0) {
+        st_[3] = clock64();
+        long long* d = reinterpret_cast<long long*>(g.am_best) + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4;
+        d[0] = st_[1] - st_[0]; d[1] = st_[2] - st_[1]; d[2] = st_[3] - st_[2]; d[3] = wall_clock64();
+    }
+#endif
 }
 
 bool split_gemm_ok(const GemmArgs& g) {

@@ -1,10 +1,12 @@
 // Micro-benchmark: the SPLIT 1x1-conv / plain GEMM kernel (fp16 hi/lo operands, 3 MFMAs per term) on the HQ-VAE decoder's shapes at
 // batch 64: the attention blocks' q / k / v / proj (16384 x 512 x 512) and the two nin_shortcuts (262144 x 256 x 512, 1048576 x 128 x 256).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/micro/bench_split_gemm.hip -o tools/micro/bench_split_gemm
+#define HQT_SPLIT_GEMM_STAMPS 1
 #include "../../hqtransformer_amd/csrc/split_conv.hip"
 #include "../../hqtransformer_amd/csrc/split_stream_conv.hip"
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct Shape { const char* name; int M, N, K; };
@@ -50,6 +52,19 @@ int main(int argc, char** argv) {
         GemmArgs gf = g; gf.a_f32 = 1; gf.lda = s.K;                       // A = the fp32 tensor, split while it is staged
         const float tf = timed(gf, st, 5);
         printf("%-34s %8.1f | %8.1f %8.1f %8.3f | %8.1f %8.3f\n", s.name, fl * 1e-9, t, fl / t * 1e-6, fl / t * 1e-6 / 2500.0, tf, fl / tf * 1e-6 / 2500.0);
+        {   // in-kernel stamps of one launch (packed operand): median cycles of prologue / loop / epilogue, span of the grid in wall-clock ticks
+            const int nwg = ((s.N + 127) / 128) * ((s.M + 127) / 128);
+            long long* dbg; CK(hipMalloc(&dbg, (size_t)nwg * 32)); CK(hipMemset(dbg, 0, (size_t)nwg * 32));
+            GemmArgs gd = g; gd.am_best = reinterpret_cast<unsigned long long*>(dbg);
+            CK(launch_split_gemm(gd, st)); CK(hipStreamSynchronize(st));
+            std::vector<long long> h((size_t)nwg * 4); CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<long long> a(nwg), b(nwg), c(nwg); long long w0 = h[3], w1 = h[3];
+            for (int i = 0; i < nwg; ++i) { a[i] = h[4 * i]; b[i] = h[4 * i + 1]; c[i] = h[4 * i + 2]; w0 = std::min(w0, h[4 * i + 3]); w1 = std::max(w1, h[4 * i + 3]); }
+            std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); std::sort(c.begin(), c.end());
+            printf("      stamps (%d workgroups, %d k-tiles): prologue %lld  loop %lld (%.0f per k-tile)  epilogue %lld cycles (median); last - first workgroup end: %.2f us\n",
+                   nwg, s.K / 32, a[nwg / 2], b[nwg / 2], (double)b[nwg / 2] / (s.K / 32), c[nwg / 2], (w1 - w0) / 100.0);
+            CK(hipFree(dbg));
+        }
     }
     return 0;
 }
