@@ -665,22 +665,56 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
     float* lbias = reinterpret_cast<float*>(lds_raw);
     if (tid < BN) lbias[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.0f;     // every wave passed the loop's last barrier: the stages are free
     __syncthreads();
-    // (Staging the tile through LDS for whole-row stores, as the 3x3 kernels do, measured SLOWER here: 46.6 vs 38.5 us for the 512-channel
-    // convs -- two more barriers and half the waves idle per half-tile cost more than the 32-byte store pieces.)
+    if (plain) {
+        // Row-major stores straight from the accumulators leave as 32 rows x 32 B per instruction (a million 32-byte write requests per
+        // launch of the 512-channel convs).  As in tile_gemm.hip every wave transposes its own 64 x 64 block through a PRIVATE patch of the
+        // dead stages, 32 rows at a time -- no workgroup barrier -- and stores whole 256-byte row segments, 16 B per lane; the residual is
+        // read the same way, all passes in flight together.  (A workgroup-wide staging of 64 x 128 halves with barriers measured slower
+        // than the direct stores: 46.6 vs 38.5 us.)
+        constexpr int PITCH = 64 + 4;                     // floats; +4: the 8 lanes of a ds_write_b128 group land on 8 distinct 4-bank sets
+        float* const stg = reinterpret_cast<float*>(lds_raw) + BN + wave * (32 * PITCH);
+        static_assert((BN + 4 * 32 * PITCH) * 4 <= 2 * 4 * OPB, "bias + staging patches fit the operand stages");
+        const int cg = (lane & 15) * 4, r0 = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + fr;
-        if (m >= g.M) continue;
-        f32x4 rv[2][4];
-        if (plain && Rb) {                                    // the residual quads of a row block are fetched together, before anything is stored
+        for (int i = 0; i < 2; ++i) {
+            const int mrow0 = m0 + wm * 64 + i * 32, ncol0 = n0 + wn * 64;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const int n4 = n0 + wn * 64 + j * 32 + 8 * q4 + 4 * fh;
-                    rv[j][q4] = *reinterpret_cast<const f32x4*>(Rb + (long long)m * g.ldc + min(n4, g.N - 4));
+                    const int cl = j * 32 + 8 * q4 + 4 * fh;
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(lbias + wn * 64 + cl);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act((accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV) * g.alpha + bq[e], g.act);
+                    *reinterpret_cast<f32x4*>(stg + fr * PITCH + cl) = v;
                 }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the patch is exchanged between the lanes of this wave only
+            __builtin_amdgcn_wave_barrier();
+            f32x4 x0[8];
+            const bool col_ok = ncol0 + cg < g.N;                      // N % 4 == 0
+            if (Rb) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int m = min(mrow0 + p * 4 + r0, g.M - 1);
+                    x0[p] = *reinterpret_cast<const f32x4*>(Rb + (long long)m * g.ldc + min(ncol0 + cg, g.N - 4));
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int r = p * 4 + r0, m = mrow0 + r;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * PITCH + cg);
+                if (Rb) v += x0[p];
+                if (m < g.M && col_ok) *reinterpret_cast<f32x4*>(Cb + (long long)m * g.ldc + ncol0 + cg) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();                           // the patch is rewritten by the next row block
         }
+    } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + fr;
+        if (m >= g.M) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -691,18 +725,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                 float s[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s[e] = accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV;
-                if (plain) {
-                    const long long idx = (long long)m * g.ldc + n4;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(s[e] * g.alpha + bq[e], g.act);
-                    if (Rb) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[j][q4][e];
-                    }
-                    const f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(Cb + idx) = o;
-                } else if (g.store == STORE_NCHW) {         // per-image transposed store (V^T of the decoder attention: layers.py:180-183)
+                if (g.store == STORE_NCHW) {                // per-image transposed store (V^T of the decoder attention: layers.py:180-183): 32 lanes = 32 consecutive pixels
                     const int img = m / g.rows_per_image, pix = m - img * g.rows_per_image;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -722,6 +745,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                         }
                 }
             }
+    }
     }
 #ifdef HQT_SPLIT_GEMM_STAMPS
     if (g.am_best && tid == 0) {
