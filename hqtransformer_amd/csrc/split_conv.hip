@@ -25,6 +25,26 @@ __device__ __forceinline__ void split2_checked(float x, half_t& hi, half_t& lo, 
     if (!(fabsf(x) < 65504.0f)) { bad = true; x = x > 0.0f ? 65472.0f : (x < 0.0f ? -65472.0f : 0.0f); }
     split2(x, hi, lo);
 }
+// Eight fp32 values -> their hi / lo planes (16 B each), for the kernels that split an operand between its global load and its LDS write:
+// the same roundings as split2 (bit-identical planes for values inside the range), on pairs -- v_med3 saturation, v_cvt_pk_f16_f32 and
+// packed fp32 arithmetic: ~6 vector instructions per element instead of the ~13 of eight scalar split2_checked calls (which made the
+// fp32-operand GEMM 15-40 % slower per launch than the packed-operand one).  Out of range: saturated to +-65472 (NaN: -65472) and flagged.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8_checked(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4], bool& bad) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x2_t v = {x[2 * p], x[2 * p + 1]};
+        bad |= !(fabsf(v.x) < 65504.0f) | !(fabsf(v.y) < 65504.0f);
+        v.x = __builtin_amdgcn_fmed3f(v.x, -65472.0f, 65472.0f);
+        v.y = __builtin_amdgcn_fmed3f(v.y, -65472.0f, 65472.0f);
+        const half2_t h = __builtin_convertvector(v, half2_t);                       // round to nearest even
+        const f32x2_t r = (v - __builtin_convertvector(h, f32x2_t)) * SPLIT_SCALE;   // exact in fp32
+        const half2_t l = __builtin_convertvector(r, half2_t);
+        hi[p] = __builtin_bit_cast(unsigned, h);
+        lo[p] = __builtin_bit_cast(unsigned, l);
+    }
+}
 __device__ __forceinline__ unsigned pack_h2(half_t a, half_t b) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
@@ -558,31 +578,31 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         for (int i = 0; i < 2; ++i) {
             char* at = lds_raw + (size_t)buf * 4 * OPB + (wave * 2 + i) * 16 * ROWB + lane * 16;
             if (AF32) {
-                half_t hi[8], lo[8];
+                float xs[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const unsigned bits = sl[i][e >> 2][e & 3];      // (hipcc 7.2: __builtin_bit_cast straight on a vector ELEMENT reads element 0)
-                    split2_checked(__builtin_bit_cast(float, bits), hi[e], lo[e], bad);
+                    xs[e] = __builtin_bit_cast(float, bits);
                 }
-                const u32x4 vh = {pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])};
-                const u32x4 vl = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])};
-                *reinterpret_cast<u32x4*>(at) = vh;
-                *reinterpret_cast<u32x4*>(at + OPB) = vl;
+                unsigned hi[4], lo[4];
+                split8_checked(xs, hi, lo, bad);
+                *reinterpret_cast<u32x4*>(at) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<u32x4*>(at + OPB) = u32x4{lo[0], lo[1], lo[2], lo[3]};
             } else {
                 *reinterpret_cast<u32x4*>(at) = sl[i][0];
                 *reinterpret_cast<u32x4*>(at + OPB) = sl[i][1];
             }
             if (BF32) {
-                half_t hi[8], lo[8];
+                float xs[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const unsigned bits = sl[i][2 + (e >> 2)][e & 3];
-                    split2_checked(__builtin_bit_cast(float, bits), hi[e], lo[e], bad);
+                    xs[e] = __builtin_bit_cast(float, bits);
                 }
-                const u32x4 vh = {pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])};
-                const u32x4 vl = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])};
-                *reinterpret_cast<u32x4*>(at + 2 * OPB) = vh;
-                *reinterpret_cast<u32x4*>(at + 3 * OPB) = vl;
+                unsigned hi[4], lo[4];
+                split8_checked(xs, hi, lo, bad);
+                *reinterpret_cast<u32x4*>(at + 2 * OPB) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<u32x4*>(at + 3 * OPB) = u32x4{lo[0], lo[1], lo[2], lo[3]};
             } else {
                 *reinterpret_cast<u32x4*>(at + 2 * OPB) = sl[i][2];
                 *reinterpret_cast<u32x4*>(at + 3 * OPB) = sl[i][3];
