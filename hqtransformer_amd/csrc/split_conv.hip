@@ -104,18 +104,18 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     half_t* yb = y + ((long long)b * HW) * 2 * C + cv * 8;
     auto emit = [&](const float4& a0, const float4& a1, int pix) {
         float f[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        half_t hi[8], lo[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float t = f[i];
             if (GN) {
-                t = (t - mu[i]) * rs[i] * gm[i] + bt[i];
+                float t = (f[i] - mu[i]) * rs[i] * gm[i] + bt[i];
                 if (swish) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));     // v_exp_f32 / v_rcp_f32 (1 ulp each): the pass is close to VALU-bound with IEEE division
+                f[i] = t;
             }
-            split2_checked(t, hi[i], lo[i], bad);
         }
-        const u32x4 vh = {pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])};
-        const u32x4 vl = {pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])};
+        unsigned hi[4], lo[4];
+        split8_checked(f, hi, lo, bad);
+        const u32x4 vh = {hi[0], hi[1], hi[2], hi[3]};
+        const u32x4 vl = {lo[0], lo[1], lo[2], lo[3]};
         half_t* dst = yb + (long long)pix * 2 * C;
         *reinterpret_cast<u32x4*>(dst) = vh;
         *reinterpret_cast<u32x4*>(dst + C) = vl;
