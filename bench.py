@@ -65,6 +65,7 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-roofline', action='store_true')
     p.add_argument('--no-graph', action='store_true')
+    p.add_argument('--no-exact-mode', action='store_true', help='skip the `exact_mode` record (fp32 AR loop: a few seconds)')
     p.add_argument('--inflight', type=int, default=None, help='passes in flight per GPU: consecutive passes are round-robined over this many '
                    'lanes (own HIP stream, KV cache and activations; shared weights).  1 = one pass at a time.  Default: see --merge')
     p.add_argument('--merge', type=int, default=None, help='execute this many queued steps as ONE device pass of merge x batch rows (every step keeps its own class id, '
@@ -147,15 +148,20 @@ def cpu_baseline(cfg, s2, s1, batch):
             'blas_threads_sweep_s_per_position': {str(k): v for k, v in sorted(sweep.items())}}
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json:
-    FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE, in bytes); None when no profile is present."""
+def pmc_traffic(family, rows=None):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json: FETCH_SIZE x 2 as
+    MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE, in bytes).  `rows`: the row count of the pass the record times -- the AR GEMM
+    family's traffic depends on it, so it is reported only when the counters were collected AT that row count (by_rows[rows]); otherwise
+    None.  rows=None: a family whose launches do not depend on the pass (the decoder runs 64-image chunks whatever the pass)."""
     path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
     try:
         with open(path) as fp:
-            return json.load(fp).get(family)
+            doc = json.load(fp)
     except (OSError, ValueError):
         return None
+    if rows is None:
+        return doc.get(family)
+    return doc.get('by_rows', {}).get(str(int(rows)), {}).get(family)
 
 
 def default_schedule(steps, merge=None, inflight=None, wide=False):
@@ -170,17 +176,52 @@ def default_schedule(steps, merge=None, inflight=None, wide=False):
     return max(1, inflight if inflight is not None else 3), max(1, merge if merge is not None else 8)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks as a CHILD `python -m torch.distributed.run`
+    of this very command line and exit with its code.  Runs before anything touches the GPU (device_count() does not initialise it on
+    this image), so the parent never holds a device; an N-GPU flag can therefore never silently produce a 1-GPU line."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()
+    if visible < n and not os.environ.get('HQT_BENCH_SHARE_GPU'):
+        raise SystemExit(f'bench.py --gpus {n}: {visible} GPU(s) visible -- refusing to print an {n}-GPU line from fewer devices')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    print(f'[bench] --gpus {n} without a launcher: starting {n} ranks: {" ".join(cmd)}', file=sys.stderr)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)                    # does not return
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:                         # a launcher that started a different number of ranks than the flag says: no line at all
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run')
     if args.gather is None:
         args.gather = 'pixels' if world > 1 else 'none'
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    gather_requested = args.gather
     dist = None
-    if world > 1:
+    # HQT_BENCH_FORCE_DIST=1 (test hook): a ONE-rank RCCL process group, so that the nccl branch below -- init, pre-flight, per-step gather,
+    # barrier, max-over-ranks -- executes on a one-GPU box too (tests/test_gpu_dist.py); the numbers are those of the plain 1-GPU run
+    force_dist = world == 1 and bool(os.environ.get('HQT_BENCH_FORCE_DIST'))
+    if force_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        if gather_requested == 'none' and not any(a.startswith('--gather') for a in sys.argv):
+            args.gather = gather_requested = 'pixels'
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -240,9 +281,10 @@ def main():
     samp_kw = (dict(top_k=[tk] * 3, top_p=[tp] * 3, softmax_temperature=[T] * 3) if three else
                dict(top_k_top=tk, top_p_top=tp, top_k_bot=tk, top_p_bot=tp, softmax_temperature=[T, T]))
 
-    def sample_codes(i, graph, nb=None):
+    def sample_codes(i, graph, nb=None, use_fast=None):
         """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels).  nb: rows of the pass (default: one step's batch)."""
         nb = nb or B
+        fast = args.precision == 'fast' if use_fast is None else use_fast
         cond = cond_of(i)
         if txt_cond and nb > B:          # a text batch is as long as its prompt tensor (sampling.py:187-190): a pass of nb rows = nb / B prompt batches
             cond = torch.cat([cond_of(i + j) for j in range(nb // B)], 0)
@@ -255,13 +297,14 @@ def main():
                                top_p_bot=tp, softmax_temperature=[T, T], use_fp16=fast, is_tqdm=False, max_seq_len=n_pos,
                                model_stage1=None, seed=1 + i, sample_offset=rank * B, use_graph=graph)
 
-    def decode(ct, cb, m=None):
+    def decode(ct, cb, m=None, prec=None):
+        prec = prec or dec_prec
         if three:
-            return (m or model).stage1.decode_sequences([ct] + list(cb), precision=dec_prec, clamp01=True)
+            return (m or model).stage1.decode_sequences([ct] + list(cb), precision=prec, clamp01=True)
         if n_pos < n_full:      # debug runs: pad the code grids so the decoder still sees full-size inputs
             ct = torch.cat([ct, ct.new_zeros(ct.shape[0], n_full - n_pos)], 1)
             cb = torch.cat([cb, cb.new_zeros(cb.shape[0], n_full - n_pos, 4)], 1)
-        return (m or model).stage1.decode_sequences(ct, cb, precision=dec_prec, clamp01=True)
+        return (m or model).stage1.decode_sequences(ct, cb, precision=prec, clamp01=True)
 
     def step(i, graph=True, nb=None):
         ct, cb = sample_codes(i, graph and not args.no_graph, nb)
@@ -352,37 +395,72 @@ def main():
     sample_codes(0, not args.no_graph)  # untimed: the policy change re-captures lane 0's graph; keep that out of the pass below
 
     # ---- reference pass: the same steps one at a time on one lane (the reference harness's order), with per-phase events
+    def one_at_a_time(n, use_fast, prec, gather=True):
+        """n batch-B steps strictly one after the other on one lane -- what measure_throughput/__main__.py:84-116 does -- timed between
+        barriers, AR / decode split by events.  Returns the record (whole-job images/s, ms per step, phase ms)."""
+        for w in range(2):                          # untimed: graph capture / workspace of this precision
+            decode(*sample_codes(w, not args.no_graph, use_fast=use_fast), prec=prec)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n)]
+        keep = []
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(n):
+            i = args.warmup + k
+            with torch.cuda.stream(s_ar):
+                ev[3 * k].record()
+                ct, cb = sample_codes(i, not args.no_graph, use_fast=use_fast)
+                ev[3 * k + 1].record()
+            with torch.cuda.stream(s_dec):
+                s_dec.wait_event(ev[3 * k + 1])
+                px = decode(ct, cb, prec=prec)
+                ev[3 * k + 2].record()
+                if gather and dist is not None and args.gather == 'pixels':
+                    dist.gather(px, gathered, dst=0)
+                elif gather and dist is not None and args.gather == 'codes':
+                    dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+            keep.append((ct, cb, px))
+        barrier()
+        el = time.perf_counter() - t0
+        model.stage1.range_check()             # SPLIT decode: an activation outside the fp16 range would invalidate the pixels (raises)
+        a_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(n)) / n
+        d_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(n)) / n
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return {'value': round(world * B * n / el, 2), 'ms_per_step': round(1000 * el / n, 3), 'steps': n,
+                'phase_ms': {'ar': round(a_ms, 3), 'decode': round(d_ms, 3)}}
+
     n_serial = args.steps if (inflight == 1 and merge == 1) else min(args.steps, 3)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n_serial)]
-    keep = []
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for k in range(n_serial):
-        i = args.warmup + k
-        with torch.cuda.stream(s_ar):
-            ev[3 * k].record()
-            ct, cb = sample_codes(i, not args.no_graph)
-            ev[3 * k + 1].record()
-        with torch.cuda.stream(s_dec):
-            s_dec.wait_event(ev[3 * k + 1])
-            px = decode(ct, cb)
-            ev[3 * k + 2].record()
-            if dist is not None and args.gather == 'pixels':
-                dist.gather(px, gathered, dst=0)
-            elif dist is not None and args.gather == 'codes':
-                dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
-        keep.append((ct, cb, px))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    model.stage1.range_check()                 # SPLIT decode: an activation outside the fp16 range would invalidate the pixels (raises)
-    ar_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(n_serial)) / n_serial
-    dec_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(n_serial)) / n_serial
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    serial_value = world * B * n_serial / elapsed
-    serial_ms = 1000 * elapsed / n_serial
+    serial = one_at_a_time(n_serial, fast, dec_prec)
+    serial['note'] = 'the same steps one at a time on one lane (the reference harness order: measure_throughput/__main__.py:84-116)'
+    ar_ms, dec_ms = serial['phase_ms']['ar'], serial['phase_ms']['decode']
+    # ---- the arithmetic whose code sequences are BIT-EXACT against the reference's CPU path (fp32 AR loop; the decode stays fp32-accurate):
+    #      the same workload, one step at a time and as one merged pass of the timed region's row count
+    exact_mode = None
+    if fast and not args.no_exact_mode and not args.positions:
+        xprec = dec_prec if dec_prec != 'fast' else 'split'
+        ex = one_at_a_time(3, False, xprec, gather=False)
+        ex['precision'] = {'ar': 'EXACT: fp32 weights / activations / accumulation on the vector ALUs -- codes bit-identical to the oracle (tests/test_gpu_timed_schedule.py)',
+                           'decode': xprec}
+        ex['note'] = '3 batch-%d steps one at a time on one lane' % B
+        exact_mode = {'like_for_like': ex}
+        if merge > 1:
+            m_ex = min(merge, 16)
+            xp = InflightSampler(model, lanes=1, device=dev, merge=m_ex)
+            for rnd in range(2):                    # first round untimed (capture at this row count)
+                barrier()
+                t0 = time.perf_counter()
+                for j in range(m_ex):
+                    xp.submit(B, cond_of(j), seed=4000 + j, max_seq_len=n_pos, use_fp16=False, sample_offset=rank * B,
+                              use_graph=not args.no_graph, after=None, precision=xprec, **samp_kw)
+                xp.drain()
+                barrier()
+                el = time.perf_counter() - t0
+            exact_mode['merged'] = {'value': round(world * B * m_ex / el, 2), 'ms_per_step': round(1000 * el / m_ex, 3), 'steps': m_ex,
+                                    'rows_per_pass': m_ex * B, 'lanes': 1,
+                                    'note': f'one pass of {m_ex} merged batch-{B} steps ({m_ex * B} rows), fp32 AR loop + {xprec} decode, one lane'}
+            del xp
     elapsed = elapsed_lanes
 
     out = None
@@ -395,8 +473,10 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if fast else 'f32', 'data': 'synthetic',
             'config': {'workload': (f'text-to-image ({s2.ctx_len_txt}-token synthetic prompts, prefill + ' if txt_cond else 'imagenet256-classcond (') + f'hq-vae({"8x8+16x16+32x32, three code levels" if three else "8x8+16x16"})+hq-transformer {s2.n_layers}L/{s2.embed_dim}d), '
-                                   f'batch {B}/GPU, {n_pos} top positions, ' + (f'top_k={tk}, top_p={tp}, T={T} (quality-mode sampler)' if quality else 'top_k=top_p=None, T=[1,1]'),
-                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
+                                   f'{args.steps} steps of batch {B}/GPU, {n_pos} top positions, ' + (f'top_k={tk}, top_p={tp}, T={T} (quality-mode sampler)' if quality else 'top_k=top_p=None, T=[1,1]') +
+                                   (f'; SCHEDULE: {args.steps} x {B}-row steps merged into {merge * B}-row passes ({merge} steps per pass, {inflight} passes in flight) -- the one-step-at-a-time order of the '
+                                    f'reference harness is the top-level `like_for_like` record' if (merge > 1 or inflight > 1) else '; one step at a time (the reference harness order)'),
+                       'global_batch': world * B, 'per_gpu_batch': B, 'steps_per_pass': merge, 'parallelism': f'dp{world} (sample-sharded, weights replicated)',
                        # the schedule, in numbers: a device pass executes `merge` steps at once, `inflight` passes are resident per GPU
                        'schedule': (('chosen from K: the timed steps are split over 3 lanes in passes of up to 16 steps (merge = min(16, ceil(K / 3)))' if (txt_cond or three) else
                                      'chosen from K: the timed steps are split over 2 lanes in passes of up to 32 steps (merge = min(32, ceil(K / 2)))')
@@ -410,21 +490,28 @@ def main():
                                                          '(the reference harness decodes in fp32, outside autocast)',
                                                 'fast': 'FAST: bf16 MFMA (0.04 max pixel error: NOT the reference harness\'s fp32 decode)',
                                                 'exact': 'EXACT: fp32 FMA chains on the vector ALUs'}[dec_prec]},
-                       'gather': (args.gather + (' (RCCL, every step, inside the timed region)' if args.gather in ('pixels', 'codes') else '')) if world > 1 else 'n/a', 'hip_graph': not args.no_graph,
+                       'gather': (args.gather + (' (RCCL, every step, inside the timed region)' if args.gather in ('pixels', 'codes') else '')) if dist is not None else 'n/a', 'hip_graph': not args.no_graph,
                        'pipeline': (f'{inflight} passes in flight per GPU (round-robin over {inflight} lanes: own HIP stream, KV cache and '
                                     f'activations, shared weights, throughput-oriented GEMM tiles)') if inflight > 1 else 'one pass at a time',
-                       'merge': (f'{merge} consecutive batch-{B} steps execute as ONE device pass of {merge * B} rows (own class id, Philox seed and global row indices per step: '
-                                 f'the draws of a step do not depend on what it is merged with); the reference harness runs one batch-{B} step at a time -- that order is the `serial` record') if merge > 1 else 'none'},
+                       'merge': (f'{merge} consecutive batch-{B} steps execute as ONE device pass of {merge * B} rows (own class id, Philox seed and global row indices per step).  In EXACT (fp32) arithmetic '
+                                 f'the draws of a step do not depend on what it is merged with (bit-identical to the unmerged call); in FAST (bf16, this line) the GEMM / attention / sampler kernels are chosen by the row '
+                                 f'count of the pass, so draws are reproducible per (seed, schedule) and agree with the unmerged call only within the FAST gates (tests/test_gpu_timed_schedule.py).  '
+                                 f'The reference harness runs one batch-{B} step at a time -- that order is the `like_for_like` (= `serial`) record') if merge > 1 else 'none'},
+            # bit-exactness against the reference's CPU path holds for the fp32 AR loop (--precision exact, the `exact_mode` record) only; the timed arithmetic is tolerance-gated
+            'bit_exact_codes': (not fast),
+            'gather_ok': (None if dist is None else (args.gather == gather_requested)),
             'host_ms_per_step': max(host_ms_ranks), 'host_ms_per_step_ranks': host_ms_ranks,
             'host_ms_per_step_unthrottled': round(1000 * host_free_s, 3),
             'host_ms_note': 'host_ms_per_step = wall time until the last step of the timed region was handed to HIP / steps -- the runtime blocks (spins) the submitting thread '
                             'when its queues are full, so a value close to ms_per_step means the DEVICE paces the run; host_ms_per_step_unthrottled = the same submission '
                             f'into empty queues (one untimed pass of {host_free_steps} steps, rank 0): what the host itself costs per step',
             'env_switches': {k: v for k, v in sorted(os.environ.items()) if k.startswith('HQT_')},
-            'serial': {'value': round(serial_value, 2), 'ms_per_step': round(serial_ms, 3), 'steps': n_serial,
-                       'phase_ms': {'ar': round(ar_ms, 3), 'decode': round(dec_ms, 3)},
-                       'note': 'the same steps one at a time on one lane (the reference harness order)'},
+            'serial': serial,
+            # the SAME record under the name VERDICT r03 asked for: BASELINE configs[1] ("batch 64") taken literally, one step at a time
+            'like_for_like': dict(serial, images_in_flight_per_gpu=B),
         }
+        if exact_mode is not None:
+            out['exact_mode'] = exact_mode
         if n_pos < n_full:
             out['INVALID'] = f'debug run: {n_pos} of {n_full} top positions sampled'
 
@@ -486,13 +573,14 @@ def main():
                    'achieved': round(tf, 1) if mfma_bound else round(hbm, 1), 'peak': MFMA_BF16_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
                    'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
                    'frac': round(tf / MFMA_BF16_PEAK_TFLOPS, 4) if mfma_bound else round(hbm / HBM_PEAK_GBS, 4),
-                   'traffic': pmc_traffic('stream_gemm'), 'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3),
+                   'traffic': pmc_traffic('stream_gemm', Bm), 'launches': n_l, 'avg_launch_us': round(1000 * gemm_ms / n_l, 3),
                    'total_ms': round(gemm_ms, 3), 'algorithmic_flops_per_launch': round(gflops / n_l), 'algorithmic_bytes_per_launch': round(wbytes / n_l),
                    'weight_stream_GBps': round(hbm, 1), 'weight_stream_frac_of_hbm_peak': round(hbm / HBM_PEAK_GBS, 4),
                    'eager_to_graph_scale': round(ar_scale, 4), 'rows_per_pass': Bm,
                    'frac_timed_region': round((gflops * passes / elapsed_lanes / 1e12 / MFMA_BF16_PEAK_TFLOPS) if mfma_bound else (wbytes * passes / elapsed_lanes / 1e9 / HBM_PEAK_GBS), 4),
-                   'traffic_source': 'profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of a bounded run of this kernel family, '
-                                     'committed with the repository; NOT collected by this invocation',
+                   'traffic_source': (f'profiles/pmc_latest.json by_rows[{Bm}]: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE over a bounded run (2 positions) of THESE {Bm}-row kernels, '
+                                      'committed with the repository; not collected by this invocation') if pmc_traffic('stream_gemm', Bm) else
+                                     f'null: no committed counter pass at {Bm} rows per pass (tools/collect_round_evidence.sh collects them at the rows of the driver and the default schedule)',
                    'note': 'per-launch figure of the kernels the timed region runs (one pass = merge x batch rows; throughput policy when several lanes are in flight), measured one lane '
                            'at a time with per-launch HIP events; algorithmic FLOPs = 2 x rows x N x K of every nn.Linear of the reference (stage2/layers.py), algorithmic bytes = the bf16 '
                            'weights, streamed once per pass',

@@ -158,14 +158,16 @@ AUDITED_KERNELS = ('_Z27conv3x3_split_ring16_kernelILi0EEv8GemmArgs', '_Z25conv2
 def audit_hand_scheduled_loops(hipcc: str, flags: List[str], hdrs: List[str], force: bool = False, verbose: bool = False) -> None:
     """The SPLIT ring kernels (the default decode path) keep inline-asm loads in flight across their loop's back edge, behind the
     compiler's own waitcnt tracking.  That is only sound if hipcc leaves the loop one basic block and never touches a register with
-    a load in flight -- checked on the ISA THIS toolchain generates from THESE sources with THESE flags (tools/micro/audit_ring.py).
+    a load in flight -- checked on the ISA THIS toolchain generates from THESE sources with THESE flags (csrc/audit_ring.py).
     The verdict is cached under a hash of the source, every header, the flags and `hipcc --version`; a failed audit fails the build
     (HqtLibraryError), so neither build() of __graft_entry__ nor a direct rebuild can link an unaudited kernel."""
     import hashlib
     import sys
     import tempfile
     src = os.path.join(CSRC, 'split_stream_conv.hip')
-    tool = os.path.join(os.path.dirname(HERE), 'tools', 'micro', 'audit_ring.py')
+    tool = os.path.join(CSRC, 'audit_ring.py')              # ships inside the package, next to the sources it audits
+    if not os.path.exists(tool):
+        raise HqtLibraryError(f'{tool} is missing: the ISA audit of the hand-scheduled SPLIT loops cannot run, refusing to build')
     stamp = os.path.join(CSRC, 'build', 'split_stream_conv.audit')
     hh = hashlib.sha256()
     for f in [src, tool] + sorted(hdrs):

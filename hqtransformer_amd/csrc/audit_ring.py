@@ -4,7 +4,7 @@
 The kernel keeps asm-issued loads in flight across its loop's back edge; that is only safe if (a) the loop body is ONE basic block and
 (b) hipcc never touches a destination register of such a load except in the MFMAs / ds_writes that consume it after the counted wait.
 This script checks both on the generated ISA:   hipcc -O3 --offload-arch=gfx950 -S --cuda-device-only split_stream_conv.hip -o x.s;
-                                                 python tools/micro/audit_ring.py x.s [mangled kernel name]
+                                                 python hqtransformer_amd/csrc/audit_ring.py x.s [mangled kernel name]
 (both hand-scheduled kernels: _Z25conv3x3_split_ring_kernelILi0EEv8GemmArgs, _Z27conv3x3_split_ring16_kernelILi0EEv8GemmArgs)
 """
 import re

@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(NT, 8) void sampler_kernel(SamplerArgs a, int n2) {
             philox4x32_10((uint32_t)i4, (uint32_t)(step * draws + draw), (uint32_t)grow, (uint32_t)(grow >> 32), k0, k1, rnd);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float u = ((float)(rnd[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                const float u = ((float)(rnd[e] >> 9) + 0.5f) * (1.0f / 8388608.0f);     // 23 bits + 0.5: exact in fp32, u in [2^-24, 1 - 2^-24] -- never 1.0 (q = 0)
                 q[e] = FM ? -__logf(u) : -logf(u);
             }
         }
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(256) void sampler_plain_fast_kernel(SamplerArgs a) 
                 uint32_t rnd[4];
                 philox4x32_10((uint32_t)i4, (uint32_t)(step * draws + draw), (uint32_t)grow, (uint32_t)(grow >> 32), k0, k1, rnd);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = -__logf(((float)(rnd[e] >> 8) + 0.5f) * (1.0f / 16777216.0f));
+                for (int e = 0; e < 4; ++e) q[e] = -__logf(((float)(rnd[e] >> 9) + 0.5f) * (1.0f / 8388608.0f));
             }
             const float l[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll

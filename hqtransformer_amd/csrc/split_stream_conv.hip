@@ -17,7 +17,7 @@
 //     fragment address is base + immediate), filled through registers by buffer loads whose range check supplies the zero padding:
 //     ONE workgroup barrier per 32-channel chunk;
 //   * the main loop is one basic block of straight-line code with asm loads in flight across its back edge; _lib.build() audits the
-//     generated ISA (tools/micro/audit_ring.py) and refuses to link a library whose loops the compiler has touched.
+//     generated ISA (csrc/audit_ring.py) and refuses to link a library whose loops the compiler has touched.
 #include "split_kernels.h"
 #include "gemm_generic.h"
 #include <algorithm>

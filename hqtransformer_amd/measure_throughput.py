@@ -13,7 +13,7 @@ default ``decode_precision=split`` is fp32-accurate on the matrix cores (pixels 
 fp32 FMA chains on the vector ALUs, ``fast`` bf16 MFMA (faster, 0.04 max pixel error).  ``inflight=N`` (default 1 = the reference's order) keeps N
 iterations in flight on N lanes (``hqtransformer_amd.pipeline``): same iterations, same accounting of the loop's wall
 time; the per-phase figures then are lane times, which overlap.  ``merge=k`` executes k consecutive iterations as one pass of
-k x batch_size rows (every iteration keeps its own class id and seed; ``bench.py``'s default schedule is ``inflight=3 merge=8``);
+k x batch_size rows (every iteration keeps its own class id and seed; ``bench.py`` picks its schedule from its step count K: 2 lanes x passes of min(32, ceil(K / 2)) steps);
 the per-phase figures are then measured per pass.
 """
 from __future__ import annotations

@@ -202,64 +202,70 @@ class HQVAEStage1(_Stage):
                 e.range_check()
 
     def decode_code(self, code_t, code_b: Optional[torch.Tensor] = None, precision: Optional[str] = None,
-                    clamp01: bool = False, lane: int = 0) -> torch.Tensor:
+                    clamp01: bool = False, lane: int = 0, check_range: bool = True) -> torch.Tensor:
         """``SimRQGAN2Generator.decode_code`` (generator.py:323-367): int64 code grids -> fp32 [B, 3, H, W],
         unclamped; either level may be None (zero quant).  ``precision``: 'exact' (fp32 FMA chains on the vector ALUs),
         'split' (fp32-accurate on the matrix cores: fp16 hi/lo operands, fp32 accumulation -- the reference decodes in fp32,
-        and this meets its 1e-4 pixel bar about 6x faster than 'exact') or 'fast' (bf16 MFMA); defaults to ``self.precision``."""
+        and this meets its 1e-4 pixel bar about 6x faster than 'exact') or 'fast' (bf16 MFMA); defaults to ``self.precision``.
+        ``check_range`` (SPLIT only): True = wait for the call and raise HqtError if an activation left the fp16 range (a stream
+        synchronisation: the call is then NOT asynchronous); False = stay asynchronous, the caller runs ``range_check()`` itself
+        once its pipeline drains (what ``decode_sequences`` always does)."""
         if isinstance(code_t, (list, tuple)):        # HQVAEGenerator.decode_code([t, m, b]) (generator.py:577-599)
             codes = list(code_t)
             ref = next(c for c in codes if c is not None)
             prec = self._prec(precision)
             eng = self.engine(int(ref.shape[0]), lane)
             px = eng.decode3(codes, precision=prec, clamp01=clamp01)
-            eng.range_check()
+            if check_range:
+                eng.range_check()
             return px
         assert code_t is not None or code_b is not None
         ref = code_t if code_t is not None else code_b
         prec = self._prec(precision)
         eng = self.engine(int(ref.shape[0]), lane)
         px = eng.decode(code_t, code_b, precision=prec, clamp01=clamp01)
-        eng.range_check()
+        if check_range:
+            eng.range_check()
         return px
 
     # -- encode side (generator.py:298-310, 369-370; HQVAEGenerator.encode 530-568)
-    def _encode(self, x: torch.Tensor, precision: Optional[str], lane: int, **want):
+    def _encode(self, x: torch.Tensor, precision: Optional[str], lane: int, check_range: bool = True, **want):
         prec = self._prec(precision)
         eng = self.engine(int(x.shape[0]), lane)
         out = eng.encode(x, precision=prec, **want)
-        eng.range_check()
+        if check_range:                                  # SPLIT: waits for the call (see decode_code)
+            eng.range_check()
         return out
 
-    def encode(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0):
+    def encode(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0, check_range: bool = True):
         """Two levels -- ``SimRQGAN2Generator.encode``: ``(quant_t, quant_b, diff_t, diff_b, (code_t, code_b, h_b))`` with the codes
         flattened as the reference returns them ([B * r_l * r_l]) and ``h_b`` the bottom quantiser's input.
         Three levels -- ``HQVAEGenerator.encode``: ``(quant, diffs, codes, resids[1:])`` with ``quant`` the summed reconstruction."""
         three = self.spec.code_levels == 3
-        o = self._encode(x, precision, lane, want_quant=not three, want_resid=True, want_recon=three, want_diff=True)
+        o = self._encode(x, precision, lane, check_range, want_quant=not three, want_resid=True, want_recon=three, want_diff=True)
         codes = [c.reshape(-1) for c in o['codes']]
         diffs = list(o['diff'].unbind(0))
         if three:
             return o['recon'], diffs, codes, o['resid'][1:]
         return o['quant'][0], o['quant'][1], diffs[0], diffs[1], (codes[0], codes[1], o['resid'][1])
 
-    def get_codes(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0):
+    def get_codes(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0, check_range: bool = True):
         """``SimRQGAN2Generator.get_codes`` (generator.py:369-370): ``(code_t, code_b)``, flattened; three levels: the list of codes."""
-        o = self._encode(x, precision, lane)
+        o = self._encode(x, precision, lane, check_range)
         codes = [c.reshape(-1) for c in o['codes']]
         return codes if self.spec.code_levels == 3 else (codes[0], codes[1])
 
-    def code_grids(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0):
+    def code_grids(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0, check_range: bool = True):
         """The codes as grids [B, r_l, r_l], coarse -> fine: what ``decode_code`` takes back."""
-        return self._encode(x, precision, lane)['codes']
+        return self._encode(x, precision, lane, check_range)['codes']
 
-    def forward(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, precision: Optional[str] = None, lane: int = 0, check_range: bool = True) -> torch.Tensor:
         """Reconstruction ``decode(encode(x))`` (the ``dec`` of ``SimRQGAN2Generator.forward`` in eval mode, generator.py:262-280;
         eval_stage1.py reads only this output)."""
-        grids = self.code_grids(x, precision, lane)
+        grids = self.code_grids(x, precision, lane, check_range=False)        # one check below covers both halves (same engine, same stream)
         if self.spec.code_levels == 3:
-            return self.decode_code(list(grids), precision=precision, lane=lane)
-        return self.decode_code(grids[0], grids[1], precision=precision, lane=lane)
+            return self.decode_code(list(grids), precision=precision, lane=lane, check_range=check_range)
+        return self.decode_code(grids[0], grids[1], precision=precision, lane=lane, check_range=check_range)
 
     __call__ = forward
 

@@ -53,7 +53,7 @@ def gate(name: str, value: float, limit: float, op: str = '<=') -> None:
 def philox_exp_noise(row_seeds, global_rows, n_steps: int, V: int, draws: int = 5) -> np.ndarray:
     """The Exp(1) noise libhqt's sampler generates in-kernel (csrc/kernels.hip, sampler_kernel): Philox4x32-10 with key = the
     row's 64-bit seed, counter = (vocabulary index // 4, step * draws + draw, global row lo, global row hi), lane v % 4 of the
-    output, q = -log((float(r >> 8) + 0.5) * 2^-24) in fp32.  The RNG is this build's own design (the reference draws from
+    output, q = -log((float(r >> 9) + 0.5) * 2^-23) in fp32 (23 random bits: the sum is exact and u < 1, so q > 0 always).  The RNG is this build's own design (the reference draws from
     torch's global generator), so this restatement is test infrastructure: it lets the oracle replay what a Philox-driven call
     drew.  Returns [n_steps, draws, B, V] fp32."""
     seeds = np.asarray(row_seeds, np.uint64)
@@ -80,6 +80,6 @@ def philox_exp_noise(row_seeds, global_rows, n_steps: int, V: int, draws: int = 
                 k0 = (k0 + np.uint64(0x9E3779B9)) & M32
                 k1 = (k1 + np.uint64(0xBB67AE85)) & M32
             r = np.stack([c0, c1, c2, c3], axis=-1).reshape(B, V4 * 4)
-            u = ((r >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+            u = ((r >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
             out[step, d] = -np.log(u, dtype=np.float32)
     return out[..., :V]

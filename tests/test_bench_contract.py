@@ -59,3 +59,39 @@ def test_default_schedule_rule():
     assert ds(96) == (2, 32) and ds(20) == (2, 10) and ds(7) == (2, 4) and ds(1) == (2, 1) and ds(1000) == (2, 32)
     assert ds(96, merge=8) == (3, 8) and ds(96, inflight=1) == (1, 8) and ds(96, 48, 2) == (2, 48)
     assert ds(48, wide=True) == (3, 16) and ds(96, wide=True) == (3, 16) and ds(20, wide=True) == (3, 7) and ds(48, 8, None, True) == (3, 8)
+
+
+def _run_bench(args, env_extra):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_gpus_flag_never_degrades_to_fewer_devices():
+    """`bench.py --gpus N` must either run N ranks or print no line: with fewer visible GPUs than N (this container has none) it refuses
+    before touching a device, and a launcher that started a different number of ranks than the flag says is refused too."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        return
+    r = _run_bench(['--gpus', '8'], {})
+    assert r.returncode != 0 and 'refusing' in r.stderr and '{"metric"' not in r.stdout
+    r = _run_bench(['--gpus', '8'], {'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr and '{"metric"' not in r.stdout
+    r = _run_bench(['--gpus', '1'], {'WORLD_SIZE': '4', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and '{"metric"' not in r.stdout
+
+
+def test_traffic_is_keyed_by_the_rows_of_the_pass():
+    """`roofline.traffic` of the AR GEMM family is attached only when the committed counter pass ran at the row count the record times."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    doc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
+    rows = sorted(int(r) for r in doc.get('by_rows', {}))
+    assert rows, 'profiles/pmc_latest.json holds no by_rows entry'
+    assert mod.pmc_traffic('stream_gemm', rows[0]) == doc['by_rows'][str(rows[0])]['stream_gemm']
+    assert mod.pmc_traffic('stream_gemm', 7) is None
+    assert mod.pmc_traffic('decoder_conv') == doc['decoder_conv']

@@ -94,3 +94,36 @@ def test_bench_two_gpus_over_rccl():
     branch executes; the gather is pre-flighted there and the line says so if it had to be dropped."""
     d = _bench_two_ranks({}, 2)
     assert d['n_gpus'] == 2 and d['config']['gather'].startswith('pixels'), d['config']['gather']
+
+
+def _bench_direct(args, extra_env):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + args + ['--steps', '6', '--warmup', '2', '--merge', '2', '--inflight', '2',
+           '--config', os.path.join(ROOT, 'configs', 'tiny-cls.yaml'), '--no-cpu-baseline', '--no-roofline', '--no-exact-mode']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env), capture_output=True, text=True, timeout=900)
+    return r
+
+
+def test_bench_gpus_flag_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver called `--gpus 1` in round 3): bench.py must start the two ranks
+    itself (a child torch.distributed.run) and print a 2-GPU line -- never a 1-GPU number under a 2-GPU flag.  Two ranks share the one
+    visible GPU through the HQT_BENCH_SHARE_GPU hook; without the hook the same command must refuse (fewer devices than ranks)."""
+    r = _bench_direct(['--gpus', '2'], {'HQT_BENCH_SHARE_GPU': '1'})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 * d['config']['per_gpu_batch']
+    assert d['gather_ok'] in (True, False) and 'like_for_like' in d
+    if torch.cuda.device_count() < 2:
+        r = _bench_direct(['--gpus', '2'], {})
+        assert r.returncode != 0 and 'refusing' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """The nccl (= RCCL) branch of bench.py on a one-GPU box: HQT_BENCH_FORCE_DIST=1 makes the plain 1-GPU run create a ONE-rank RCCL
+    process group, so init_process_group('nccl'), the gather pre-flight, `dist.gather` of every step's pixels on the lane's stream,
+    the barrier and the max-over-ranks all execute on RCCL (with two GPUs test_bench_two_gpus_over_rccl runs the real thing)."""
+    r = _bench_direct(['--gpus', '1'], {'HQT_BENCH_FORCE_DIST': '1'})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['config']['gather'].startswith('pixels'), d['config']['gather']
+    assert d['gather_ok'] is True

@@ -30,9 +30,10 @@ def variants(eng):
     return {k: v[0] for k, v in eng.timing_report().items() if k.startswith('variant:')}
 
 
-@pytest.mark.parametrize('B,n', [(512, 3), (2048, 2)])
+@pytest.mark.parametrize('B,n', [(512, 3), (640, 3), (2048, 2)])
 def test_merged_pass_kernels_vs_oracle_at_imagenet_width(B, n):
-    """A 512-row pass exactly as a merge-8 step of bench.py issues it, and a 2048-row pass as a merge-32 step (the default schedule) does (same engine call, same policy, graph and eager): EXACT codes
+    """A 512-row pass exactly as a merge-8 step of bench.py issues it, a 640-row pass as the DRIVER's invocation (`--steps 20`: merge 10; five 128-row tiles, ragged against the
+    8-tile groups of the XCD-aware order) and a 2048-row pass as a merge-32 step (the default schedule) does (same engine call, same policy, graph and eager): EXACT codes
     bit-identical and logits <= 2e-4 against the oracle, FAST teacher-forced logits inside the bf16 gate, and the launches counted
     per kernel variant: every body / depth GEMM of the FAST pass must have gone through the tile kernels."""
     spec = Stage2Spec(embed_dim=1536, n_layers=1, n_heads=24, n_layers_depth=1, vocab_top=8192, vocab_bot=8192, vocab_txt=64,
@@ -66,8 +67,8 @@ def test_merged_pass_kernels_vs_oracle_at_imagenet_width(B, n):
             stream = {k: c for k, c in v.items() if k.startswith('variant:stream_gemm')}
             # per position: body qkv/proj/fc1/fc2 + 2 x depth qkv/proj/fc1/fc2 + 2 heads = 14 GEMMs; only the 512-row proj (K = D: one short
             # K loop over 48 tiles) stays on the streaming kernel (body + depth sub-step 0); from 1024 rows nothing does
-            if B == 512:
-                assert set(stream) <= {'variant:stream_gemm:gemm_proj'} and sum(stream.values()) == 2 * n, f'streaming GEMMs in a 512-row pass: {stream}'
+            if B in (512, 640):
+                assert set(stream) <= {'variant:stream_gemm:gemm_proj'} and sum(stream.values()) == 2 * n, f'streaming GEMMs in a {B}-row pass: {stream}'
                 assert sum(tile.values()) == 12 * n, v
             else:
                 assert not stream and sum(tile.values()) == 14 * n, v
@@ -125,10 +126,10 @@ def _one_layer_model(seed):
     return ImageGPT2(cfg, seed=seed).to('cuda').eval()
 
 
-@pytest.mark.parametrize('merge_k,lanes,check', [(8, 3, (3, 20)), (32, 2, (9, 62))])
+@pytest.mark.parametrize('merge_k,lanes,check', [(8, 3, (3, 20)), (10, 2, (3, 17)), (32, 2, (9, 62))])
 def test_inflight_sampler_at_the_timed_schedules_vs_oracle(merge_k, lanes, check):
     """The harness schedule itself: steps of batch 64 through InflightSampler(merge=8, lanes=3) -- three passes of 512 rows, one
-    per lane -- and through InflightSampler(merge=32, lanes=2), bench.py's default -- two passes of 2048 rows --, each row drawing
+    per lane --, through InflightSampler(merge=10, lanes=2), what the driver's `bench.py --steps 20` runs -- two passes of 640 rows --, and through InflightSampler(merge=32, lanes=2), bench.py's default -- two passes of 2048 rows --, each row drawing
     with the Philox key of ITS step.  In EXACT arithmetic two of the eight steps of a pass are replayed
     by the oracle (Philox noise restated on the host, tests/helpers.py) and must match bit for bit; the FAST passes (what bench.py
     times) must draw the same codes as the EXACT ones under the same keys almost everywhere."""
@@ -159,7 +160,8 @@ def test_inflight_sampler_at_the_timed_schedules_vs_oracle(merge_k, lanes, check
     first = np.mean([((a[0][:, 0] == b[0][:, 0]).mean() + 4 * (a[1][:, 0] == b[1][:, 0]).mean()) / 5 for a, b in zip(res[False], res[True])])
     gate(f'timed_schedule.inflight_merge{merge_k}_lanes{lanes}.fast_vs_exact_first_position', first, 0.985, '>=')
     same = np.mean([((a[0] == b[0]).mean() + (a[1] == b[1]).mean()) / 2 for a, b in zip(res[False], res[True])])
-    gate(f'timed_schedule.inflight_merge{merge_k}_lanes{lanes}.fast_vs_exact_all_positions', same, 0.25, '>=')
+    # (measured 0.995 in round 3, profiles/r03_fast_gates.txt: with one body + one depth layer a differing draw rarely cascades)
+    gate(f'timed_schedule.inflight_merge{merge_k}_lanes{lanes}.fast_vs_exact_all_positions', same, 0.9, '>=')
 
 
 @pytest.mark.parametrize('steps', [8, 32])
