@@ -33,7 +33,7 @@ def test_roofline_and_cpu_baseline_objects():
         assert r['traffic'] is None or r['traffic'] > 0
         assert r['launches'] > 0 and r['avg_launch_us'] > 0
     c = d['cpu_baseline']
-    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str) and c['unit'] == d['unit']
+    assert c['kind'] in ('port', 'native-port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and isinstance(c['sample'], str) and c['unit'] == d['unit']
     # the per-launch figure follows from its own parts: achieved = algorithmic work per launch / average launch duration
     r = d['roofline']
     if r['bound'] == 'mfma':

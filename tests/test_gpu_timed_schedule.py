@@ -126,7 +126,7 @@ def _one_layer_model(seed):
     return ImageGPT2(cfg, seed=seed).to('cuda').eval()
 
 
-@pytest.mark.parametrize('merge_k,lanes,check', [(8, 3, (3, 20)), (10, 2, (3, 17)), (32, 2, (9, 62))])
+@pytest.mark.parametrize('merge_k,lanes,check', [(8, 3, (3, 20)), (10, 2, (3, 19)), (32, 2, (9, 62))])
 def test_inflight_sampler_at_the_timed_schedules_vs_oracle(merge_k, lanes, check):
     """The harness schedule itself: steps of batch 64 through InflightSampler(merge=8, lanes=3) -- three passes of 512 rows, one
     per lane --, through InflightSampler(merge=10, lanes=2), what the driver's `bench.py --steps 20` runs -- two passes of 640 rows --, and through InflightSampler(merge=32, lanes=2), bench.py's default -- two passes of 2048 rows --, each row drawing
@@ -152,7 +152,13 @@ def test_inflight_sampler_at_the_timed_schedules_vs_oracle(merge_k, lanes, check
     orc = O.OracleStage2(s2, w2)
     for k in check:                                          # a step inside the first pass (lane 0) and one inside the last (last lane)
         noise = philox_exp_noise([seeds[k]] * B, [offs[k] + i for i in range(B)], n, s2.vocab_top)
+        O.MARGIN_SINK = []
         want = orc.sample(np.full(B, cls[k]), B, n, noise)
+        margin, O.MARGIN_SINK = min(O.MARGIN_SINK), None
+        # 64 positions x 5 draws x 64 rows over V = 8192: the closest winner / runner-up pair of p / q of a step is typically within
+        # 1e-5 .. 5e-5; a pair within ~2e-6 is decided by summation order (step 17 of this very schedule: 1.000002) and says nothing
+        # about parity.  The checked steps are chosen well-conditioned, and the test says so if the noise stream ever changes.
+        assert margin >= 1.00001, f'step {k}: the oracle\'s closest draw has margin {margin}: ill-conditioned for a bit-exact comparison, check another step'
         assert (res[False][k][0] == want[0]).all() and (res[False][k][1] == want[1]).all(), f'step {k}: merged EXACT codes differ from the oracle'
     # FAST vs EXACT under the same keys.  Free-running, a differing draw changes everything fed back after it, so the per-draw
     # gate is taken at position 0 (the input is the class embedding in both runs: 24 x 64 x 5 independent draws); the whole
