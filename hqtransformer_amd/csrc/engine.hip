@@ -600,16 +600,16 @@ static int load_block(hqt_handle* h, const std::string& p, BlockW& b) {
     HIPCHK(hipMemcpy(bqkv, bq, D * 4, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(bqkv + D, bk, D * 4, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(bqkv + 2 * D, bv, D * 4, hipMemcpyDeviceToDevice));
-    CHK(make_lin(h, b.qkv, wqkv, bqkv, 3 * D, D, true));
+    CHK(make_lin(h, b.qkv, wqkv, bqkv, 3 * D, D, true, true));      // + fp16 hi / lo planes: the SPLIT AR loop
     CHK(get_w(h, p + ".attn.proj.weight", {D, D}, &w));
     CHK(get_w(h, p + ".attn.proj.bias", {D}, &bias));
-    CHK(make_lin(h, b.proj, w, bias, D, D, true));
+    CHK(make_lin(h, b.proj, w, bias, D, D, true, true));      // + fp16 hi / lo planes: the SPLIT AR loop
     CHK(get_w(h, p + ".mlp.0.weight", {4 * D, D}, &w));
     CHK(get_w(h, p + ".mlp.0.bias", {4 * D}, &bias));
-    CHK(make_lin(h, b.fc1, w, bias, 4 * D, D, true));
+    CHK(make_lin(h, b.fc1, w, bias, 4 * D, D, true, true));      // + fp16 hi / lo planes: the SPLIT AR loop
     CHK(get_w(h, p + ".mlp.2.weight", {D, 4 * D}, &w));
     CHK(get_w(h, p + ".mlp.2.bias", {D}, &bias));
-    CHK(make_lin(h, b.fc2, w, bias, D, 4 * D, true));
+    CHK(make_lin(h, b.fc2, w, bias, D, 4 * D, true, true));      // + fp16 hi / lo planes: the SPLIT AR loop
     CHK(fold_ln(h, b.qkv, b.ln1_g, b.ln1_b));
     CHK(fold_ln(h, b.fc1, b.ln2_g, b.ln2_b));
     return HQT_OK;
@@ -733,12 +733,12 @@ static int finalize_impl(hqt_handle* h) {
         const int64_t D = c.embed_dim;
         const bool l3 = c.code_levels == 3;
         CHK(get_w(h, key2(h, "head_top.weight"), {c.vocab_top, D}, &w));
-        CHK(make_lin(h, h->head_top, w, nullptr, c.vocab_top, D, true));
+        CHK(make_lin(h, h->head_top, w, nullptr, c.vocab_top, D, true, true));      // + fp16 hi / lo planes: the SPLIT AR loop
         CHK(get_w(h, key2(h, "head_bot.weight"), {c.vocab_bot, D}, &w));
-        CHK(make_lin(h, h->head_bot, w, nullptr, c.vocab_bot, D, true));
+        CHK(make_lin(h, h->head_bot, w, nullptr, c.vocab_bot, D, true, true));      // + fp16 hi / lo planes: the SPLIT AR loop
         if (l3) {
             CHK(get_w(h, "stage2.head_levels.2.weight", {c.vocab_top, D}, &w));
-            CHK(make_lin(h, h->head_l2, w, nullptr, c.vocab_top, D, true));
+            CHK(make_lin(h, h->head_l2, w, nullptr, c.vocab_top, D, true, true));      // + fp16 hi / lo planes: the SPLIT AR loop
         }
         // presence/shape checks of the remaining tensors happen here so that sample() cannot fail late
         const float* t;
@@ -830,16 +830,18 @@ static int finalize_impl(hqt_handle* h) {
 // ------------------------------------------------------------------------------------------ GEMM dispatch
 struct Mode {
     bool fast = false;
-    bool split = false;     // stage 1 only: fp32 tensors, convolutions on the matrix cores with fp16 hi / lo operands (split_kernels.h)
+    bool split = false;     // stage 1: fp32 tensors, convolutions on the matrix cores with fp16 hi / lo operands (split_kernels.h)
+    bool split_ar = false;  // stage 2 (hqt_sample / hqt_sample_l3): the EXACT launch sequence -- fp32 activations, LayerNorm, attention, sampler -- with
+                            // every nn.Linear on the matrix cores: fp32 activation rows split into fp16 hi / lo while their tile is staged, the weights as
+                            // fp16 hi / lo planes, three MFMAs per product term, fp32 accumulation (split_gemm_kernel<fp32 A>)
     int act_dt() const { return fast ? DT_BF16 : DT_F32; }
     size_t act_sz() const { return fast ? 2 : 4; }
 };
 static int mode_of(int precision, bool stage1, Mode* md) {
     if (precision == HQT_PRECISION_FAST) md->fast = true;
     else if (precision == HQT_PRECISION_SPLIT && stage1) md->split = true;
-    else if (precision != HQT_PRECISION_EXACT)
-        return fail(HQT_ERR_INVALID, precision == HQT_PRECISION_SPLIT ? "HQT_PRECISION_SPLIT applies to the stage-1 entry points (decode / encode) only"
-                                                                       : "unknown precision %d", precision);
+    else if (precision == HQT_PRECISION_SPLIT) md->split_ar = true;
+    else if (precision != HQT_PRECISION_EXACT) return fail(HQT_ERR_INVALID, "unknown precision %d", precision);
     return HQT_OK;
 }
 
@@ -923,9 +925,19 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         HIPCHK(launch_gemm_generic(g, a_dt, DT_BF16, c_dt, st));
         return HQT_OK;
     }
+    if (md.split_ar && l.w16h && l.w16l && !g.conv_taps && !g.a_packed_mb) {
+        GemmArgs sg = g;
+        sg.a_f32 = 1; sg.Bw = l.w16h; sg.Bw_lo = l.w16l; sg.range_flag = h->range_flag;
+        if (split_gemm_ok(sg)) {
+            HIPCHK(launch_split_gemm(sg, st));
+            count_variant(h, "variant:split_gemm:%s", tag);
+            return HQT_OK;
+        }
+    }
     g.Bw = l.w32;
     if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
     HIPCHK(launch_gemm_generic(g, DT_F32, DT_F32, DT_F32, st));
+    if (md.split_ar) count_variant(h, "variant:gemm_generic_f32:%s", tag);
     return HQT_OK;
 }
 

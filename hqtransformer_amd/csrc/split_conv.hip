@@ -681,7 +681,12 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
     // of a workgroup's 80 k (tools/micro/bench_split_gemm, in-kernel stamps); 14-25 k since.
     float* Cb = reinterpret_cast<float*>(g.C) + (long long)bz * g.c_batch_stride;
     const float* Rb = g.resid ? reinterpret_cast<const float*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
-    const bool plain = g.store == STORE_ROWS && g.rows_per_group == 0 && (g.N & 3) == 0 && (g.ldc & 3) == 0;
+    // STORE_QKV (SPLIT AR loop: the fused [query; key; value] GEMM of a block, stage2/layers.py:73-85): a wave's 64-column block lies in ONE
+    // part (the launcher guarantees qkv_D % 64 == 0), so the destination -- q rows as they are, K / V rows through the cache's row remap --
+    // is resolved once per wave, never per element (a per-element select between C / C2 / C3 was miscompiled by hipcc -O3, fast_kernels.hip)
+    const bool qkv = g.store == STORE_QKV;
+    const bool plain = ((g.store == STORE_ROWS && g.rows_per_group == 0) || qkv) && (g.N & 3) == 0 && (g.ldc & 3) == 0;
+    const int qkv_row_dev = (qkv && g.row_offset_dev) ? *g.row_offset_dev : 0;
     float* lbias = reinterpret_cast<float*>(lds_raw);
     if (tid < BN) lbias[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.0f;     // every wave passed the loop's last barrier: the stages are free
     __syncthreads();
@@ -695,9 +700,14 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         float* const stg = reinterpret_cast<float*>(lds_raw) + BN + wave * (32 * PITCH);
         static_assert((BN + 4 * 32 * PITCH) * 4 <= 2 * 4 * OPB, "bias + staging patches fit the operand stages");
         const int cg = (lane & 15) * 4, r0 = lane >> 4;
+        const int ncol0 = n0 + wn * 64;
+        const int part_local = qkv ? ncol0 / max(g.qkv_D, 1) : 0, part = part_local + (qkv ? g.qkv_first : 0);
+        float* const Cw = qkv ? reinterpret_cast<float*>(part == 0 ? g.C : (part == 1 ? g.C2 : g.C3)) : Cb;
+        const int ccol0 = ncol0 - part_local * (qkv ? g.qkv_D : 0);          // column inside the destination
+        const bool remap = qkv && part > 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int mrow0 = m0 + wm * 64 + i * 32, ncol0 = n0 + wn * 64;
+            const int mrow0 = m0 + wm * 64 + i * 32;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -725,7 +735,9 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                 const int r = p * 4 + r0, m = mrow0 + r;
                 f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * PITCH + cg);
                 if (Rb) v += x0[p];
-                if (m < g.M && col_ok) *reinterpret_cast<f32x4*>(Cb + (long long)m * g.ldc + ncol0 + cg) = v;
+                long long orow = m;
+                if (remap) orow = (long long)(m / g.rows_per_group) * g.group_stride + m % g.rows_per_group + g.row_offset + qkv_row_dev;
+                if (m < g.M && col_ok) *reinterpret_cast<f32x4*>(Cw + orow * g.ldc + ccol0 + cg) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();                           // the patch is rewritten by the next row block
@@ -782,6 +794,8 @@ bool split_gemm_ok(const GemmArgs& g) {
     if (g.K % 64 != 0 || g.ldb % 8 != 0) return false;
     if (g.a_f32 && (g.conv_taps ? g.Cin : g.lda) % 4 != 0) return false;
     if (g.b_f32 && (!g.a_f32 || g.ldb % 4 != 0)) return false;
+    if (g.store == STORE_QKV)       // the SPLIT AR loop's fused [query; key; value] GEMM: fp32 rows, parts aligned to a wave's 64 columns
+        return g.a_f32 && !g.b_f32 && g.qkv_D > 0 && g.qkv_D % 64 == 0 && g.N % 64 == 0 && g.ldc % 4 == 0 && g.rows_per_group > 0 && !g.resid && !g.qkv_v_pk && g.batch <= 1;
     if (g.store != STORE_ROWS && g.store != STORE_NCHW) return false;
     if (g.store == STORE_ROWS && g.rows_per_group != 0) return false;
     if (g.store == STORE_NCHW && (g.resid || g.act != ACT_NONE)) return false;

@@ -252,6 +252,7 @@ class Engine:
         with torch.cuda.device(dev):
             _lib.check(self.lib.hqt_sample(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(force_top), _ptr(force_bot),
                                            _ptr(logits), _ptr(out_top), _ptr(out_bot), C.c_void_p(stream)))
+            self._note_split(precision, stream)
         # inputs must outlive the asynchronous launches
         self._keep = (cond, noise, force_top, force_bot, rows)
         self._trust(out_top, out_bot, bound=max(self.s2.vocab_top, self.s2.vocab_bot))     # the sampler only writes ids inside the vocabulary
@@ -303,6 +304,7 @@ class Engine:
         with torch.cuda.device(dev):
             _lib.check(self.lib.hqt_sample_l3(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(f[0]), _ptr(f[1]), _ptr(f[2]),
                                               _ptr(logits), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), C.c_void_p(stream)))
+            self._note_split(precision, stream)
         self._keep = (cond, noise, f, rows)
         self._trust(*outs, bound=max(self.s2.vocab_top, self.s2.vocab_bot))
         return (outs[0], outs[1], outs[2], logits) if return_logits else tuple(outs)

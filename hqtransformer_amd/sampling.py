@@ -9,13 +9,21 @@ from typing import List, Optional
 
 import torch
 
-from ._lib import PRECISION_EXACT, PRECISION_FAST
+from ._lib import PRECISION_EXACT, PRECISION_FAST, PRECISIONS
 
 
 def _seed_from_torch() -> int:
     """The reference consumes torch's global generator through ``torch.multinomial``; the Philox seed of the
     in-kernel Exp(1) noise is drawn from that same generator so ``set_seed`` keeps runs reproducible."""
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def _precision(precision: Optional[str], use_fp16: bool) -> int:
+    if precision is None:
+        return PRECISION_FAST if use_fp16 else PRECISION_EXACT
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+    return PRECISIONS[precision]
 
 
 @torch.no_grad()
@@ -38,7 +46,8 @@ def sampling_ihqgpt(model,
                     use_graph: bool = True,
                     lane: int = 0,
                     row_seeds=None,
-                    row_offsets=None):
+                    row_offsets=None,
+                    precision: Optional[str] = None):
     """Returns ``(codes_top int64 [B, max_seq_len], codes_bot int64 [B, max_seq_len, 4])`` on the model's GPU.
 
     ``model`` is ``ImageGPT2.stage2``.  ``cond``: python int (class id, repeated for every candidate), an
@@ -50,7 +59,10 @@ def sampling_ihqgpt(model,
     identity) for bit-reproducible runs; ``sample_offset``/``seed`` for sharded batches; ``lane`` selects one of
     several workspaces over the same weights (one per batch in flight, see ``hqtransformer_amd.pipeline``);
     ``row_seeds`` / ``row_offsets`` (B entries each): merged steps -- row b draws what global row ``row_offsets[b]`` of a call
-    seeded ``row_seeds[b]`` would draw, so several independent calls can share one pass over the weights.
+    seeded ``row_seeds[b]`` would draw, so several independent calls can share one pass over the weights;
+    ``precision`` ('exact' | 'fast' | 'split') overrides ``use_fp16``: 'split' = the fp32 launch sequence with every nn.Linear on the
+    matrix cores (fp16 hi / lo operands, three MFMAs per term, fp32 accumulation): code sequences bit-identical to 'exact' wherever the
+    draw is well-conditioned, at several times its speed.
     """
     spec = model.spec
     if model.use_txt_cond:
@@ -82,7 +94,7 @@ def sampling_ihqgpt(model,
     eng = model.engine(B, max_seq_len, lane)
     if seed is None and noise is None:
         seed = _seed_from_torch()
-    return eng.sample(B, cond, max_seq_len, precision=PRECISION_FAST if use_fp16 else PRECISION_EXACT,
+    return eng.sample(B, cond, max_seq_len, precision=_precision(precision, use_fp16),
                       top_k=(top_k_top, top_k_bot), top_p=(top_p_top, top_p_bot), temperature=softmax_temperature,
                       noise=noise, seed=seed or 0, sample_offset=sample_offset, force_top=force_top, use_graph=use_graph,
                       row_seeds=row_seeds, row_offsets=row_offsets)
@@ -104,7 +116,8 @@ def sampling_hqtransformer(model,
                            use_graph: bool = True,
                            lane: int = 0,
                            row_seeds=None,
-                           row_offsets=None):
+                           row_offsets=None,
+                           precision: Optional[str] = None):
     """Counterpart of ``hqvae.utils.sampling.sampling_hqtransformer`` (sampling.py:240-307) for the three-level
     HQTransformer: returns ``[codes0 int64 [B, L], codes1 [B, L, 4], codes2 [B, L, 16]]`` on the model's GPU.
     ``top_k`` / ``top_p`` / ``softmax_temperature`` are per-level lists (None = no cut-off); ``cond`` as in
@@ -135,7 +148,7 @@ def sampling_hqtransformer(model,
     eng = model.engine(B, max_seq_len, lane)
     if seed is None and noise is None:
         seed = _seed_from_torch()
-    return list(eng.sample3(B, cond, max_seq_len, precision=PRECISION_FAST if use_fp16 else PRECISION_EXACT, top_k=top_k, top_p=top_p,
+    return list(eng.sample3(B, cond, max_seq_len, precision=_precision(precision, use_fp16), top_k=top_k, top_p=top_p,
                             temperature=softmax_temperature, noise=noise, seed=seed or 0, sample_offset=sample_offset, use_graph=use_graph,
                             row_seeds=row_seeds, row_offsets=row_offsets))
 

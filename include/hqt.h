@@ -46,7 +46,12 @@ enum { HQT_EMB_TRANSFORMER1 = 0, HQT_EMB_REDUCE = 1 };
  * convolutions on the matrix cores with every fp32 operand carried as two fp16 values (hi, lo * 2^11): three
  * v_mfma_f32_16x16x32_f16 per product term, fp32 accumulation -- fp32-accurate (2^-22 per operand), what the reference's
  * fp32 decode (measure_throughput/__main__.py:108-113, outside autocast) computes up to summation order, at matrix-core
- * speed; layers whose shapes the split kernels do not take run the EXACT kernels. */
+ * speed; layers whose shapes the split kernels do not take run the EXACT kernels.
+ * SPLIT on the stage-2 entry points (hqt_sample / hqt_sample_l3, round 4): the EXACT launch sequence -- fp32 activations, LayerNorm,
+ * attention, softmax and sampler exactly as EXACT -- with every nn.Linear (stage2/layers.py:73-85,190,313-315; the heads) on the matrix
+ * cores: the fp32 activation rows are split into fp16 hi / lo while their tile is staged, the weights travel as fp16 hi / lo planes,
+ * three v_mfma_f32_32x32x16_f16 per product term.  Code sequences are bit-identical to EXACT (and to the reference's CPU path) wherever
+ * the draw is well-conditioned, logits within 2e-4; hqt_range_check applies as for stage 1. */
 enum { HQT_PRECISION_EXACT = 0, HQT_PRECISION_FAST = 1, HQT_PRECISION_SPLIT = 2 };
 enum { HQT_DTYPE_F32 = 0 };
 

@@ -769,7 +769,15 @@ def test_full_benchmark_model_exact_vs_oracle():
     _, _, lf = eng.sample(B, torch.from_numpy(cond), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise),
                           force_top=torch.from_numpy(want[0]), force_bot=torch.from_numpy(want[1]), return_logits=True, use_graph=True)
     gate('benchmark_model_B64.fast_logits_vs_oracle', np.abs(np_(lf) - want[2]).max(), 0.06)
-    print(f'full 12+4-layer model, B = 64: EXACT logits vs oracle {err:.2e} (std {want[2].std():.3f}), FAST {np.abs(np_(lf) - want[2]).max():.4f}')
+    # SPLIT (round 4): fp32-accurate AR loop on the matrix cores -- the same bar as EXACT: codes bit-identical, logits <= 2e-4
+    from hqtransformer_amd._lib import PRECISION_SPLIT
+    for graph in (False, True):
+        st, sb, ls = eng.sample(B, torch.from_numpy(cond), n, precision=PRECISION_SPLIT, noise=torch.from_numpy(noise), return_logits=True, use_graph=graph)
+        serr = np.abs(np_(ls) - want[2]).max()
+        assert serr <= LOGIT_TOL, f'SPLIT logits of the full model differ from the oracle by {serr}'
+        assert (np_(st) == want[0]).all() and (np_(sb) == want[1]).all(), 'SPLIT codes of the full model differ from the oracle'
+    eng.range_check()
+    print(f'full 12+4-layer model, B = 64: EXACT logits vs oracle {err:.2e} (std {want[2].std():.3f}), SPLIT {serr:.2e}, FAST {np.abs(np_(lf) - want[2]).max():.4f}')
 
 
 def test_text_prefill_at_the_cc15m_shape_vs_oracle():

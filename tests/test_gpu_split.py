@@ -250,13 +250,30 @@ np.save(sys.argv[1], px.cpu().numpy())
     assert not np.array_equal(out['phase'], out['nine']), 'HQT_SPLIT_UP=0 did not change the kernel'
 
 
-def test_split_is_rejected_by_the_sampler():
+def test_split_sampler_tiny_fixture_bit_exact():
+    """HQT_PRECISION_SPLIT on the stage-2 entry point (round 4): the EXACT launch sequence with every nn.Linear on the matrix cores
+    (fp32 activation rows split into fp16 hi / lo while staged, fp16 hi / lo weight planes, three MFMAs per term) -- the reference
+    fixture G4 (codes of 64 positions under three sampler settings) must come out bit for bit, logits within 2e-4."""
+    import json
     from tests.helpers import stage2_from_fixture
     fx = load('g4_tiny_cls.npz')
     spec, weights = stage2_from_fixture(fx)
-    e = Engine(spec, None, dev(), 2, 8)
+    B, n = int(fx['B']), int(fx['n_steps'])
+    e = Engine(spec, None, dev(), B, n)
     e.load(stage2=weights)
     e.finalize()
-    from hqtransformer_amd._lib import HqtError
-    with pytest.raises(HqtError):
-        e.sample(2, torch.tensor([1, 2]), 4, precision=PRECISION_SPLIT)
+    noise = torch.from_numpy(synth.exp_noise(int(fx['noise_seed']), n, B, spec.vocab_top))
+    e.timing(True)
+    e.timing_reset()
+    for si, (tk, tp, T) in enumerate(json.loads(str(fx['settings']))):
+        for graph in (False, True):
+            ct, cb, lg = e.sample(B, torch.full((B,), 7), n, precision=PRECISION_SPLIT, top_k=tk, top_p=tp, temperature=T, noise=noise,
+                                  return_logits=True, use_graph=graph)
+            assert (ct.cpu().numpy() == fx[f'codes_top_{si}']).all() and (cb.cpu().numpy() == fx[f'codes_bot_{si}']).all(), (si, graph)
+            scale = np.array([T[0]] + [T[1]] * 4, np.float32)[None, :, None, None]
+            np.testing.assert_allclose(lg.cpu().numpy()[fx['keep_steps']] / scale, fx[f'logits_{si}'], atol=2e-4, rtol=0)
+    v = {k: c[0] for k, c in e.timing_report().items() if k.startswith('variant:')}
+    e.timing(False)
+    assert any(k.startswith('variant:split_gemm:') for k in v), v
+    assert not any(k.startswith('variant:gemm_generic_f32:') for k in v), f'fp32 vector-ALU GEMMs ran inside a SPLIT call: {v}'
+    e.range_check()

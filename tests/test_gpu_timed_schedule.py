@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from hqtransformer_amd import synth
-from hqtransformer_amd._lib import POLICY_LATENCY, POLICY_THROUGHPUT, PRECISION_EXACT, PRECISION_FAST
+from hqtransformer_amd._lib import POLICY_LATENCY, POLICY_THROUGHPUT, PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT
 from hqtransformer_amd.config import get_base_config, merge
 from hqtransformer_amd.engine import Engine
 from hqtransformer_amd.models import ImageGPT2
@@ -50,6 +50,11 @@ def test_merged_pass_kernels_vs_oracle_at_imagenet_width(B, n):
     ct, cb, lg = eng.sample(B, tc, n, precision=PRECISION_EXACT, noise=tn, return_logits=True, use_graph=False)
     assert np.abs(np_(lg) - want[2]).max() <= LOGIT_TOL
     assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all()
+    # SPLIT AR (fp32-accurate on the matrix cores, round 4) at the same merged-pass rows: the EXACT bar
+    st, sb, ls = eng.sample(B, tc, n, precision=PRECISION_SPLIT, noise=tn, return_logits=True, use_graph=True)
+    assert np.abs(np_(ls) - want[2]).max() <= LOGIT_TOL
+    assert (np_(st) == want[0]).all() and (np_(sb) == want[1]).all()
+    eng.range_check()
     ft, fb = torch.from_numpy(want[0]), torch.from_numpy(want[1])
     eng.timing(True)
     eng.timing_reset()
