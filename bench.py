@@ -75,6 +75,7 @@ def parse():
                    'With only one of the two given the other defaults to --merge 8 / --inflight 3')
     p.add_argument('--overlap', action='store_true', help='EXPERIMENT: run the decode of batch k on a second stream underneath the AR '
                    'loop of batch k+1 (measured slower on MI355X: the decoder starves the latency-bound AR kernels)')
+    p.add_argument('--skip-decode', action='store_true', help='DEBUG ONLY (counter collection of the AR kernels at large row counts): no decode; the line is marked invalid')
     p.add_argument('--positions', type=int, default=0, help='DEBUG ONLY (counter collection): sample this many top positions '
                    'instead of the full grid; the resulting line is marked invalid')
     return p.parse_args()
@@ -339,24 +340,28 @@ def main():
     samp_kw = (dict(top_k=[tk] * 3, top_p=[tp] * 3, softmax_temperature=[T] * 3) if three else
                dict(top_k_top=tk, top_p_top=tp, top_k_bot=tk, top_p_bot=tp, softmax_temperature=[T, T]))
 
-    def sample_codes(i, graph, nb=None, use_fast=None):
-        """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels).  nb: rows of the pass (default: one step's batch)."""
+    def sample_codes(i, graph, nb=None, ar_prec=None):
+        """(codes0, rest): rest = codes_bot (two levels) or [codes1, codes2] (three levels).  nb: rows of the pass (default: one step's batch);
+        ar_prec: 'fast' | 'exact' | 'split' (default: --precision)."""
         nb = nb or B
-        fast = args.precision == 'fast' if use_fast is None else use_fast
+        ar_prec = ar_prec or args.precision
+        fast = ar_prec == 'fast'
         cond = cond_of(i)
         if txt_cond and nb > B:          # a text batch is as long as its prompt tensor (sampling.py:187-190): a pass of nb rows = nb / B prompt batches
             cond = torch.cat([cond_of(i + j) for j in range(nb // B)], 0)
         if three:
             c = sampling_hqtransformer(model.stage2, num_candidates=nb, cond=cond, top_k=[tk] * 3, top_p=[tp] * 3,
                                        softmax_temperature=[T] * 3, use_fp16=fast, is_tqdm=False, max_seq_len=n_pos, seed=1 + i,
-                                       sample_offset=rank * B, use_graph=graph)
+                                       sample_offset=rank * B, use_graph=graph, precision=ar_prec)
             return c[0], c[1:]
         return sampling_ihqgpt(model.stage2, num_candidates=nb, cond=cond, top_k_top=tk, top_p_top=tp, top_k_bot=tk,
                                top_p_bot=tp, softmax_temperature=[T, T], use_fp16=fast, is_tqdm=False, max_seq_len=n_pos,
-                               model_stage1=None, seed=1 + i, sample_offset=rank * B, use_graph=graph)
+                               model_stage1=None, seed=1 + i, sample_offset=rank * B, use_graph=graph, precision=ar_prec)
 
     def decode(ct, cb, m=None, prec=None):
         prec = prec or dec_prec
+        if args.skip_decode:
+            return torch.zeros((ct.shape[0], s1.out_ch, 8, 8), dtype=torch.float32, device=dev)
         if three:
             return (m or model).stage1.decode_sequences([ct] + list(cb), precision=prec, clamp01=True)
         if n_pos < n_full:      # debug runs: pad the code grids so the decoder still sees full-size inputs
@@ -453,11 +458,11 @@ def main():
     sample_codes(0, not args.no_graph)  # untimed: the policy change re-captures lane 0's graph; keep that out of the pass below
 
     # ---- reference pass: the same steps one at a time on one lane (the reference harness's order), with per-phase events
-    def one_at_a_time(n, use_fast, prec, gather=True):
+    def one_at_a_time(n, ar_prec, prec, gather=True):
         """n batch-B steps strictly one after the other on one lane -- what measure_throughput/__main__.py:84-116 does -- timed between
         barriers, AR / decode split by events.  Returns the record (whole-job images/s, ms per step, phase ms)."""
         for w in range(2):                          # untimed: graph capture / workspace of this precision
-            decode(*sample_codes(w, not args.no_graph, use_fast=use_fast), prec=prec)
+            decode(*sample_codes(w, not args.no_graph, ar_prec=ar_prec), prec=prec)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n)]
         keep = []
         barrier()
@@ -466,7 +471,7 @@ def main():
             i = args.warmup + k
             with torch.cuda.stream(s_ar):
                 ev[3 * k].record()
-                ct, cb = sample_codes(i, not args.no_graph, use_fast=use_fast)
+                ct, cb = sample_codes(i, not args.no_graph, ar_prec=ar_prec)
                 ev[3 * k + 1].record()
             with torch.cuda.stream(s_dec):
                 s_dec.wait_event(ev[3 * k + 1])
@@ -490,7 +495,7 @@ def main():
                 'phase_ms': {'ar': round(a_ms, 3), 'decode': round(d_ms, 3)}}
 
     n_serial = args.steps if (inflight == 1 and merge == 1) else min(args.steps, 3)
-    serial = one_at_a_time(n_serial, fast, dec_prec)
+    serial = one_at_a_time(n_serial, args.precision, dec_prec)
     serial['note'] = 'the same steps one at a time on one lane (the reference harness order: measure_throughput/__main__.py:84-116)'
     ar_ms, dec_ms = serial['phase_ms']['ar'], serial['phase_ms']['decode']
     # ---- the arithmetic whose code sequences are BIT-EXACT against the reference's CPU path (fp32 AR loop; the decode stays fp32-accurate):
@@ -498,27 +503,34 @@ def main():
     exact_mode = None
     if fast and not args.no_exact_mode and not args.positions:
         xprec = dec_prec if dec_prec != 'fast' else 'split'
-        ex = one_at_a_time(3, False, xprec, gather=False)
-        ex['precision'] = {'ar': 'EXACT: fp32 weights / activations / accumulation on the vector ALUs -- codes bit-identical to the oracle (tests/test_gpu_timed_schedule.py)',
-                           'decode': xprec}
-        ex['note'] = '3 batch-%d steps one at a time on one lane' % B
-        exact_mode = {'like_for_like': ex}
-        if merge > 1:
-            m_ex = min(merge, 16)
-            xp = InflightSampler(model, lanes=1, device=dev, merge=m_ex)
-            for rnd in range(2):                    # first round untimed (capture at this row count)
-                barrier()
-                t0 = time.perf_counter()
-                for j in range(m_ex):
-                    xp.submit(B, cond_of(j), seed=4000 + j, max_seq_len=n_pos, use_fp16=False, sample_offset=rank * B,
-                              use_graph=not args.no_graph, after=None, precision=xprec, **samp_kw)
-                xp.drain()
-                barrier()
-                el = time.perf_counter() - t0
-            exact_mode['merged'] = {'value': round(world * B * m_ex / el, 2), 'ms_per_step': round(1000 * el / m_ex, 3), 'steps': m_ex,
-                                    'rows_per_pass': m_ex * B, 'lanes': 1,
-                                    'note': f'one pass of {m_ex} merged batch-{B} steps ({m_ex * B} rows), fp32 AR loop + {xprec} decode, one lane'}
-            del xp
+        what = {'exact': 'EXACT: fp32 weights / activations / accumulation on the vector ALUs -- codes bit-identical to the oracle (tests/test_gpu_timed_schedule.py)',
+                'split': 'SPLIT: the EXACT launch sequence with every nn.Linear on the matrix cores (fp32 activations split into fp16 hi / lo while staged, fp16 hi / lo weight planes, '
+                         '3 MFMAs per term, fp32 accumulation); fp32 LayerNorm / attention / softmax / sampler -- codes bit-identical to the oracle, logits <= 2e-4 (same tests)'}
+        exact_mode = {}
+        for arp in ('split', 'exact'):
+            ex = one_at_a_time(3, arp, xprec, gather=False)
+            ex['precision'] = {'ar': what[arp], 'decode': xprec}
+            ex['note'] = '3 batch-%d steps one at a time on one lane' % B
+            rec = {'like_for_like': ex}
+            if merge > 1:
+                m_ex = merge if arp == 'split' else min(merge, 16)
+                xp = InflightSampler(model, lanes=1, device=dev, merge=m_ex)
+                for rnd in range(2):                    # first round untimed (capture at this row count)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for j in range(m_ex):
+                        xp.submit(B, cond_of(j), seed=4000 + j, max_seq_len=n_pos, use_fp16=False, sample_offset=rank * B,
+                                  use_graph=not args.no_graph, after=None, precision=xprec, ar_precision=arp, **samp_kw)
+                    xp.drain()
+                    barrier()
+                    el = time.perf_counter() - t0
+                rec['merged'] = {'value': round(world * B * m_ex / el, 2), 'ms_per_step': round(1000 * el / m_ex, 3), 'steps': m_ex,
+                                 'rows_per_pass': m_ex * B, 'lanes': 1,
+                                 'note': f'one pass of {m_ex} merged batch-{B} steps ({m_ex * B} rows), {arp} AR loop + {xprec} decode, one lane'}
+                del xp
+            exact_mode[arp] = rec
+        exact_mode['note'] = ('the arithmetic whose code sequences are bit-identical to the reference CPU path (north_star): `split` = fp32-accurate on the matrix cores, '
+                              '`exact` = fp32 FMA chains on the vector ALUs; same workload, same decode; the headline `value` runs the tolerance-gated bf16 AR loop')
     elapsed = elapsed_lanes
 
     out = None
@@ -570,8 +582,8 @@ def main():
         }
         if exact_mode is not None:
             out['exact_mode'] = exact_mode
-        if n_pos < n_full:
-            out['INVALID'] = f'debug run: {n_pos} of {n_full} top positions sampled'
+        if n_pos < n_full or args.skip_decode:
+            out['INVALID'] = f'debug run: {n_pos} of {n_full} top positions sampled' + (', decode skipped' if args.skip_decode else '')
 
     # ---- roofline: per-launch HIP-event timers inside libhqt, un-graphed pass, rank 0 only
     if rank == 0 and not args.no_roofline:

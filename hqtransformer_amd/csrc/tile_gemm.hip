@@ -241,9 +241,12 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
             for (int i = 0; i < MBW; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[SET][j], af[SET][i], acc[j][i], 0, 0, 0);   // D rows = n, cols = m
     };
     auto wait_stage = [&](int younger) {                          // all but the `younger` most recent stages of this wave's DMA have landed
-        if (NSTAGE >= 4 && younger >= 3 && CPW * 3 < 64) wait_vmcnt<(NSTAGE >= 4 && CPW * 3 < 64) ? CPW * 3 : 0>();
-        else if (NSTAGE >= 3 && younger >= 2 && CPW * 2 < 64) wait_vmcnt<(NSTAGE >= 3 && CPW * 2 < 64) ? CPW * 2 : 0>();
-        else if (NSTAGE >= 2 && younger >= 1) wait_vmcnt<CPW>();
+        constexpr int MAXY = (63 / CPW) < (NSTAGE - 1) ? (63 / CPW) : (NSTAGE - 1);        // vmcnt is a 6-bit immediate
+        if (MAXY >= 5 && younger >= 5) wait_vmcnt<MAXY >= 5 ? CPW * 5 : 0>();
+        else if (MAXY >= 4 && younger >= 4) wait_vmcnt<MAXY >= 4 ? CPW * 4 : 0>();
+        else if (MAXY >= 3 && younger >= 3) wait_vmcnt<MAXY >= 3 ? CPW * 3 : 0>();
+        else if (MAXY >= 2 && younger >= 2) wait_vmcnt<MAXY >= 2 ? CPW * 2 : 0>();
+        else if (MAXY >= 1 && younger >= 1) wait_vmcnt<CPW>();
         else wait_vmcnt<0>();
     };
     const bool early = NW < 8 || wave < NW / 2 || HQT_TILE_STAGGER == 0;
@@ -545,6 +548,11 @@ typedef TileGeom<2, 2, 2, 2, 2, 3> Tile128;
 // 128 x 128 (qkv: 144) -- fewer workgroups than the chip has CUs, each walking K alone on its CU at the latency-bound pace of a single
 // ring; halving the row tile doubles the workgroups for 1.5x the LDS-DMA bytes per FLOP, which these shapes have to spare.
 typedef TileGeom<2, 2, 1, 2, 2, 3> Tile64;
+// 64 x 128 with EIGHT waves (32 x 32 each), stages of 64 k (24 KiB), two workgroups per CU: launches of about one workgroup per CU
+// (640-row passes: 360 tiles).  In-kernel stamps put a lone 4-wave workgroup's stage at ~650 cycles against 128-256 of MFMA work whatever
+// the ring depth (6 stages in flight instead of 2 measured within 1 %: profiles/r04_tile_variants.txt) -- what paces it is the ISSUE of its
+// LDS-DMA pieces, ~150 cycles per 1-KiB piece and wave; eight waves issue the same pieces twice as fast.
+typedef TileGeom<2, 4, 1, 1, 4, 3> Tile64W8;
 
 template <class G, int STORE, bool DLN, typename TC>
 static hipError_t launch_tile_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
@@ -586,9 +594,14 @@ bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
 TilePlan tile_gemm_plan(const GemmArgs& g) {
     constexpr int max_s = 8;
     static const int max_geom = getenv("HQT_TILE_GEOM") ? atoi(getenv("HQT_TILE_GEOM")) : 1;         // A/B runs: 0 = 128 x 128 tiles only
+    static const int w8 = getenv("HQT_TILE_W8") ? atoi(getenv("HQT_TILE_W8")) : 1;                   // A/B runs: 0 = 4-wave 64 x 128 tiles
     TilePlan p{0, Tile128::BM, Tile128::BN, 1};
     const int KS = g.K / 16, tiles = ((g.M + p.bm - 1) / p.bm) * (g.N / p.bn);
-    if (max_geom >= 1 && g.store != STORE_RESID && tiles < 256 && KS / Tile64::KU >= Tile64::NSTAGE) return TilePlan{1, Tile64::BM, Tile64::BN, 1};
+    if (max_geom >= 1 && g.store != STORE_RESID && tiles < 256 && KS / Tile64::KU >= Tile64::NSTAGE) {
+        const int t64 = ((g.M + Tile64::BM - 1) / Tile64::BM) * (g.N / Tile64::BN);
+        if (w8 && t64 <= 512 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE) return TilePlan{2, Tile64::BM, Tile64::BN, 1};
+        return TilePlan{1, Tile64::BM, Tile64::BN, 1};
+    }
     if (g.store == STORE_RESID && g.K >= 3072 && tiles < 256) {
         for (int S : {8, 6, 4, 3, 2})
             if (S <= max_s && tiles * S <= 576 && KS % (Tile128::KU * S) == 0 && KS / S / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = S; break; }
@@ -600,6 +613,7 @@ hipError_t launch_tile_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int 
     (void)a_dt;
     if (p.geom == 0) return launch_tile_g<Tile128>(g, wpk, c_dt, p.S, slabs, st);
     if (p.geom == 1) return launch_tile_g<Tile64>(g, wpk, c_dt, p.S, slabs, st);
+    if (p.geom == 2) return launch_tile_g<Tile64W8>(g, wpk, c_dt, p.S, slabs, st);
     return hipErrorInvalidValue;
 }
 
@@ -634,6 +648,8 @@ static hipError_t configure_g() {
     return hipSuccess;
 }
 hipError_t tile_gemm_configure() {
-    const hipError_t e = configure_g<Tile128>();
-    return e != hipSuccess ? e : configure_g<Tile64>();
+    hipError_t e = configure_g<Tile128>();
+    if (e == hipSuccess) e = configure_g<Tile64>();
+    if (e == hipSuccess) e = configure_g<Tile64W8>();
+    return e;
 }

@@ -108,6 +108,14 @@ class _Stage:
         self.load_state_dict(sd, strict=strict)
         print(f'{path} successfully restored..')
 
+    def range_check(self) -> None:
+        """SPLIT precision carries fp32 activations as fp16 hi / lo pairs: an activation that is NaN or beyond 65504 invalidates the call
+        that met it (include/hqt.h: hqt_range_check).  Waits for the pending SPLIT calls of every lane of this stage and raises HqtError
+        if one of them did; a no-op (no synchronisation) when no SPLIT call is pending."""
+        if self._engine is not None:
+            for e in [self._engine] + list(self.__dict__.get('_lanes', {}).values()):
+                e.range_check()
+
     def _need_gpu(self):
         if self._device.type != 'cuda':
             raise _lib.HqtLibraryError('the model is on the CPU: call .to("cuda") first (hqtransformer_amd has no CPU compute path)')
@@ -191,15 +199,6 @@ class HQVAEStage1(_Stage):
             e.finalize()
             self._engine = e
         return self._lane(e, lane)
-
-    def range_check(self) -> None:
-        """SPLIT precision carries activations as fp16 hi / lo planes: an activation that is NaN or beyond 65504 invalidates the call
-        that met it (include/hqt.h: hqt_range_check).  Waits for the pending SPLIT calls of every lane and raises HqtError if one
-        of them did.  ``decode_code`` / ``encode`` / ``get_codes`` / ``forward`` call it themselves; ``decode_sequences`` (the
-        asynchronous pipeline primitive) leaves it to its caller (``InflightSampler.drain``, the drivers)."""
-        if self._engine is not None:
-            for e in [self._engine] + list(self.__dict__.get('_lanes', {}).values()):
-                e.range_check()
 
     def decode_code(self, code_t, code_b: Optional[torch.Tensor] = None, precision: Optional[str] = None,
                     clamp01: bool = False, lane: int = 0, check_range: bool = True) -> torch.Tensor:

@@ -138,6 +138,9 @@ class InflightSampler:
                 after=None, phase_events=None, order_after_current: bool = True, **sample_kw):
         lane = self.k % self.n
         self.k += 1
+        # `ar_precision` ('exact' | 'fast' | 'split', optional, travels with the sampler settings): arithmetic of the AR loop, overriding
+        # use_fp16 (sampling_ihqgpt's `precision`; the `precision` of this method is the DECODE arithmetic)
+        ar_precision = sample_kw.pop('ar_precision', None)
         st = self.streams[lane]
         caller = torch.cuda.current_stream(self.device)
         # order the lane after whatever the caller's stream has queued (inputs; earlier direct use of lane 0's engine):
@@ -156,11 +159,11 @@ class InflightSampler:
             three = getattr(self.model.stage2.spec, 'levels', 2) == 3
             if three:                                # HQTransformer: (codes0, [codes1, codes2]) keeps the 4-tuple shape of the result
                 codes = sampling_hqtransformer(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
-                                               use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, **sample_kw)
+                                               use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, precision=ar_precision, **sample_kw)
                 ct, cb = codes[0], codes[1:]
             else:
                 ct, cb = sampling_ihqgpt(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
-                                         use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, **sample_kw)
+                                         use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, precision=ar_precision, **sample_kw)
             if phase_events is not None:
                 phase_events[1].record(st)
             px = None
@@ -194,3 +197,4 @@ class InflightSampler:
             cur.wait_stream(st)
             st.synchronize()
         self.model.stage1.range_check()          # SPLIT decodes: an activation outside the fp16 range invalidates the pass (raises)
+        self.model.stage2.range_check()          # ... and SPLIT AR passes (ar_precision='split')

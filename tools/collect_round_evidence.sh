@@ -1,46 +1,46 @@
 #!/bin/bash
-# Everything profiles/r03_* is made of, in one GPU-box call (outputs under gpurun_out/r03/; copy what is to be judged into profiles/).
+# Everything profiles/r04_* is made of, in one GPU-box call (outputs under gpurun_out/r03/; copy what is to be judged into profiles/).
 #   gpurun --timeout 3300 -- 'bash tools/collect_round_evidence.sh'
 set -u
-R=r03
+R=r04
 O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-PMCRUN="python3 bench.py --batch 512 --merge 1 --inflight 1 --positions 2 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph"
-# ---- the default line, and the same kernels one lane at a time under the profiler (the per-kernel averages the roofline record must agree with)
-timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-# the driver's own invocation (K = 20: the schedule rule gives 2 lanes x passes of 10 steps)
+# (the decoder runs 64-image chunks whatever the pass: its counters come from the 640-row run; the 2048-row run skips the decode -- 32 chunks of it would not fit a counter pass)
+pmcrun() { echo "python3 bench.py --batch $1 --merge 1 --inflight 1 --positions 2 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph --no-exact-mode $([ $1 -gt 1024 ] && echo --skip-decode)"; }
+# ---- the driver's own invocation FIRST (K = 20: 2 lanes x passes of 10 steps = 640 rows), plain and under the profiler: the EXACT command
 timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_steps20.json 2> $O/bench_driver_steps20.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --inflight 1 --merge 32 --steps 64 --warmup 8 --no-cpu-baseline > $O/bench_one_lane_under_rocprof.json 2> $O/bench_one_lane_under_rocprof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/statsd -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_steps20_under_rocprof.json 2> $O/bench_driver_steps20_under_rocprof.err
+python tools/prof_summary.py $O/statsd 70 > $O/kernel_stats_driver_steps20.txt
+cp $(find $O/statsd -name "*kernel_stats.csv" | head -1) $O/kernel_stats_driver_steps20.csv
+rm -rf $O/statsd
+# ---- the default line (K = 96: 2 lanes x passes of 32 steps = 2048 rows), and the same kernels one lane at a time under the profiler
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --inflight 1 --merge 32 --steps 64 --warmup 8 --no-cpu-baseline --no-exact-mode > $O/bench_one_lane_under_rocprof.json 2> $O/bench_one_lane_under_rocprof.err
 python tools/prof_summary.py $O/stats1 60 > $O/kernel_stats_one_lane_merge32.txt
 cp $(find $O/stats1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_one_lane_merge32.csv
 rm -rf $O/stats1
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -- python3 bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.json 2> $O/bench_default_under_rocprof.err
-python tools/prof_summary.py $O/stats3 60 > $O/kernel_stats_bench_default.txt
-rm -rf $O/stats3
-# ---- counters: separate passes over a bounded run of the same 512-row kernels
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- $PMCRUN > /dev/null 2> $O/pmc_$c.err
-  python tools/pmc_summary.py $O/pmc_$c > $O/pmc_${c}_rows512_positions2.txt
-  rm -rf $O/pmc_$c
+# ---- counters: separate passes over a bounded run (2 positions + the decode) of the kernels AT THE ROWS OF THE TIMED PASSES: 640 (driver) and 2048 (default)
+rm -f $O/pmc_latest.json
+for rows in 640 2048; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- $(pmcrun $rows) > /dev/null 2> $O/pmc_${c}_$rows.err
+    python tools/pmc_summary.py $O/pmc_$c > $O/pmc_${c}_rows${rows}_positions2.txt
+    rm -rf $O/pmc_$c
+  done
+  python tools/pmc_traffic.py $O/pmc_FETCH_SIZE_rows${rows}_positions2.txt $O/pmc_WRITE_SIZE_rows${rows}_positions2.txt $O/pmc_latest.json $rows
+  timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- $(pmcrun $rows) > /dev/null 2> $O/pmc_mfma_$rows.err
+  python tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma_raw.txt
+  python tools/pmc_mfma.py $O/pmc_mfma_raw.txt $O/pmc_mfma_util_rows${rows}_positions2.txt > /dev/null
+  rm -rf $O/pmc_mfma $O/pmc_mfma_raw.txt
 done
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- $PMCRUN > /dev/null 2> $O/pmc_mfma.err
-python tools/pmc_summary.py $O/pmc_mfma > $O/pmc_mfma_raw.txt
-python tools/pmc_mfma.py $O/pmc_mfma_raw.txt $O/pmc_mfma_util_rows512_positions2.txt > /dev/null
-rm -rf $O/pmc_mfma
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE_rows512_positions2.txt $O/pmc_WRITE_SIZE_rows512_positions2.txt $O/pmc_latest.json
-# counters of a 2048-row pass (what a merge-32 schedule runs): the tile GEMMs where they are MFMA-bound
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma2k -- python3 bench.py --batch 2048 --merge 1 --inflight 1 --positions 1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph --decode-precision fast > /dev/null 2> $O/pmc_mfma2k.err
-python tools/pmc_summary.py $O/pmc_mfma2k > $O/pmc_mfma2k_raw.txt
-python tools/pmc_mfma.py $O/pmc_mfma2k_raw.txt $O/pmc_mfma_util_rows2048_positions1.txt > /dev/null
-rm -rf $O/pmc_mfma2k $O/pmc_mfma2k_raw.txt
 # ---- other schedules and configurations of the same build
-timeout 600 python bench.py --merge 8 --inflight 3 --no-cpu-baseline > $O/bench_merge8_lanes3.json 2>/dev/null
-timeout 600 python bench.py --merge 48 --inflight 2 --no-cpu-baseline --no-roofline > $O/bench_merge48_lanes2.json 2>/dev/null
-timeout 600 python bench.py --merge 1 --inflight 3 --no-cpu-baseline --no-roofline > $O/bench_merge1_lanes3.json 2>/dev/null
-timeout 600 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
-timeout 600 python bench.py --sampler quality --no-cpu-baseline > $O/bench_quality_sampler.json 2>/dev/null
-timeout 600 python bench.py --decode-precision fast --no-cpu-baseline --no-roofline > $O/bench_decode_fast.json 2>/dev/null
+timeout 600 python bench.py --merge 8 --inflight 3 --no-cpu-baseline --no-exact-mode > $O/bench_merge8_lanes3.json 2>/dev/null
+timeout 600 python bench.py --merge 48 --inflight 2 --no-cpu-baseline --no-roofline --no-exact-mode > $O/bench_merge48_lanes2.json 2>/dev/null
+timeout 600 python bench.py --merge 1 --inflight 3 --no-cpu-baseline --no-roofline --no-exact-mode > $O/bench_merge1_lanes3.json 2>/dev/null
+timeout 600 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline --no-exact-mode > $O/bench_serial.json 2>/dev/null
+timeout 600 python bench.py --sampler quality --no-cpu-baseline --no-exact-mode > $O/bench_quality_sampler.json 2>/dev/null
+timeout 600 python bench.py --decode-precision fast --no-cpu-baseline --no-roofline --no-exact-mode > $O/bench_decode_fast.json 2>/dev/null
 timeout 900 python bench.py --config configs/imagenet-12l-level3.yaml --steps 48 > $O/bench_level3.json 2>/dev/null
 timeout 900 python bench.py --config configs/cc15m-12l-txt.yaml --steps 48 > $O/bench_text_cond.json 2>/dev/null
 timeout 300 python tools/bench_decode.py --precision split > $O/decode_split_batch64.json 2>/dev/null
@@ -50,8 +50,11 @@ timeout 300 python tools/bench_decoder.py --precision fast > $O/decoder_only_102
 timeout 300 python tools/bench_encode.py > $O/encode_batch64.json 2>/dev/null
 timeout 300 python tools/diag_overlap.py --rows 512 > $O/diag_overlap_rows512.json 2>/dev/null
 timeout 300 python tools/diag_overlap.py --rows 2048 --lanes 2 --passes 4 > $O/diag_overlap_rows2048.json 2>/dev/null
-timeout 300 python tools/ar_pass_time.py --rows 64 512 1024 2048 3072 --policy 1 --breakdown > $O/ar_pass_time_by_rows.json 2>/dev/null
-timeout 300 python tools/ar_pass_time.py --rows 512 --policy 1 --breakdown --by-rows > $O/ar_pass_time_rows512_per_gemm.json 2>/dev/null
+timeout 300 python tools/ar_pass_time.py --rows 64 512 640 1024 2048 3072 --policy 1 --breakdown > $O/ar_pass_time_by_rows.json 2>/dev/null
+timeout 300 python tools/ar_pass_time.py --rows 640 --policy 1 --breakdown --by-rows > $O/ar_pass_time_rows640_per_gemm.json 2>/dev/null
+for p in split exact; do timeout 400 python tools/ar_pass_time.py --rows 64 640 2048 --precision $p --reps 1 --breakdown > $O/ar_pass_time_$p.json 2>/dev/null; done
+timeout 300 python tools/split_step_probe.py > $O/split_step_probe.json 2>/dev/null
+(for d in 0 1; do HQT_TILE_W8=$d timeout 300 python tools/ar_pass_time.py --rows 512 640 --policy 1 --breakdown --by-rows; echo; done) > $O/tile_variants.txt 2>/dev/null
 # ---- micro-benchmarks
 timeout 300 tools/micro/bench_split > $O/micro_split_conv_variants.txt 2>&1
 timeout 100 tools/micro/bench_split_gemm > $O/micro_split_gemm_1x1.txt 2>&1
