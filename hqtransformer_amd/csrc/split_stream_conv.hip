@@ -6,7 +6,7 @@
 //   conv3x3_split_out16_kernel    conv_out (<= 16 output channels, NCHW store + clamp)
 // Shapes they do not take fall back to conv3x3_split_kernel (split_conv.hip), and from there to the fp32 vector-ALU kernel.
 //
-// Design, arrived at over five measured generations (tools/micro/split_generations.hip keeps the superseded kernels, DESIGN.md 5.2b
+// Design, arrived at over five measured generations (the superseded kernels: git history up to round 3; DESIGN.md 5.2b
 // what each one taught):
 //   * 4 waves per workgroup, 8 x 16 pixel tile x 128 channels, two workgroups per CU; each wave owns 128 pixels x 32 channels
 //     (8 pixel blocks x 2 channel blocks of v_mfma_f32_16x16x32_f16: 128 accumulator registers, main + cross);

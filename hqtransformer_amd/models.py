@@ -19,7 +19,7 @@ import torch
 from . import _lib, synth
 from ._lib import PRECISION_EXACT, PRECISION_FAST, PRECISIONS
 from .engine import Engine
-from .spec import (COND_CLS, COND_TXT, STAGE2_UNUSED, Stage1Spec, Stage2Spec, stage1_encoder_param_shapes, stage1_is_ignored, stage1_param_shapes,
+from .spec import (COND_CLS, COND_TXT, stage2_unused, Stage1Spec, Stage2Spec, stage1_encoder_param_shapes, stage1_is_ignored, stage1_param_shapes,
                    stage1_spec_from_config, stage2_param_shapes, stage2_spec_from_config)
 
 
@@ -156,7 +156,8 @@ class HQTransformerStage2(_Stage):
         if e is None or batch > e.max_batch or n_steps > e.max_steps:
             self._drop_engine()
             e = Engine(self.spec, None, self._device, max(batch, e.max_batch if e else 0), self.spec.ctx_len_img)
-            e.load(stage2={k: v for k, v in self._w.items() if k not in STAGE2_UNUSED})
+            unused = stage2_unused(self.spec)
+            e.load(stage2={k: v for k, v in self._w.items() if k not in unused})
             e.finalize()
             self._engine = e
         return self._lane(e, lane)

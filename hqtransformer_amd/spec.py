@@ -221,6 +221,14 @@ def stage2_param_shapes(s: Stage2Spec) -> 'OrderedDict[str, Tuple[int, ...]]':
 STAGE2_UNUSED = ('tok_emb_bot_depth.weight', 'tok_emb_depth_levels.2.weight', 'head_txt.weight', 'ln_txt.weight', 'ln_txt.bias')
 
 
+def stage2_unused(s) -> tuple:
+    """Checkpoint keys of THIS model the sampling path never reads: accepted by load_state_dict, never uploaded.  'top2mid2bot' feeds its
+    21 causal sub-steps from tok_emb_levels (hqtransformer.py:718-725), so none of its tok_emb_depth_levels tables is read
+    ([V, D] each; under 'parallel-reduce' level 2 alone is [V, 16 D] = 805 MB at V = 8192, D = 1536)."""
+    extra = tuple(f'tok_emb_depth_levels.{li}.weight' for li in range(3)) if getattr(s, 'levels', 2) == 3 and getattr(s, 'depth_decoding', '') == 'top2mid2bot' else ()
+    return STAGE2_UNUSED + extra
+
+
 @dataclass
 class DecoderLayer:
     """One step of ``Decoder.forward`` (layers.py:385-410) in execution order."""

@@ -3,7 +3,6 @@
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/micro/bench_split.hip -o tools/micro/bench_split
 #include "../../hqtransformer_amd/csrc/split_conv.hip"
 #include "../../hqtransformer_amd/csrc/split_stream_conv.hip"
-#include "split_generations.hip"
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -19,48 +18,6 @@ static float run(const GemmArgs& g, hipStream_t st, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     CK(hipEventRecord(a, st));
     for (int r = 0; r < reps; ++r) k<<<grid, PC ? 512 : 256, split_conv3_lds(128), st>>>(g);
-    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
-    float ms; CK(hipEventElapsedTime(&ms, a, b));
-    return 1000.f * ms / reps;
-}
-
-template <int ABL>
-static float run_wide(const GemmArgs& g, hipStream_t st, int reps) {
-    const dim3 grid((g.N + 127) / 128, g.M / 256, 1);
-    auto* k = conv3x3_split_wide_kernel<false, 128, ABL>;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, split_wide_lds(128)));
-    k<<<grid, 512, split_wide_lds(128), st>>>(g);
-    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    CK(hipEventRecord(a, st));
-    for (int r = 0; r < reps; ++r) k<<<grid, 512, split_wide_lds(128), st>>>(g);
-    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
-    float ms; CK(hipEventElapsedTime(&ms, a, b));
-    return 1000.f * ms / reps;
-}
-
-template <int ABL>
-static float run_stream(const GemmArgs& g, hipStream_t st, int reps) {
-    const dim3 grid((g.N + 127) / 128, g.M / 128, 1);
-    void (*k)(GemmArgs) = conv3x3_split_stream_kernel<false, 128, ABL>;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS));
-    k<<<grid, 256, R_LDS, st>>>(g);
-    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    CK(hipEventRecord(a, st));
-    for (int r = 0; r < reps; ++r) k<<<grid, 256, R_LDS, st>>>(g);
-    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
-    float ms; CK(hipEventElapsedTime(&ms, a, b));
-    return 1000.f * ms / reps;
-}
-
-template <int ABL>
-static float run_ring(const GemmArgs& g, hipStream_t st, int reps) {
-    const dim3 grid((g.N + 127) / 128, g.M / 128, 1);
-    void (*k)(GemmArgs) = conv3x3_split_ring_kernel<ABL>;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-    k<<<grid, 256, G_LDS, st>>>(g);
-    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    CK(hipEventRecord(a, st));
-    for (int r = 0; r < reps; ++r) k<<<grid, 256, G_LDS, st>>>(g);
     CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     return 1000.f * ms / reps;
@@ -117,8 +74,8 @@ int main(int argc, char** argv) {
         }
     }
     CK(hipMemset(bias, 0, 512 * 4)); CK(hipMemset(zero, 0, 256));
-    half_t *Wfrag, *Wfrag16; float* W32;
-    CK(hipMalloc(&Wfrag, split_frag_elems(512, 512) * 2)); CK(hipMalloc(&Wfrag16, split_frag_elems(512, 512) * 2)); CK(hipMalloc(&W32, wmax * 4));
+    half_t* Wfrag16; float* W32;
+    CK(hipMalloc(&Wfrag16, split_frag_elems(512, 512) * 2)); CK(hipMalloc(&W32, wmax * 4));
     {
         std::vector<float> wf(wmax);
         unsigned x = 777u;
@@ -126,7 +83,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(W32, wf.data(), wmax * 4, hipMemcpyHostToDevice));
     }
     printf("%-22s %8s | %7s %7s %7s | %7s %7s %7s %7s | %7s %7s\n", "layer (batch 64)", "GF x3", "pc1 us", "TF eq", "pc0 us", "no-epi", "no-dma", "dma", "mfma", "pc0nodma", "pc0 mfma");
-    double tot = 0, totf = 0, tot_stream = 0, tot_ring = 0, tot_ring16 = 0, tot_up16 = 0;
+    double tot = 0, totf = 0, tot_ring16 = 0, tot_up16 = 0;
     for (const Shape& s : shapes) {
         GemmArgs g{};
         g.A = A; g.conv_taps = 9; g.H = s.res; g.W = s.res; g.Cin = s.cin; g.upsample = s.up;
@@ -137,18 +94,8 @@ int main(int argc, char** argv) {
         const float t0 = run<1, 0>(g, st, reps), p0 = run<0, 0>(g, st, reps), t1 = run<1, 1>(g, st, reps), t2 = run<1, 2>(g, st, reps),
                     t3 = run<1, 3>(g, st, reps), t4 = run<1, 4>(g, st, reps), q2 = run<0, 2>(g, st, reps), q4 = run<0, 4>(g, st, reps);
         printf("%-22s %8.1f | %7.1f %7.1f %7.1f | %7.1f %7.1f %7.1f %7.1f | %7.1f %7.1f\n", s.name, fl * 1e-9, t0, fl / t0 * 1e-6, p0, t1, t2, t3, t4, q2, q4);
-        const float w0 = run_wide<0>(g, st, reps), w1 = run_wide<1>(g, st, reps), w2 = run_wide<2>(g, st, reps), w3 = run_wide<3>(g, st, reps), w4 = run_wide<4>(g, st, reps), w6 = run_wide<6>(g, st, reps), w5 = run_wide<5>(g, st, reps);
-        printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7.1f %7.1f | contiguous-src %7.1f stagger %7.1f\n", "   wide tile 16x16", "", w0, fl / w0 * 1e-6, "", w1, w2, w3, w4, w6, w5);
         {
-            CK(launch_pack_split_frag(W32, Wfrag, s.cout, s.cin, st));
-            GemmArgs gs = g; gs.Bw_frag = Wfrag;
-            const float r0 = run_stream<0>(gs, st, reps), r1 = run_stream<1>(gs, st, reps), r2 = run_stream<2>(gs, st, reps), r4 = run_stream<4>(gs, st, reps);
-            printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f\n", "   stream (1 wave/simd)", "", r0, fl / r0 * 1e-6, "", r1, r2, "", r4);
-            tot_stream += r0;
-            const float g0 = run_ring<0>(gs, st, reps), g1 = run_ring<1>(gs, st, reps), g2 = run_ring<2>(gs, st, reps), g4 = run_ring<4>(gs, st, reps);
-            const float g5 = run_ring<5>(gs, st, reps), g6 = run_ring<6>(gs, st, reps), g7 = run_ring<7>(gs, st, reps), g8 = run_ring<8>(gs, st, reps);
-            printf("%-22s %8s | %7.1f %7.1f %7s | %7.1f %7.1f %7s %7.1f | patch reads only %7.1f (no barrier %7.1f, hi plane only %7.1f) filter loads only %7.1f\n", "   ring (filters 5 k-steps ahead)", "", g0, fl / g0 * 1e-6, "", g1, g2, "", g4, g5, g7, g8, g6);
-            tot_ring += g0;
+            GemmArgs gs = g;
             CK(launch_pack_split_frag16(W32, Wfrag16, s.cout, s.cin, st));
             GemmArgs gh = gs; gh.Bw_frag16 = Wfrag16;
             const float h0 = run_ring16<0>(gh, st, reps), h1 = run_ring16<1>(gh, st, reps), h2 = run_ring16<2>(gh, st, reps), h4 = run_ring16<4>(gh, st, reps);
@@ -165,19 +112,8 @@ int main(int argc, char** argv) {
                 tot_up16 += u0;
             } else tot_up16 += h0;
         }
-        {
-            static long long* dbg = nullptr;
-            if (!dbg) CK(hipMalloc(&dbg, 8 * 8 * 8));
-            CK(hipMemset(dbg, 0, 8 * 8 * 8));
-            GemmArgs gd = g; gd.am_best = reinterpret_cast<unsigned long long*>(dbg);
-            run_wide<9>(gd, st, 1);
-            long long hd[64]; CK(hipMemcpy(hd, dbg, sizeof(hd), hipMemcpyDeviceToHost));
-            for (int w : {0, 4}) printf("      wave %d cycles per k-tile: staging first %.0f, reads+mfma %.0f, staging last %.0f, barrier %.0f | loop total %.0f (%lld k-tiles)\n", w,
-                   hd[w * 8] / (double)hd[w * 8 + 5], hd[w * 8 + 1] / (double)hd[w * 8 + 5], hd[w * 8 + 2] / (double)hd[w * 8 + 5], hd[w * 8 + 3] / (double)hd[w * 8 + 5],
-                   hd[w * 8 + 4] / (double)hd[w * 8 + 5], hd[w * 8 + 5]);
-        }
-        tot += std::min(t0, w0); totf += fl;
+        tot += t0; totf += fl;
     }
-    printf("sum (one launch per shape): %.1f us, %.1f TFLOP/s MFMA-equivalent; stream kernel: %.1f us, %.1f; ring kernel: %.1f us, %.1f; ring16: %.1f us, %.1f; ring16 + up16: %.1f us\n", tot, totf / tot * 1e-6, tot_stream, totf / tot_stream * 1e-6, tot_ring, totf / tot_ring * 1e-6, tot_ring16, totf / tot_ring16 * 1e-6, tot_up16);
+    printf("sum (one launch per shape): fallback kernel %.1f us, %.1f TFLOP/s MFMA-equivalent; ring16: %.1f us, %.1f; ring16 + up16: %.1f us   (the superseded generations -- wide, stream, ring -- and their numbers: git history up to round 3, profiles/r0[23]_micro_split_conv_variants.txt)\n", tot, totf / tot * 1e-6, tot_ring16, totf / tot_ring16 * 1e-6, tot_up16);
     return 0;
 }
