@@ -41,13 +41,15 @@ timeout 600 python bench.py --merge 1 --inflight 3 --no-cpu-baseline --no-roofli
 timeout 600 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline --no-exact-mode > $O/bench_serial.json 2>/dev/null
 timeout 600 python bench.py --sampler quality --no-cpu-baseline --no-exact-mode > $O/bench_quality_sampler.json 2>/dev/null
 timeout 600 python bench.py --decode-precision fast --no-cpu-baseline --no-roofline --no-exact-mode > $O/bench_decode_fast.json 2>/dev/null
-timeout 900 python bench.py --config configs/imagenet-12l-level3.yaml --steps 48 > $O/bench_level3.json 2>/dev/null
-timeout 900 python bench.py --config configs/cc15m-12l-txt.yaml --steps 48 > $O/bench_text_cond.json 2>/dev/null
+timeout 900 python bench.py --config configs/imagenet-12l-level3.yaml --steps 48 --no-exact-mode > $O/bench_level3.json 2>/dev/null
+timeout 900 python bench.py --config configs/cc15m-12l-txt.yaml --steps 48 --no-exact-mode > $O/bench_text_cond.json 2>/dev/null
+timeout 900 python bench.py --config configs/imagenet-12l-level3-top2mid2bot.yaml --steps 24 --no-cpu-baseline --no-exact-mode > $O/bench_level3_top2mid2bot.json 2>/dev/null
 timeout 300 python tools/bench_decode.py --precision split > $O/decode_split_batch64.json 2>/dev/null
 timeout 300 python tools/bench_decode.py --precision fast > $O/decode_fast_batch64.json 2>/dev/null
 timeout 300 python tools/bench_decoder.py --precision split > $O/decoder_only_1024_split.json 2>/dev/null
 timeout 300 python tools/bench_decoder.py --precision fast > $O/decoder_only_1024_fast.json 2>/dev/null
 timeout 300 python tools/bench_encode.py > $O/encode_batch64.json 2>/dev/null
+timeout 300 python tools/cpu_twin_probe.py > $O/cpu_twin_probe.txt 2>&1
 timeout 300 python tools/diag_overlap.py --rows 512 > $O/diag_overlap_rows512.json 2>/dev/null
 timeout 300 python tools/diag_overlap.py --rows 2048 --lanes 2 --passes 4 > $O/diag_overlap_rows2048.json 2>/dev/null
 timeout 300 python tools/ar_pass_time.py --rows 64 512 640 1024 2048 3072 --policy 1 --breakdown > $O/ar_pass_time_by_rows.json 2>/dev/null
