@@ -468,6 +468,13 @@ def test_l3_sampling_vs_reference_fixture_and_oracle():
                                          noise=torch.from_numpy(noise), return_logits=True, use_graph=graph)
             assert np.abs(np_(lg)[fx['keep_steps']] - fx[f'logits_{si}']).max() <= LOGIT_TOL
             assert (np_(c0) == fx[f'codes0_{si}']).all() and (np_(c1) == fx[f'codes1_{si}']).all() and (np_(c2) == fx[f'codes2_{si}']).all()
+        # SPLIT (fp32-accurate AR loop on the matrix cores): the same bar as EXACT
+        from hqtransformer_amd._lib import PRECISION_SPLIT
+        c0, c1, c2, lg = eng.sample3(B, torch.full((B,), 7), n, precision=PRECISION_SPLIT, top_k=tk, top_p=tp, temperature=T,
+                                     noise=torch.from_numpy(noise), return_logits=True, use_graph=True)
+        assert np.abs(np_(lg)[fx['keep_steps']] - fx[f'logits_{si}']).max() <= LOGIT_TOL
+        assert (np_(c0) == fx[f'codes0_{si}']).all() and (np_(c1) == fx[f'codes1_{si}']).all() and (np_(c2) == fx[f'codes2_{si}']).all()
+    eng.range_check()
     force = [torch.from_numpy(fx[f'codes{i}_0'].copy()) for i in range(3)]
     ex = eng.sample3(B, torch.full((B,), 7), 16, precision=PRECISION_EXACT, noise=torch.from_numpy(noise[:16]),
                      force=[f[:, :16] for f in force], return_logits=True, use_graph=False)
@@ -797,6 +804,11 @@ def test_text_prefill_at_the_cc15m_shape_vs_oracle():
                             use_graph=False)
     assert np.abs(np_(lg) - want[2]).max() <= LOGIT_TOL
     assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all()
+    from hqtransformer_amd._lib import PRECISION_SPLIT           # the 4096-row prefill + cached positions, fp32-accurate on the matrix cores
+    st, sb, ls = eng.sample(B, torch.from_numpy(txt), n, precision=PRECISION_SPLIT, noise=torch.from_numpy(noise), return_logits=True, use_graph=True)
+    assert np.abs(np_(ls) - want[2]).max() <= LOGIT_TOL
+    assert (np_(st) == want[0]).all() and (np_(sb) == want[1]).all()
+    eng.range_check()
     ft, fb = torch.from_numpy(want[0]), torch.from_numpy(want[1])
     for graph in (False, True):
         _, _, lf = eng.sample(B, torch.from_numpy(txt), n, precision=PRECISION_FAST, noise=torch.from_numpy(noise), force_top=ft, force_bot=fb,
