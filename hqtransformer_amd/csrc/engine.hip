@@ -936,6 +936,11 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     }
     g.Bw = l.w32;
     if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
+    if (exact_mfma_ok(g)) {                      // plain fp32 nn.Linear (the AR loop): the fp32 matrix instructions, one tile per wave
+        HIPCHK(launch_exact_mfma_gemm(g, st));
+        count_variant(h, "variant:exact_mfma:%s", tag);
+        return HQT_OK;
+    }
     HIPCHK(launch_gemm_generic(g, DT_F32, DT_F32, DT_F32, st));
     if (md.split_ar) count_variant(h, "variant:gemm_generic_f32:%s", tag);
     return HQT_OK;

@@ -1,0 +1,103 @@
+// EXACT-precision nn.Linear of the AR loop on the fp32 matrix instructions (round 4).
+//
+//   y[M, N] = x[M, K] W[N, K]^T (+bias, act, +resid; fused [query; key; value] split with the KV-cache row remap)      stage2/layers.py:73-85,190,313-315
+//
+// EXACT is the arithmetic whose code sequences are compared bit for bit with the reference's CPU path: fp32 operands, one fp32 fused
+// multiply-add per product, fp32 accumulation.  v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 compute exactly that -- per output a
+// k-ordered chain of fmaf, one rounding per product, no wider internal accumulator (MI355X_MICROARCH.md, 'FP32-input MFMA') -- at the
+// fp32 vector rate, but without the 64 x 64 LDS tile of gemm_tile_kernel (gemm_generic.h), which leaves 72 workgroups for a 64-row
+// GEMM of the body (0.16 TB/s of weights: 15 ms per top position at batch 64).  Here a WAVE owns a T x T output tile (T = 16 or 32)
+// and walks K alone: no LDS, no barrier, operands straight from L2 / HBM as 16-byte loads (lane (r, q) holds W[n0 + r][kb + 4 q ..]
+// and x[m0 + r][kb + 4 q ..]), a register ring of DEPTH chunks in flight.
+//
+// Summation order.  Element e of a lane's float4 feeds MFMA step e, so inside a 16-wide chunk the k indices enter an output's chain in
+// the order [0 4 8 12 | 1 5 9 13 | 2 6 10 14 | 3 7 11 15] (16x16x4: one instruction per group; 32x32x2: two, (0 4) then (8 12)), chunks
+// ascending.  BOTH tile shapes produce that same order, so an output's bits do not depend on the tile shape the launcher picks from
+// the row count -- a step's EXACT draws stay independent of the pass it is merged into (tests/test_gpu_timed_schedule.py).
+#include "gemm_generic.h"
+#include "kernels.h"
+#include <cstdlib>
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <bool T32>
+__global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM, int TN) {
+    constexpr int T = T32 ? 32 : 16;
+    constexpr int LPC = T32 ? 2 : 1;                     // float4 loads per operand and 16-k chunk
+    constexpr int DEPTH = T32 ? 6 : 12;                  // chunks in flight per wave (one wave per SIMD hides memory latency by depth, not by occupancy)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    if (tile >= (long long)TM * TN) return;              // whole waves leave; the kernel has no barrier
+    const int tm = (int)(tile % TM), tn = (int)(tile / TM);       // the waves of a workgroup: neighbouring row tiles of ONE column tile (W rows shared through the L1)
+    const int r = lane & (T - 1), q = lane / T;
+    const int m0 = tm * T, n0 = tn * T;
+    const float* xrow = reinterpret_cast<const float*>(g.A) + (size_t)min(m0 + r, g.M - 1) * g.lda + 4 * q;
+    const float* wrow = reinterpret_cast<const float*>(g.Bw) + (size_t)min(n0 + r, g.N - 1) * g.ldb + 4 * q;
+    const int NCH = g.K >> 4;
+    f32x4 wv[DEPTH][LPC], xv[DEPTH][LPC];
+    auto fetch = [&](int c, int slot) {
+        c = min(c, NCH - 1);                             // past the end: a duplicate nobody multiplies (keeps the loads unconditional)
+#pragma unroll
+        for (int t = 0; t < LPC; ++t) {
+            wv[slot][t] = *reinterpret_cast<const f32x4*>(wrow + c * 16 + 8 * t);
+            xv[slot][t] = *reinterpret_cast<const f32x4*>(xrow + c * 16 + 8 * t);
+        }
+    };
+    typename std::conditional<T32, f32x16, f32x4>::type acc;
+#pragma unroll
+    for (int i = 0; i < (T32 ? 16 : 4); ++i) acc[i] = 0.0f;
+    auto multiply = [&](int slot) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < LPC; ++t) {
+                if constexpr (T32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot][t][e], xv[slot][t][e], acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][t][e], xv[slot][t][e], acc, 0, 0, 0);
+            }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) fetch(d, d);
+    int c0 = 0;
+    for (; c0 + DEPTH <= NCH; c0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            multiply(d);
+            fetch(c0 + d + DEPTH, d);
+        }
+    }
+    // tail: NCH % DEPTH chunks, already in slots 0 .. (their loads were issued above)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (c0 + d < NCH) multiply(d);
+    // D map: column = lane & (T - 1) -> row m of y; rows -> columns n of y (32x32: (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); 16x16: 4 (lane >> 4) + reg)
+    const int m = m0 + r;
+    if (m >= g.M) return;
+#pragma unroll
+    for (int i = 0; i < (T32 ? 16 : 4); ++i) {
+        const int n = n0 + (T32 ? (i & 3) + 8 * (i >> 2) + 4 * q : 4 * q + i);
+        if (n < g.N) gemm_store<float>(g, 0, m, n, acc[i]);
+    }
+}
+
+// plain fp32 row-major operands, K in whole chunks, the AR loop's store modes (gemm_store handles bias / act / resid / row remap / QKV split)
+bool exact_mfma_ok(const GemmArgs& g) {
+    static const bool off = getenv("HQT_NO_EXACT_MFMA") != nullptr;                // A/B switch: the 64 x 64 vector-ALU tile kernel for everything
+    if (off || g.conv_taps || g.a_packed_mb || g.a_rows_per_group || g.batch > 1 || g.gn_stats) return false;
+    if (g.K % 16 != 0 || g.K < 16 || g.lda % 4 != 0 || g.ldb % 4 != 0) return false;
+    return g.store == STORE_ROWS || g.store == STORE_QKV;
+}
+
+hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st) {
+    // 32 x 32 tiles (half the operand bytes per FLOP) once they fill the chip's 1024 SIMDs; below that 16 x 16 tiles: four times the waves
+    const long long w32 = (long long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+    if (w32 >= 1024) {
+        const int TM = (g.M + 31) / 32, TN = (g.N + 31) / 32;
+        exact_mfma_gemm_kernel<true><<<(unsigned)(((long long)TM * TN + 3) / 4), 256, 0, st>>>(g, TM, TN);
+    } else {
+        const int TM = (g.M + 15) / 16, TN = (g.N + 15) / 16;
+        exact_mfma_gemm_kernel<false><<<(unsigned)(((long long)TM * TN + 3) / 4), 256, 0, st>>>(g, TM, TN);
+    }
+    return hipGetLastError();
+}

@@ -6,6 +6,9 @@ enum { DT_F32 = 0, DT_BF16 = 1 };
 
 // generic GEMM (vector ALUs).  ta/tb/tc are DT_*.
 hipError_t launch_gemm_generic(const GemmArgs& g, int ta, int tb, int tc, hipStream_t st);
+// EXACT nn.Linear of the AR loop on the fp32 matrix instructions, one T x T tile per wave (exact_gemm.hip)
+bool exact_mfma_ok(const GemmArgs& g);
+hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st);
 
 struct EmbedArgs {
     int B, D, n_steps;

@@ -203,8 +203,11 @@ def test_full_benchmark_model_merged_pass_properties(steps):
         assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]), f'FAST {rows}-row pass is not reproducible (graph / eager / run to run)'
     # (2) step 5 alone, as the unmerged 64-row call of the reference harness
     k = 5
-    alone = eng.sample(B, cls[k * B:(k + 1) * B], n, precision=PRECISION_EXACT, seed=seeds[k * B], sample_offset=0, use_graph=False)
+    alone = eng.sample(B, cls[k * B:(k + 1) * B], n, precision=PRECISION_EXACT, seed=seeds[k * B], sample_offset=0, use_graph=False, return_logits=True)
     assert torch.equal(alone[0], ex[0][k * B:(k + 1) * B]) and torch.equal(alone[1], ex[1][k * B:(k + 1) * B]), 'a step draws differently inside a merged pass'
+    # ... and not only the draws: every fp32 logit is BIT-identical (the 64-row call runs 16 x 16 tiles of the fp32 matrix instruction, the merged
+    # pass 32 x 32 tiles -- exact_gemm.hip feeds both the same k order, so an output's summation chain does not depend on the tile shape)
+    assert torch.equal(alone[2], ex[2][:, :, k * B:(k + 1) * B]), 'EXACT logits of a step depend on the pass it is merged into'
     # (3) FAST vs EXACT
     first = ((runs[0][0][:, 0] == ex[0][:, 0]).float().mean() + 4 * (runs[0][1][:, 0] == ex[1][:, 0]).float().mean()) / 5
     gate(f'timed_schedule.full_model_rows{rows}.fast_vs_exact_first_position', float(first), 0.985, '>=')
