@@ -12,8 +12,9 @@
 //
 // Summation order.  Element e of a lane's float4 feeds MFMA step e, so inside a 16-wide chunk the k indices enter an output's chain in
 // the order [0 4 8 12 | 1 5 9 13 | 2 6 10 14 | 3 7 11 15] (16x16x4: one instruction per group; 32x32x2: two, (0 4) then (8 12)), chunks
-// ascending.  BOTH tile shapes produce that same order, so an output's bits do not depend on the tile shape the launcher picks from
-// the row count -- a step's EXACT draws stay independent of the pass it is merged into (tests/test_gpu_timed_schedule.py).
+// ascending.  gemm_tile_kernel (the vector-ALU kernel larger row counts keep) walks its 16-wide chunks in that same order, and a
+// k-ordered fmaf chain is what both compute, so an output's bits do not depend on the kernel the row count selects -- a step's EXACT
+// draws AND logits stay independent of the pass it is merged into (tests/test_gpu_timed_schedule.py compares them bit for bit).
 #include "gemm_generic.h"
 #include "kernels.h"
 #include <cstdlib>
@@ -25,8 +26,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 template <bool T32>
 __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM, int TN) {
     constexpr int T = T32 ? 32 : 16;
-    constexpr int LPC = T32 ? 2 : 1;                     // float4 loads per operand and 16-k chunk
-    constexpr int DEPTH = T32 ? 6 : 12;                  // chunks in flight per wave (one wave per SIMD hides memory latency by depth, not by occupancy)
+    constexpr int LPC = T32 ? 4 : 2;                     // float4 loads per operand and 32-k step (two 16-k chunks: a lane group reads whole 128-byte lines)
+    constexpr int DEPTH = T32 ? 3 : 6;                   // 32-k steps in flight per wave (one wave per SIMD hides memory latency by depth, not by occupancy)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long tile = (long long)blockIdx.x * 4 + wave;
     if (tile >= (long long)TM * TN) return;              // whole waves leave; the kernel has no barrier
@@ -35,42 +36,46 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
     const int m0 = tm * T, n0 = tn * T;
     const float* xrow = reinterpret_cast<const float*>(g.A) + (size_t)min(m0 + r, g.M - 1) * g.lda + 4 * q;
     const float* wrow = reinterpret_cast<const float*>(g.Bw) + (size_t)min(n0 + r, g.N - 1) * g.ldb + 4 * q;
-    const int NCH = g.K >> 4;
+    const int NST = g.K >> 5;
     f32x4 wv[DEPTH][LPC], xv[DEPTH][LPC];
+    // load t of a step: chunk t / (LPC / 2), half t % (LPC / 2): offsets 0, 16 (16x16) / 0, 8, 16, 24 (32x32) floats -- issued back to back per operand,
+    // so the two halves of a row's 128-byte line are requested together
     auto fetch = [&](int c, int slot) {
-        c = min(c, NCH - 1);                             // past the end: a duplicate nobody multiplies (keeps the loads unconditional)
+        c = min(c, NST - 1);                             // past the end: a duplicate nobody multiplies (keeps the loads unconditional)
 #pragma unroll
-        for (int t = 0; t < LPC; ++t) {
-            wv[slot][t] = *reinterpret_cast<const f32x4*>(wrow + c * 16 + 8 * t);
-            xv[slot][t] = *reinterpret_cast<const f32x4*>(xrow + c * 16 + 8 * t);
-        }
+        for (int t = 0; t < LPC; ++t) wv[slot][t] = *reinterpret_cast<const f32x4*>(wrow + c * 32 + (T32 ? 8 : 16) * t);
+#pragma unroll
+        for (int t = 0; t < LPC; ++t) xv[slot][t] = *reinterpret_cast<const f32x4*>(xrow + c * 32 + (T32 ? 8 : 16) * t);
     };
     typename std::conditional<T32, f32x16, f32x4>::type acc;
 #pragma unroll
     for (int i = 0; i < (T32 ? 16 : 4); ++i) acc[i] = 0.0f;
     auto multiply = [&](int slot) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int ch = 0; ch < 2; ++ch)                   // the two 16-k chunks of the step, ascending
 #pragma unroll
-            for (int t = 0; t < LPC; ++t) {
-                if constexpr (T32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot][t][e], xv[slot][t][e], acc, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][t][e], xv[slot][t][e], acc, 0, 0, 0);
-            }
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < LPC / 2; ++t) {
+                    const int u = ch * (LPC / 2) + t;
+                    if constexpr (T32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot][u][e], xv[slot][u][e], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][u][e], xv[slot][u][e], acc, 0, 0, 0);
+                }
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) fetch(d, d);
     int c0 = 0;
-    for (; c0 + DEPTH <= NCH; c0 += DEPTH) {
+    for (; c0 + DEPTH <= NST; c0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             multiply(d);
             fetch(c0 + d + DEPTH, d);
         }
     }
-    // tail: NCH % DEPTH chunks, already in slots 0 .. (their loads were issued above)
+    // tail: NST % DEPTH steps, already in slots 0 .. (their loads were issued above)
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-        if (c0 + d < NCH) multiply(d);
+        if (c0 + d < NST) multiply(d);
     // D map: column = lane & (T - 1) -> row m of y; rows -> columns n of y (32x32: (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); 16x16: 4 (lane >> 4) + reg)
     const int m = m0 + r;
     if (m >= g.M) return;
@@ -82,22 +87,22 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
 }
 
 // plain fp32 row-major operands, K in whole chunks, the AR loop's store modes (gemm_store handles bias / act / resid / row remap / QKV split)
+bool exact_mfma_small(const GemmArgs& g);
 bool exact_mfma_ok(const GemmArgs& g) {
     static const bool off = getenv("HQT_NO_EXACT_MFMA") != nullptr;                // A/B switch: the 64 x 64 vector-ALU tile kernel for everything
     if (off || g.conv_taps || g.a_packed_mb || g.a_rows_per_group || g.batch > 1 || g.gn_stats) return false;
-    if (g.K % 16 != 0 || g.K < 16 || g.lda % 4 != 0 || g.ldb % 4 != 0) return false;
-    return g.store == STORE_ROWS || g.store == STORE_QKV;
+    if (g.K % 32 != 0 || g.K < 32 || g.lda % 4 != 0 || g.ldb % 4 != 0) return false;
+    return (g.store == STORE_ROWS || g.store == STORE_QKV) && exact_mfma_small(g);
 }
 
+// Small row counts only: one 16 x 16 tile per wave puts 4 x the waves of a 32 x 32 tiling on the chip, which is what a 64-row GEMM
+// needs (288 workgroups instead of 72: 960 -> 397 ms of AR loop per batch-64 step).  From ~1024 tiles of 32 x 32 the LDS-shared
+// 64 x 64 tile of gemm_tile_kernel (the same summation order since round 4) moves half the operand bytes per FLOP and wins
+// (a 32 x 32-per-wave variant of this kernel measured 178 vs 155 ms per 64 images at 640 rows, 154 vs 119 at 2048: dropped).
+bool exact_mfma_small(const GemmArgs& g) { return (long long)((g.M + 31) / 32) * ((g.N + 31) / 32) < 1024; }
+
 hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st) {
-    // 32 x 32 tiles (half the operand bytes per FLOP) once they fill the chip's 1024 SIMDs; below that 16 x 16 tiles: four times the waves
-    const long long w32 = (long long)((g.M + 31) / 32) * ((g.N + 31) / 32);
-    if (w32 >= 1024) {
-        const int TM = (g.M + 31) / 32, TN = (g.N + 31) / 32;
-        exact_mfma_gemm_kernel<true><<<(unsigned)(((long long)TM * TN + 3) / 4), 256, 0, st>>>(g, TM, TN);
-    } else {
-        const int TM = (g.M + 15) / 16, TN = (g.N + 15) / 16;
-        exact_mfma_gemm_kernel<false><<<(unsigned)(((long long)TM * TN + 3) / 4), 256, 0, st>>>(g, TM, TN);
-    }
+    const int TM = (g.M + 15) / 16, TN = (g.N + 15) / 16;
+    exact_mfma_gemm_kernel<false><<<(unsigned)(((long long)TM * TN + 3) / 4), 256, 0, st>>>(g, TM, TN);
     return hipGetLastError();
 }

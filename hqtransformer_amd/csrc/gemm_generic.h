@@ -152,8 +152,11 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { As[lk + i][lrow] = a4[i]; Bs[lk + i][lrow] = b4[i]; }
         __syncthreads();
+        // k order inside a 16-wide chunk: [0 4 8 12 | 1 5 9 13 | 2 6 10 14 | 3 7 11 15] -- the order in which exact_gemm.hip's fp32 matrix
+        // instructions chain the same products, so an output's bits do not depend on which of the two kernels a row count selects
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
+        for (int ki = 0; ki < 16; ++ki) {
+            const int kk = (ki & 3) * 4 + (ki >> 2);
             const float4 av = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
             const float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
             const float a[4] = {av.x, av.y, av.z, av.w};
