@@ -65,6 +65,7 @@ struct Lin {            // one nn.Linear / conv filter bank in every layout the 
     bf16_t* w16 = nullptr;        // [N, K] bf16 row-major (FAST generic + conv MFMA)
     half_t* w16h = nullptr;       // [N, K] fp16 hi / lo planes of w32 (SPLIT convolutions: split_kernels.h)
     half_t* w16l = nullptr;
+    float* w32t = nullptr;        // fp32 tile-contiguous copy [N / 16][K / 32][16][32] (EXACT AR loop at small row counts: exact_gemm.hip)
     half_t* wfrag16 = nullptr;    // 3x3 filters, hi + lo, packed in MFMA fragment order (16-channel blocks of v_mfma_f32_16x16x32_f16; split_stream_conv.hip)
     half_t* wup16 = nullptr;      // upsampling convs: the four 2x2 phase filters (pre-summed taps), same packing
     bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)
@@ -561,6 +562,10 @@ static int make_lin(hqt_handle* h, Lin& l, const float* w32, const float* b32, i
         CHK(dev_alloc(h, (void**)&l.w16l, (size_t)N * K * 2, false));
         HIPCHK(launch_split_f32(w32, l.w16h, l.w16l, (size_t)N * K, 0));
     }
+    if (stream_pack && N % 16 == 0 && K % 32 == 0) {          // the AR loop's linears: tile-contiguous fp32 for the EXACT small-row GEMM
+        CHK(dev_alloc(h, (void**)&l.w32t, (size_t)N * K * 4, false));
+        HIPCHK(launch_pack_exact_tiles(w32, l.w32t, N, K, 0));
+    }
     if (stream_pack && stream_gemm_supported(N, K)) {
         CHK(dev_alloc(h, (void**)&l.wpk, (size_t)N * K * 2, false));
         HIPCHK(launch_pack_stream_weights(w32, l.wpk, N, K, 0));
@@ -937,6 +942,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
     g.Bw = l.w32;
     if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
     if (exact_mfma_ok(g)) {                      // plain fp32 nn.Linear (the AR loop): the fp32 matrix instructions, one tile per wave
+        if (l.w32t && g.N % 16 == 0) { g.Bw = l.w32t; g.b_tile16 = 1; }
         HIPCHK(launch_exact_mfma_gemm(g, st));
         count_variant(h, "variant:exact_mfma:%s", tag);
         return HQT_OK;

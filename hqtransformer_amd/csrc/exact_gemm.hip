@@ -17,6 +17,7 @@
 // draws AND logits stay independent of the pass it is merged into (tests/test_gpu_timed_schedule.py compares them bit for bit).
 #include "gemm_generic.h"
 #include "kernels.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -35,15 +36,21 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
     const int r = lane & (T - 1), q = lane / T;
     const int m0 = tm * T, n0 = tn * T;
     const float* xrow = reinterpret_cast<const float*>(g.A) + (size_t)min(m0 + r, g.M - 1) * g.lda + 4 * q;
-    const float* wrow = reinterpret_cast<const float*>(g.Bw) + (size_t)min(n0 + r, g.N - 1) * g.ldb + 4 * q;
     const int NST = g.K >> 5;
+    // W: row-major [N][K], or (b_tile16, 16 x 16 tiles) the tile-contiguous copy: a wave's 16 rows of a 32-k step are ONE 2-KiB run and its
+    // whole stream one contiguous 2 NST KiB -- row-major, 4608 row streams advance 128 B at a time each and DRAM sees scattered lines
+    // (0.7 TB/s of weights measured at 64 rows); the values and their order in the chain are the same either way
+    const bool tiled = !T32 && g.b_tile16;
+    const float* wrow = tiled ? reinterpret_cast<const float*>(g.Bw) + ((size_t)tn * NST * 16 + r) * 32 + 4 * q
+                              : reinterpret_cast<const float*>(g.Bw) + (size_t)min(n0 + r, g.N - 1) * g.ldb + 4 * q;
+    const int wstep = tiled ? 16 * 32 : 32;
     f32x4 wv[DEPTH][LPC], xv[DEPTH][LPC];
     // load t of a step: chunk t / (LPC / 2), half t % (LPC / 2): offsets 0, 16 (16x16) / 0, 8, 16, 24 (32x32) floats -- issued back to back per operand,
     // so the two halves of a row's 128-byte line are requested together
     auto fetch = [&](int c, int slot) {
         c = min(c, NST - 1);                             // past the end: a duplicate nobody multiplies (keeps the loads unconditional)
 #pragma unroll
-        for (int t = 0; t < LPC; ++t) wv[slot][t] = *reinterpret_cast<const f32x4*>(wrow + c * 32 + (T32 ? 8 : 16) * t);
+        for (int t = 0; t < LPC; ++t) wv[slot][t] = *reinterpret_cast<const f32x4*>(wrow + (size_t)c * wstep + (T32 ? 8 : 16) * t);
 #pragma unroll
         for (int t = 0; t < LPC; ++t) xv[slot][t] = *reinterpret_cast<const f32x4*>(xrow + c * 32 + (T32 ? 8 : 16) * t);
     };
@@ -104,5 +111,22 @@ bool exact_mfma_small(const GemmArgs& g) { return (long long)((g.M + 31) / 32) *
 hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st) {
     const int TM = (g.M + 15) / 16, TN = (g.N + 15) / 16;
     exact_mfma_gemm_kernel<false><<<(unsigned)(((long long)TM * TN + 3) / 4), 256, 0, st>>>(g, TM, TN);
+    return hipGetLastError();
+}
+
+// fp32 [N][K] -> [N / 16][K / 32][16][32] (N % 16 == 0, K % 32 == 0)
+__global__ void pack_exact_tiles_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int K) {
+    const size_t total = (size_t)N * K;
+    const int NST = K >> 5;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i & 31), rr = (int)((i >> 5) & 15);
+        const size_t st = i >> 9;
+        const int c = (int)(st % NST), tn = (int)(st / NST);
+        out[i] = w[(size_t)(tn * 16 + rr) * K + c * 32 + kk];
+    }
+}
+hipError_t launch_pack_exact_tiles(const float* w, float* out, int N, int K, hipStream_t st) {
+    if (N % 16 != 0 || K % 32 != 0) return hipErrorInvalidValue;
+    pack_exact_tiles_kernel<<<(unsigned)std::min<size_t>(((size_t)N * K + 255) / 256, 8192), 256, 0, st>>>(w, out, N, K);
     return hipGetLastError();
 }
