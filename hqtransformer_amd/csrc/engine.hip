@@ -65,7 +65,7 @@ struct Lin {            // one nn.Linear / conv filter bank in every layout the 
     bf16_t* w16 = nullptr;        // [N, K] bf16 row-major (FAST generic + conv MFMA)
     half_t* w16h = nullptr;       // [N, K] fp16 hi / lo planes of w32 (SPLIT convolutions: split_kernels.h)
     half_t* w16l = nullptr;
-    float* w32t = nullptr;        // fp32 tile-contiguous copy [N / 16][K / 32][16][32] (EXACT AR loop at small row counts: exact_gemm.hip)
+    float* w32t = nullptr;        // fp32 copy in MFMA fragment order [N / 16][K / 32][chunk][lane][4] (EXACT AR loop at small row counts: exact_gemm.hip)
     half_t* wfrag16 = nullptr;    // 3x3 filters, hi + lo, packed in MFMA fragment order (16-channel blocks of v_mfma_f32_16x16x32_f16; split_stream_conv.hip)
     half_t* wup16 = nullptr;      // upsampling convs: the four 2x2 phase filters (pre-summed taps), same packing
     bf16_t* wpk = nullptr;        // MFMA-fragment-packed bf16 for the weight-streaming GEMM (FAST AR)

@@ -7,8 +7,7 @@
 // k-ordered chain of fmaf, one rounding per product, no wider internal accumulator (MI355X_MICROARCH.md, 'FP32-input MFMA') -- at the
 // fp32 vector rate, but without the 64 x 64 LDS tile of gemm_tile_kernel (gemm_generic.h), which leaves 72 workgroups for a 64-row
 // GEMM of the body (0.16 TB/s of weights: 15 ms per top position at batch 64).  Here a WAVE owns a T x T output tile (T = 16 or 32)
-// and walks K alone: no LDS, no barrier, operands straight from L2 / HBM as 16-byte loads (lane (r, q) holds W[n0 + r][kb + 4 q ..]
-// and x[m0 + r][kb + 4 q ..]), a register ring of DEPTH chunks in flight.
+// and walks K alone: no workgroup barrier, a register ring of DEPTH 32-k steps in flight (operand paths: at the kernel).
 //
 // Summation order.  Element e of a lane's float4 feeds MFMA step e, so inside a 16-wide chunk the k indices enter an output's chain in
 // the order [0 4 8 12 | 1 5 9 13 | 2 6 10 14 | 3 7 11 15] (16x16x4: one instruction per group; 32x32x2: two, (0 4) then (8 12)), chunks
@@ -24,50 +23,55 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <bool T32>
+// One wave = one 16 x 16 output tile over the whole K, v_mfma_f32_16x16x4_f32.  Operand maps (cdna_hip_programming.md §3): lane l = r + 16 q supplies
+// A[i = r][k = q] and B[k = q][j = r]; with A = W (i = column n of y) and B = x (j = row m of y) the result D has m on the lanes and four consecutive
+// n per lane.  Per 32-k step a lane needs W[n0 + r][kb + 16 ch + 4 q .. + 3] and x[m0 + r][the same k] (ch = 0, 1), element e feeding MFMA e of the chunk.
+//   * W comes from the fragment-ordered fp32 copy made at finalize ([n / 16][k / 32][chunk][lane][4]): one fully coalesced 1-KiB load per chunk.
+//     (Read from the row-major tensor the same lanes touch 16 rows x 64 B per instruction -- adjacent lanes 6 KiB apart -- and the 64-row GEMMs
+//     of the body ran at 0.7 TB/s of weights.)
+//   * x is row-major [M][K] (it is what the LayerNorm / attention / GELU kernels write): fetched as 8 rows x 128 B per instruction (adjacent
+//     lanes adjacent), turned into the fragment order through a wave-private LDS patch -- no workgroup barrier, LDS operations of a wave execute in order.
+template <bool TILED>
 __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM, int TN) {
-    constexpr int T = T32 ? 32 : 16;
-    constexpr int LPC = T32 ? 4 : 2;                     // float4 loads per operand and 32-k step (two 16-k chunks: a lane group reads whole 128-byte lines)
-    constexpr int DEPTH = T32 ? 3 : 6;                   // 32-k steps in flight per wave (one wave per SIMD hides memory latency by depth, not by occupancy)
+    constexpr int DEPTH = 6;                             // 32-k steps in flight per wave (few waves per SIMD: memory latency is hidden by depth)
+    constexpr int PITCH = 36;                            // floats per staged row: the 16 rows of a fragment read start in 16 different 4-bank groups
+    __shared__ __attribute__((aligned(16))) float patch_all[4][16 * PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long tile = (long long)blockIdx.x * 4 + wave;
-    if (tile >= (long long)TM * TN) return;              // whole waves leave; the kernel has no barrier
-    const int tm = (int)(tile % TM), tn = (int)(tile / TM);       // the waves of a workgroup: neighbouring row tiles of ONE column tile (W rows shared through the L1)
-    const int r = lane & (T - 1), q = lane / T;
-    const int m0 = tm * T, n0 = tn * T;
-    const float* xrow = reinterpret_cast<const float*>(g.A) + (size_t)min(m0 + r, g.M - 1) * g.lda + 4 * q;
+    if (tile >= (long long)TM * TN) return;              // whole waves leave; the kernel has no workgroup barrier
+    const int tm = (int)(tile % TM), tn = (int)(tile / TM);       // the waves of a workgroup: neighbouring row tiles of ONE column tile (the W stream is shared through the L1)
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = tm * 16, n0 = tn * 16;
     const int NST = g.K >> 5;
-    // W: row-major [N][K], or (b_tile16, 16 x 16 tiles) the tile-contiguous copy: a wave's 16 rows of a 32-k step are ONE 2-KiB run and its
-    // whole stream one contiguous 2 NST KiB -- row-major, 4608 row streams advance 128 B at a time each and DRAM sees scattered lines
-    // (0.7 TB/s of weights measured at 64 rows); the values and their order in the chain are the same either way
-    const bool tiled = !T32 && g.b_tile16;
-    const float* wrow = tiled ? reinterpret_cast<const float*>(g.Bw) + ((size_t)tn * NST * 16 + r) * 32 + 4 * q
+    float* const patch = patch_all[wave];
+    // x: load t of a step covers rows 8 t .. 8 t + 7, lane l -> row 8 t + (l >> 3), floats 4 (l & 7) .. + 3 of the step's 32
+    const float* xsrc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) xsrc[t] = reinterpret_cast<const float*>(g.A) + (size_t)min(m0 + 8 * t + (lane >> 3), g.M - 1) * g.lda + 4 * (lane & 7);
+    float* const pw = patch + (lane >> 3) * PITCH + 4 * (lane & 7);          // + 8 t rows
+    const float* const pr = patch + r * PITCH + 4 * q;                       // + 16 ch floats
+    const float* wsrc = TILED ? reinterpret_cast<const float*>(g.Bw) + (size_t)tn * NST * 512 + lane * 4
                               : reinterpret_cast<const float*>(g.Bw) + (size_t)min(n0 + r, g.N - 1) * g.ldb + 4 * q;
-    const int wstep = tiled ? 16 * 32 : 32;
-    f32x4 wv[DEPTH][LPC], xv[DEPTH][LPC];
-    // load t of a step: chunk t / (LPC / 2), half t % (LPC / 2): offsets 0, 16 (16x16) / 0, 8, 16, 24 (32x32) floats -- issued back to back per operand,
-    // so the two halves of a row's 128-byte line are requested together
+    f32x4 wv[DEPTH][2], xg[DEPTH][2];
     auto fetch = [&](int c, int slot) {
         c = min(c, NST - 1);                             // past the end: a duplicate nobody multiplies (keeps the loads unconditional)
 #pragma unroll
-        for (int t = 0; t < LPC; ++t) wv[slot][t] = *reinterpret_cast<const f32x4*>(wrow + (size_t)c * wstep + (T32 ? 8 : 16) * t);
+        for (int ch = 0; ch < 2; ++ch) wv[slot][ch] = *reinterpret_cast<const f32x4*>(wsrc + (TILED ? ((size_t)c * 2 + ch) * 256 : (size_t)c * 32 + 16 * ch));
 #pragma unroll
-        for (int t = 0; t < LPC; ++t) xv[slot][t] = *reinterpret_cast<const f32x4*>(xrow + c * 32 + (T32 ? 8 : 16) * t);
+        for (int t = 0; t < 2; ++t) xg[slot][t] = *reinterpret_cast<const f32x4*>(xsrc[t] + c * 32);
     };
-    typename std::conditional<T32, f32x16, f32x4>::type acc;
-#pragma unroll
-    for (int i = 0; i < (T32 ? 16 : 4); ++i) acc[i] = 0.0f;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     auto multiply = [&](int slot) {
+        // rows -> fragments through the wave's patch (in-order LDS: the reads below see the writes above, the next step's writes follow these reads)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4*>(pw + 8 * t * PITCH) = xg[slot][t];
+        f32x4 xf[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) xf[ch] = *reinterpret_cast<const f32x4*>(pr + 16 * ch);
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)                   // the two 16-k chunks of the step, ascending
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int t = 0; t < LPC / 2; ++t) {
-                    const int u = ch * (LPC / 2) + t;
-                    if constexpr (T32) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[slot][u][e], xv[slot][u][e], acc, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][u][e], xv[slot][u][e], acc, 0, 0, 0);
-                }
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][ch][e], xf[ch][e], acc, 0, 0, 0);
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) fetch(d, d);
@@ -83,12 +87,12 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (c0 + d < NST) multiply(d);
-    // D map: column = lane & (T - 1) -> row m of y; rows -> columns n of y (32x32: (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); 16x16: 4 (lane >> 4) + reg)
+    // D map: column = lane & 15 -> row m of y; register i of lane group q -> column n0 + 4 q + i
     const int m = m0 + r;
     if (m >= g.M) return;
 #pragma unroll
-    for (int i = 0; i < (T32 ? 16 : 4); ++i) {
-        const int n = n0 + (T32 ? (i & 3) + 8 * (i >> 2) + 4 * q : 4 * q + i);
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + 4 * q + i;
         if (n < g.N) gemm_store<float>(g, 0, m, n, acc[i]);
     }
 }
@@ -110,19 +114,21 @@ bool exact_mfma_small(const GemmArgs& g) { return (long long)((g.M + 31) / 32) *
 
 hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st) {
     const int TM = (g.M + 15) / 16, TN = (g.N + 15) / 16;
-    exact_mfma_gemm_kernel<false><<<(unsigned)(((long long)TM * TN + 3) / 4), 256, 0, st>>>(g, TM, TN);
+    const unsigned grid = (unsigned)(((long long)TM * TN + 3) / 4);
+    if (g.b_tile16) exact_mfma_gemm_kernel<true><<<grid, 256, 0, st>>>(g, TM, TN);
+    else exact_mfma_gemm_kernel<false><<<grid, 256, 0, st>>>(g, TM, TN);
     return hipGetLastError();
 }
 
-// fp32 [N][K] -> [N / 16][K / 32][16][32] (N % 16 == 0, K % 32 == 0)
+// fp32 [N][K] -> fragment order [N / 16][K / 32][chunk 2][lane 64][4]: lane = r + 16 q holds W[16 tn + r][32 c + 16 ch + 4 q .. + 3]   (N % 16 == 0, K % 32 == 0)
 __global__ void pack_exact_tiles_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int K) {
     const size_t total = (size_t)N * K;
     const int NST = K >> 5;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int kk = (int)(i & 31), rr = (int)((i >> 5) & 15);
+        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), ch = (int)((i >> 8) & 1);
         const size_t st = i >> 9;
         const int c = (int)(st % NST), tn = (int)(st / NST);
-        out[i] = w[(size_t)(tn * 16 + rr) * K + c * 32 + kk];
+        out[i] = w[(size_t)(tn * 16 + (lane & 15)) * K + c * 32 + 16 * ch + 4 * (lane >> 4) + e];
     }
 }
 hipError_t launch_pack_exact_tiles(const float* w, float* out, int N, int K, hipStream_t st) {

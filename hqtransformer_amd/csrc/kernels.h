@@ -9,7 +9,7 @@ hipError_t launch_gemm_generic(const GemmArgs& g, int ta, int tb, int tc, hipStr
 // EXACT nn.Linear of the AR loop on the fp32 matrix instructions, one T x T tile per wave (exact_gemm.hip)
 bool exact_mfma_ok(const GemmArgs& g);
 hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st);
-hipError_t launch_pack_exact_tiles(const float* w, float* out, int N, int K, hipStream_t st);   // fp32 [N][K] -> [N / 16][K / 32][16][32]
+hipError_t launch_pack_exact_tiles(const float* w, float* out, int N, int K, hipStream_t st);   // fp32 [N][K] -> MFMA fragment order [N / 16][K / 32][chunk][lane][4]
 
 struct EmbedArgs {
     int B, D, n_steps;
