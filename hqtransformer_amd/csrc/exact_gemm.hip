@@ -31,47 +31,55 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 //     of the body ran at 0.7 TB/s of weights.)
 //   * x is row-major [M][K] (it is what the LayerNorm / attention / GELU kernels write): fetched as 8 rows x 128 B per instruction (adjacent
 //     lanes adjacent), turned into the fragment order through a wave-private LDS patch -- no workgroup barrier, LDS operations of a wave execute in order.
-template <bool TILED>
+template <bool TILED, int MT>
 __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM, int TN) {
-    constexpr int DEPTH = 6;                             // 32-k steps in flight per wave (few waves per SIMD: memory latency is hidden by depth)
+    constexpr int DEPTH = MT == 1 ? 6 : 4;               // 32-k steps in flight per wave (few waves per SIMD: memory latency is hidden by depth)
+    // MT: 16-row tiles per wave (TM counts wave rows of 16 MT rows): one W fragment feeds MT independent accumulator chains -- the fp32
+    // instruction's 40-cycle dependent latency against its 32-cycle issue disappears, and the W stream is fetched by 1 / MT as many waves
     constexpr int PITCH = 36;                            // floats per staged row: the 16 rows of a fragment read start in 16 different 4-bank groups
-    __shared__ __attribute__((aligned(16))) float patch_all[4][16 * PITCH];
+    __shared__ __attribute__((aligned(16))) float patch_all[4][MT * 16 * PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long tile = (long long)blockIdx.x * 4 + wave;
     if (tile >= (long long)TM * TN) return;              // whole waves leave; the kernel has no workgroup barrier
     const int tm = (int)(tile % TM), tn = (int)(tile / TM);       // the waves of a workgroup: neighbouring row tiles of ONE column tile (the W stream is shared through the L1)
     const int r = lane & 15, q = lane >> 4;
-    const int m0 = tm * 16, n0 = tn * 16;
+    const int m0 = tm * 16 * MT, n0 = tn * 16;
     const int NST = g.K >> 5;
     float* const patch = patch_all[wave];
-    // x: load t of a step covers rows 8 t .. 8 t + 7, lane l -> row 8 t + (l >> 3), floats 4 (l & 7) .. + 3 of the step's 32
-    const float* xsrc[2];
+    // x: load t of a step covers rows 8 t .. 8 t + 7 of the wave's 16 MT, lane l -> row 8 t + (l >> 3), floats 4 (l & 7) .. + 3 of the step's 32
+    const float* xsrc[2 * MT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) xsrc[t] = reinterpret_cast<const float*>(g.A) + (size_t)min(m0 + 8 * t + (lane >> 3), g.M - 1) * g.lda + 4 * (lane & 7);
+    for (int t = 0; t < 2 * MT; ++t) xsrc[t] = reinterpret_cast<const float*>(g.A) + (size_t)min(m0 + 8 * t + (lane >> 3), g.M - 1) * g.lda + 4 * (lane & 7);
     float* const pw = patch + (lane >> 3) * PITCH + 4 * (lane & 7);          // + 8 t rows
-    const float* const pr = patch + r * PITCH + 4 * q;                       // + 16 ch floats
+    const float* const pr = patch + r * PITCH + 4 * q;                       // + 16 mt rows, + 16 ch floats
     const float* wsrc = TILED ? reinterpret_cast<const float*>(g.Bw) + (size_t)tn * NST * 512 + lane * 4
                               : reinterpret_cast<const float*>(g.Bw) + (size_t)min(n0 + r, g.N - 1) * g.ldb + 4 * q;
-    f32x4 wv[DEPTH][2], xg[DEPTH][2];
+    f32x4 wv[DEPTH][2], xg[DEPTH][2 * MT];
     auto fetch = [&](int c, int slot) {
         c = min(c, NST - 1);                             // past the end: a duplicate nobody multiplies (keeps the loads unconditional)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) wv[slot][ch] = *reinterpret_cast<const f32x4*>(wsrc + (TILED ? ((size_t)c * 2 + ch) * 256 : (size_t)c * 32 + 16 * ch));
 #pragma unroll
-        for (int t = 0; t < 2; ++t) xg[slot][t] = *reinterpret_cast<const f32x4*>(xsrc[t] + c * 32);
+        for (int t = 0; t < 2 * MT; ++t) xg[slot][t] = *reinterpret_cast<const f32x4*>(xsrc[t] + c * 32);
     };
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     auto multiply = [&](int slot) {
         // rows -> fragments through the wave's patch (in-order LDS: the reads below see the writes above, the next step's writes follow these reads)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4*>(pw + 8 * t * PITCH) = xg[slot][t];
-        f32x4 xf[2];
+        for (int t = 0; t < 2 * MT; ++t) *reinterpret_cast<f32x4*>(pw + 8 * t * PITCH) = xg[slot][t];
+        f32x4 xf[MT][2];
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) xf[ch] = *reinterpret_cast<const f32x4*>(pr + 16 * ch);
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch)                   // the two 16-k chunks of the step, ascending
+            for (int ch = 0; ch < 2; ++ch) xf[mt][ch] = *reinterpret_cast<const f32x4*>(pr + 16 * mt * PITCH + 16 * ch);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][ch][e], xf[ch][e], acc, 0, 0, 0);
+        for (int ch = 0; ch < 2; ++ch)                   // the two 16-k chunks of the step, ascending; per output ONE chain, whatever MT
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][ch][e], xf[mt][ch][e], acc[mt], 0, 0, 0);
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) fetch(d, d);
@@ -88,12 +96,15 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
     for (int d = 0; d < DEPTH; ++d)
         if (c0 + d < NST) multiply(d);
     // D map: column = lane & 15 -> row m of y; register i of lane group q -> column n0 + 4 q + i
-    const int m = m0 + r;
-    if (m >= g.M) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + 4 * q + i;
-        if (n < g.N) gemm_store<float>(g, 0, m, n, acc[i]);
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + 16 * mt + r;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + 4 * q + i;
+            if (n < g.N) gemm_store<float>(g, 0, m, n, acc[mt][i]);
+        }
     }
 }
 
@@ -106,17 +117,22 @@ bool exact_mfma_ok(const GemmArgs& g) {
     return (g.store == STORE_ROWS || g.store == STORE_QKV) && exact_mfma_small(g);
 }
 
-// Small row counts only: one 16 x 16 tile per wave puts 4 x the waves of a 32 x 32 tiling on the chip, which is what a 64-row GEMM
-// needs (288 workgroups instead of 72: 960 -> 397 ms of AR loop per batch-64 step).  From ~1024 tiles of 32 x 32 the LDS-shared
-// 64 x 64 tile of gemm_tile_kernel (the same summation order since round 4) moves half the operand bytes per FLOP and wins
-// (a 32 x 32-per-wave variant of this kernel measured 178 vs 155 ms per 64 images at 640 rows, 154 vs 119 at 2048: dropped).
-bool exact_mfma_small(const GemmArgs& g) { return (long long)((g.M + 31) / 32) * ((g.N + 31) / 32) < 1024; }
+// Small row counts only (the 64-row passes of one batch-64 step at a time and their 256-row depth sub-step): a 64-row GEMM of the body is 72
+// workgroups for the 64 x 64 LDS tile of gemm_tile_kernel and 144-1152 waves here (960 -> 263 ms of AR loop per batch-64 step with one tile per
+// wave).  Above 256 rows gemm_tile_kernel (the same summation order since round 4) moves fewer operand bytes per FLOP and wins (a 32 x 32-per-wave
+// variant of this kernel measured 178 vs 155 ms per 64 images at 640 rows, 154 vs 119 at 2048: dropped).
+bool exact_mfma_small(const GemmArgs& g) { return g.M <= 256; }
 
 hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st) {
-    const int TM = (g.M + 15) / 16, TN = (g.N + 15) / 16;
+    // tiles per wave: as many as still leave about one wave per SIMD (1024)
+    const int t16 = (g.M + 15) / 16, TN = (g.N + 15) / 16;
+    const int MT = (t16 % 4 == 0 && (long long)(t16 / 4) * TN >= 768) ? 4 : ((t16 % 2 == 0 && (long long)(t16 / 2) * TN >= 512) ? 2 : 1);
+    const int TM = (t16 + MT - 1) / MT;
     const unsigned grid = (unsigned)(((long long)TM * TN + 3) / 4);
-    if (g.b_tile16) exact_mfma_gemm_kernel<true><<<grid, 256, 0, st>>>(g, TM, TN);
-    else exact_mfma_gemm_kernel<false><<<grid, 256, 0, st>>>(g, TM, TN);
+#define HQT_EXACT_LAUNCH(TILED, MT_) exact_mfma_gemm_kernel<TILED, MT_><<<grid, 256, 0, st>>>(g, TM, TN)
+    if (g.b_tile16) { if (MT == 4) HQT_EXACT_LAUNCH(true, 4); else if (MT == 2) HQT_EXACT_LAUNCH(true, 2); else HQT_EXACT_LAUNCH(true, 1); }
+    else { if (MT == 4) HQT_EXACT_LAUNCH(false, 4); else if (MT == 2) HQT_EXACT_LAUNCH(false, 2); else HQT_EXACT_LAUNCH(false, 1); }
+#undef HQT_EXACT_LAUNCH
     return hipGetLastError();
 }
 
