@@ -124,10 +124,18 @@ bool exact_mfma_ok(const GemmArgs& g) {
 bool exact_mfma_small(const GemmArgs& g) { return g.M <= 256; }
 
 hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st) {
-    // tiles per wave: as many as still leave about one wave per SIMD (1024)
+    // Row tiles per wave: a wave's time is MT x (K / 4) matrix instructions (x 40 / 32 for a single dependent chain), the launch takes
+    // ceil(waves / 1024 SIMDs) such rounds -- 1152 waves of MT = 4 are two rounds of four, 2304 of MT = 2 three rounds of two (rocprof: 90 us
+    // for the 256-row qkv at MT = 4).  Ties go to the larger MT (the W stream is fetched by fewer waves).
     const int t16 = (g.M + 15) / 16, TN = (g.N + 15) / 16;
-    const int MT = (t16 % 4 == 0 && (long long)(t16 / 4) * TN >= 768) ? 4 : ((t16 % 2 == 0 && (long long)(t16 / 2) * TN >= 512) ? 2 : 1);
-    const int TM = (t16 + MT - 1) / MT;
+    int MT = 1;
+    long long best = -1;
+    for (int mt : {1, 2, 4}) {
+        if (t16 % mt) continue;
+        const long long waves = (long long)(t16 / mt) * TN, cost = ((waves + 1023) / 1024) * mt * (mt == 1 ? 5 : 4);
+        if (best < 0 || cost <= best) { best = cost; MT = mt; }
+    }
+    const int TM = t16 / MT;
     const unsigned grid = (unsigned)(((long long)TM * TN + 3) / 4);
 #define HQT_EXACT_LAUNCH(TILED, MT_) exact_mfma_gemm_kernel<TILED, MT_><<<grid, 256, 0, st>>>(g, TM, TN)
     if (g.b_tile16) { if (MT == 4) HQT_EXACT_LAUNCH(true, 4); else if (MT == 2) HQT_EXACT_LAUNCH(true, 2); else HQT_EXACT_LAUNCH(true, 1); }
