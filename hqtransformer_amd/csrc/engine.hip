@@ -930,7 +930,9 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         HIPCHK(launch_gemm_generic(g, a_dt, DT_BF16, c_dt, st));
         return HQT_OK;
     }
-    if (md.split_ar && l.w16h && l.w16l && !g.conv_taps && !g.a_packed_mb) {
+    // (up to 256 rows the fp32 matrix instructions of exact_gemm.hip are faster than three fp16 MFMAs on 128 x 128 tiles that are mostly padding:
+    //  249 vs 483 ms of AR loop per batch-64 step -- SPLIT takes them there, and is bit-identical to EXACT on those launches)
+    if (md.split_ar && l.w16h && l.w16l && !g.conv_taps && !g.a_packed_mb && g.M > 256) {
         GemmArgs sg = g;
         sg.a_f32 = 1; sg.Bw = l.w16h; sg.Bw_lo = l.w16l; sg.range_flag = h->range_flag;
         if (split_gemm_ok(sg)) {

@@ -51,6 +51,14 @@ def test_merged_pass_kernels_vs_oracle_at_imagenet_width(B, n):
     assert np.abs(np_(lg) - want[2]).max() <= LOGIT_TOL
     assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all()
     # SPLIT AR (fp32-accurate on the matrix cores, round 4) at the same merged-pass rows: the EXACT bar
+    eng.timing(True)
+    eng.timing_reset()
+    st, sb, ls = eng.sample(B, tc, n, precision=PRECISION_SPLIT, noise=tn, return_logits=True, use_graph=False)
+    vs = variants(eng)
+    eng.timing(False)
+    assert sum(c for k, c in vs.items() if k.startswith('variant:split_gemm:')) == 14 * n, vs      # every nn.Linear of the pass on the fp16 hi / lo matrix path
+    assert np.abs(np_(ls) - want[2]).max() <= LOGIT_TOL
+    assert (np_(st) == want[0]).all() and (np_(sb) == want[1]).all()
     st, sb, ls = eng.sample(B, tc, n, precision=PRECISION_SPLIT, noise=tn, return_logits=True, use_graph=True)
     assert np.abs(np_(ls) - want[2]).max() <= LOGIT_TOL
     assert (np_(st) == want[0]).all() and (np_(sb) == want[1]).all()
