@@ -583,8 +583,10 @@ bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
     if (g.N % 128 != 0 || g.K % 32 != 0 || g.K < 256 || g.ldc % 8 != 0 || g.resid) return false;
     if (g.store == STORE_QKV) return c_dt == DT_BF16 && g.qkv_D % 128 == 0 && g.rows_per_group > 0;
     if (g.store == STORE_PACKED) return c_dt == DT_BF16 && g.c_packed_mb > 0;
-    // (proj, K = D, below 1024 rows: 48 tiles of one short K loop each -- the streaming kernel's 64-row tiles measured 18 vs 26 us there)
-    if (g.store == STORE_RESID) return c_dt == DT_F32 && g.c_packed_mb > 0 && !g.ln_parts && g.resid_pk && g.resid_parts && g.N == g.ldc && (g.K >= 3072 || g.M >= 1024);
+    // (proj, K = D: one short K loop over 48 column-tile rows.  Below 640 rows the streaming kernel's 64-row tiles win (23.5 vs 25.2 us at 512 rows); from 640
+    //  rows the 8-wave 64 x 128 tiles do (27.8 -> 24.9 us at 640, 30.0 -> 26.8 at 768, 37.5 -> 29.3 at 1024; HQT_TILE_W8_RESID=0: round 3's choice))
+    static const int w8r = getenv("HQT_TILE_W8_RESID") ? atoi(getenv("HQT_TILE_W8_RESID")) : 1;
+    if (g.store == STORE_RESID) return c_dt == DT_F32 && g.c_packed_mb > 0 && !g.ln_parts && g.resid_pk && g.resid_parts && g.N == g.ldc && (g.K >= 3072 || g.M >= (w8r ? 640 : 1024));
     if (g.store == STORE_ROWS) return g.rows_per_group == 0;
     return false;
 }
@@ -602,6 +604,9 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
         if (w8 && t64 <= 512 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE) return TilePlan{2, Tile64::BM, Tile64::BN, 1};
         return TilePlan{1, Tile64::BM, Tile64::BN, 1};
     }
+    static const int w8r = getenv("HQT_TILE_W8_RESID") ? atoi(getenv("HQT_TILE_W8_RESID")) : 1;      // the narrow residual producer (proj) on 8-wave 64 x 128 tiles
+    if (w8r && g.store == STORE_RESID && g.K < 3072 && tiles < 256 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
+        return TilePlan{2, Tile64::BM, Tile64::BN, 1};
     if (g.store == STORE_RESID && g.K >= 3072 && tiles < 256) {
         for (int S : {8, 6, 4, 3, 2})
             if (S <= max_s && tiles * S <= 576 && KS % (Tile128::KU * S) == 0 && KS / S / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = S; break; }
