@@ -95,3 +95,31 @@ def test_traffic_is_keyed_by_the_rows_of_the_pass():
     assert mod.pmc_traffic('stream_gemm', rows[0]) == doc['by_rows'][str(rows[0])]['stream_gemm']
     assert mod.pmc_traffic('stream_gemm', 7) is None
     assert mod.pmc_traffic('decoder_conv') == doc['decoder_conv']
+
+
+def test_round4_records_of_the_committed_driver_line():
+    """What VERDICT r03 asked the line to carry: the schedule in the workload string, the one-step-at-a-time record under its own name, the
+    bit-exact arithmetic's throughput, the gather flag, and traffic only from counters collected at the rows of the timed pass."""
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_driver_steps20.json')))
+    d = json.load(open(files[-1]))
+    if 'like_for_like' not in d:                      # lines of earlier rounds
+        return
+    cfg = d['config']
+    assert d['steps'] == 20 and cfg['rows_per_pass'] == cfg['steps_per_pass'] * cfg['per_gpu_batch']
+    assert f"merged into {cfg['rows_per_pass']}-row passes" in cfg['workload'] and 'like_for_like' in cfg['workload']
+    lfl = d['like_for_like']
+    assert lfl['images_in_flight_per_gpu'] == cfg['per_gpu_batch'] and lfl['value'] == d['serial']['value'] and lfl['value'] < d['value']
+    assert abs(lfl['ms_per_step'] - (lfl['phase_ms']['ar'] + lfl['phase_ms']['decode'])) / lfl['ms_per_step'] < 0.05
+    assert d['bit_exact_codes'] is False and d['gather_ok'] is None            # FAST arithmetic timed; one GPU: no collective
+    em = d['exact_mode']
+    for mode in ('split', 'exact'):
+        assert em[mode]['like_for_like']['steps'] >= 3 and em[mode]['like_for_like']['value'] > 0
+        assert em[mode]['merged']['rows_per_pass'] % cfg['per_gpu_batch'] == 0
+    assert em['split']['merged']['value'] > em['exact']['merged']['value']     # the matrix-core arithmetic is the faster bit-exact one in merged passes
+    gemm = [r for r in [d['roofline']] + d['roofline_other'] if 'AR GEMM family' in r['kernel']][0]
+    doc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
+    want = doc.get('by_rows', {}).get(str(gemm['rows_per_pass']), {}).get('stream_gemm')
+    # attached only from a counter pass at these rows: None when the line predates the pass; otherwise the committed pass of its own
+    # evidence run or the one before it (the line reads the file committed when it ran) -- the same kernels, within a few per cent
+    assert gemm['traffic'] is None or (want is not None and abs(gemm['traffic'] - want) / want < 0.05)
+    assert d['cpu_baseline']['kind'] == 'native-port' and d['cpu_baseline']['cores'] >= 1
