@@ -23,7 +23,7 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-// One wave = one 16 x 16 output tile over the whole K, v_mfma_f32_16x16x4_f32.  Operand maps (cdna_hip_programming.md §3): lane l = r + 16 q supplies
+// One workgroup = one 16 MT x 16 output tile, its four waves a quarter of K each, v_mfma_f32_16x16x4_f32.  Operand maps (cdna_hip_programming.md §3): lane l = r + 16 q supplies
 // A[i = r][k = q] and B[k = q][j = r]; with A = W (i = column n of y) and B = x (j = row m of y) the result D has m on the lanes and four consecutive
 // n per lane.  Per 32-k step a lane needs W[n0 + r][kb + 16 ch + 4 q .. + 3] and x[m0 + r][the same k] (ch = 0, 1), element e feeding MFMA e of the chunk.
 //   * W comes from the fragment-ordered fp32 copy made at finalize ([n / 16][k / 32][chunk][lane][4]): one fully coalesced 1-KiB load per chunk.
@@ -38,10 +38,12 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
     // instruction's 40-cycle dependent latency against its 32-cycle issue disappears, and the W stream is fetched by 1 / MT as many waves
     constexpr int PITCH = 36;                            // floats per staged row: the 16 rows of a fragment read start in 16 different 4-bank groups
     __shared__ __attribute__((aligned(16))) float patch_all[4][MT * 16 * PITCH];
+    __shared__ __attribute__((aligned(16))) float red_all[3][MT][64][4];       // partial tiles of waves 1 .. 3
+    // The FOUR WAVES of a workgroup share one output tile and split its K: wave w chains the 32-k steps with index = w (mod 4), ascending;
+    // the four partial tiles meet in LDS and leave as (p0 + p1) + (p2 + p3) -- the summation order gemm_tile_kernel uses too (gemm_generic.h).
+    // Chains are a quarter as long (fc2 at 64 rows: 1536 dependent matrix instructions per wave before), and four times the waves fill the chip.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long tile = (long long)blockIdx.x * 4 + wave;
-    if (tile >= (long long)TM * TN) return;              // whole waves leave; the kernel has no workgroup barrier
-    const int tm = (int)(tile % TM), tn = (int)(tile / TM);       // the waves of a workgroup: neighbouring row tiles of ONE column tile (the W stream is shared through the L1)
+    const int tm = (int)(blockIdx.x % TM), tn = (int)(blockIdx.x / TM);
     const int r = lane & 15, q = lane >> 4;
     const int m0 = tm * 16 * MT, n0 = tn * 16;
     const int NST = g.K >> 5;
@@ -81,20 +83,36 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][ch][e], xf[mt][ch][e], acc[mt], 0, 0, 0);
     };
+    // this wave's steps: wave, wave + 4, ... (NW of them); slot d holds its (c0 + d)-th
+    const int NW = (NST - wave + 3) >> 2;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) fetch(d, d);
+    for (int d = 0; d < DEPTH; ++d) fetch(wave + 4 * d, d);
     int c0 = 0;
-    for (; c0 + DEPTH <= NST; c0 += DEPTH) {
+    for (; c0 + DEPTH <= NW; c0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             multiply(d);
-            fetch(c0 + d + DEPTH, d);
+            fetch(wave + 4 * (c0 + d + DEPTH), d);
         }
     }
-    // tail: NST % DEPTH steps, already in slots 0 .. (their loads were issued above)
+    // tail: NW % DEPTH steps, already in slots 0 .. (their loads were issued above)
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-        if (c0 + d < NST) multiply(d);
+        if (c0 + d < NW) multiply(d);
+    // (p0 + p1) + (p2 + p3)
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(red_all[wave - 1][mt][lane]) = acc[mt];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(red_all[0][mt][lane]), p2 = *reinterpret_cast<const f32x4*>(red_all[1][mt][lane]),
+                    p3 = *reinterpret_cast<const f32x4*>(red_all[2][mt][lane]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mt][i] = (acc[mt][i] + p1[i]) + (p2[i] + p3[i]);
+    }
     // D map: column = lane & 15 -> row m of y; register i of lane group q -> column n0 + 4 q + i
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -124,19 +142,18 @@ bool exact_mfma_ok(const GemmArgs& g) {
 bool exact_mfma_small(const GemmArgs& g) { return g.M <= 256; }
 
 hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st) {
-    // Row tiles per wave: a wave's time is MT x (K / 4) matrix instructions (x 40 / 32 for a single dependent chain), the launch takes
-    // ceil(waves / 1024 SIMDs) such rounds -- 1152 waves of MT = 4 are two rounds of four, 2304 of MT = 2 three rounds of two (rocprof: 90 us
-    // for the 256-row qkv at MT = 4).  Ties go to the larger MT (the W stream is fetched by fewer waves).
+    // Row tiles per wave: a wave's time is ~MT x (K / 16) matrix instructions, the launch takes ceil(4 waves x tiles / 4096 wave slots) such
+    // rounds (four per SIMD at these register counts).  Ties go to the larger MT (the W stream is fetched by fewer workgroups).
     const int t16 = (g.M + 15) / 16, TN = (g.N + 15) / 16;
     int MT = 1;
     long long best = -1;
     for (int mt : {1, 2, 4}) {
         if (t16 % mt) continue;
-        const long long waves = (long long)(t16 / mt) * TN, cost = ((waves + 1023) / 1024) * mt * (mt == 1 ? 5 : 4);
+        const long long waves = 4LL * (t16 / mt) * TN, cost = ((waves + 4095) / 4096) * mt * (mt == 1 ? 5 : 4);
         if (best < 0 || cost <= best) { best = cost; MT = mt; }
     }
     const int TM = t16 / MT;
-    const unsigned grid = (unsigned)(((long long)TM * TN + 3) / 4);
+    const unsigned grid = (unsigned)((long long)TM * TN);
 #define HQT_EXACT_LAUNCH(TILED, MT_) exact_mfma_gemm_kernel<TILED, MT_><<<grid, 256, 0, st>>>(g, TM, TN)
     if (g.b_tile16) { if (MT == 4) HQT_EXACT_LAUNCH(true, 4); else if (MT == 2) HQT_EXACT_LAUNCH(true, 2); else HQT_EXACT_LAUNCH(true, 1); }
     else { if (MT == 4) HQT_EXACT_LAUNCH(false, 4); else if (MT == 2) HQT_EXACT_LAUNCH(false, 2); else HQT_EXACT_LAUNCH(false, 1); }
