@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
     constexpr int PITCH = 36;                            // floats per staged row: the 16 rows of a fragment read start in 16 different 4-bank groups
     __shared__ __attribute__((aligned(16))) float patch_all[4][MT * 16 * PITCH];
     __shared__ __attribute__((aligned(16))) float red_all[3][MT][64][4];       // partial tiles of waves 1 .. 3
-    // The FOUR WAVES of a workgroup share one output tile and split its K: wave w chains the 32-k steps with index = w (mod 4), ascending;
+    // The FOUR WAVES of a workgroup share one output tile and split its K: wave w chains the w-th contiguous quarter of the 32-k steps, ascending;
     // the four partial tiles meet in LDS and leave as (p0 + p1) + (p2 + p3) -- the summation order gemm_tile_kernel uses too (gemm_generic.h).
     // Chains are a quarter as long (fc2 at 64 rows: 1536 dependent matrix instructions per wave before), and four times the waves fill the chip.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -83,16 +83,16 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[slot][ch][e], xf[mt][ch][e], acc[mt], 0, 0, 0);
     };
-    // this wave's steps: wave, wave + 4, ... (NW of them); slot d holds its (c0 + d)-th
-    const int NW = (NST - wave + 3) >> 2;
+    // this wave's steps: the contiguous quarter [lo, lo + NW) of the NST; slot d holds step lo + c0 + d
+    const int lo = (NST * wave) >> 2, NW = ((NST * (wave + 1)) >> 2) - lo;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) fetch(wave + 4 * d, d);
+    for (int d = 0; d < DEPTH; ++d) fetch(lo + d, d);
     int c0 = 0;
     for (; c0 + DEPTH <= NW; c0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             multiply(d);
-            fetch(wave + 4 * (c0 + d + DEPTH), d);
+            fetch(lo + c0 + d + DEPTH, d);
         }
     }
     // tail: NW % DEPTH steps, already in slots 0 .. (their loads were issued above)

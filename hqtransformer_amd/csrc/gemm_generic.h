@@ -127,7 +127,7 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, int bz, int m, int
     st1<TC>(reinterpret_cast<TC*>(g.C) + idx, v);
 }
 
-template <typename TA, typename TB, typename TC>
+template <typename TA, typename TB, typename TC, bool QUARTERS = false>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
     __shared__ float As[16][68];
     __shared__ float Bs[16][68];
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
     const TB* brow = reinterpret_cast<const TB*>(g.Bw) + (long long)bz * g.b_batch_stride + (long long)(b_ok ? bn : 0) * g.ldb;
     const int tx = tid & 15, ty = tid >> 4;
     // Summation order of an output (shared, bit for bit, with exact_gemm.hip's fp32 matrix-instruction kernel, so that an output does not
-    // depend on which of the two a row count selects): K is cut into steps of 32; partial s (0 .. 3) chains the steps with index = s (mod 4),
-    // ascending, each step's two 16-wide chunks in the k order [0 4 8 12 | 1 5 9 13 | 2 6 10 14 | 3 7 11 15]; the result is (p0 + p1) + (p2 + p3).
-    // (Four interleaved chains instead of one: the matrix-instruction kernel gives one to each wave of a workgroup.)
+    // depend on which of the two a row count selects): K is cut into steps of 32 and the steps into four contiguous quarters (boundaries
+    // (steps x s) / 4); partial s chains its quarter ascending, each 16-wide chunk in the k order [0 4 8 12 | 1 5 9 13 | 2 6 10 14 | 3 7 11 15];
+    // the result is (p0 + p1) + (p2 + p3).  (Four chains instead of one: the matrix-instruction kernel gives one to each wave of a workgroup.)
     float part[4][4][4];
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp)
@@ -151,31 +151,39 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) part[sp][i][j] = 0.0f;
 
-    for (int kb = 0; kb < g.K; kb += 128) {
+    auto chunk = [&](int k0, float (&ps)[4][4]) {
+        float a4[4], b4[4];
+        al.load(k0 + lk, a4);
+        if (b_ok) ld4<TB>(brow + k0 + lk, b4); else b4[0] = b4[1] = b4[2] = b4[3] = 0.0f;
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) {
-            const int k0 = kb + 16 * c8;
-            if (k0 >= g.K) break;                        // uniform over the workgroup (K % 16 == 0)
-            float a4[4], b4[4];
-            al.load(k0 + lk, a4);
-            if (b_ok) ld4<TB>(brow + k0 + lk, b4); else b4[0] = b4[1] = b4[2] = b4[3] = 0.0f;
+        for (int i = 0; i < 4; ++i) { As[lk + i][lrow] = a4[i]; Bs[lk + i][lrow] = b4[i]; }
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { As[lk + i][lrow] = a4[i]; Bs[lk + i][lrow] = b4[i]; }
-            __syncthreads();
+        for (int ki = 0; ki < 16; ++ki) {
+            const int kk = (ki & 3) * 4 + (ki >> 2);
+            const float4 av = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+            const float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+            const float a[4] = {av.x, av.y, av.z, av.w};
+            const float b[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-            for (int ki = 0; ki < 16; ++ki) {
-                const int kk = (ki & 3) * 4 + (ki >> 2);
-                const float4 av = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
-                const float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
-                const float a[4] = {av.x, av.y, av.z, av.w};
-                const float b[4] = {bv.x, bv.y, bv.z, bv.w};
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) part[c8 >> 1][i][j] = fmaf(a[i], b[j], part[c8 >> 1][i][j]);
-            }
-            __syncthreads();
+                for (int j = 0; j < 4; ++j) ps[i][j] = fmaf(a[i], b[j], ps[i][j]);
         }
+        __syncthreads();
+    };
+    // QUARTERS: the plain fp32 nn.Linear launches of the AR loop above 256 rows (below, exact_mfma_gemm_kernel computes the same chains).  Every other
+    // use -- the decoder's convolutions and attention products, bf16 fallbacks -- keeps ONE chain per output (the four partial tiles cost 178 registers
+    // and a third of the EXACT decoder's speed), with the same order inside a chunk.
+    if (QUARTERS) {
+        const int nst = g.K >> 5;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+            const int k_lo = 32 * ((nst * sp) >> 2), k_hi = sp == 3 ? g.K : 32 * ((nst * (sp + 1)) >> 2);
+            for (int k0 = k_lo; k0 < k_hi; k0 += 16) chunk(k0, part[sp]);
+        }
+    } else {
+        for (int k0 = 0; k0 < g.K; k0 += 16) chunk(k0, part[0]);
     }
     float acc[4][4];
 #pragma unroll

@@ -1951,7 +1951,12 @@ hipError_t launch_gemm_generic(const GemmArgs& g, int ta, int tb, int tc, hipStr
     const dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, g.batch > 0 ? g.batch : 1);
     const int key = ta * 4 + tb * 2 + tc;
     switch (key) {
-        case 0: gemm_tile_kernel<float, float, float><<<grid, 256, 0, st>>>(g); break;
+        case 0:
+            // plain fp32 nn.Linear (the AR loop): the four-quarter summation order exact_mfma_gemm_kernel shares (exact_gemm.hip)
+            if (!g.conv_taps && !g.a_packed_mb && !g.a_rows_per_group && g.batch <= 1 && !g.gn_stats && g.K % 32 == 0 && (g.store == STORE_ROWS || g.store == STORE_QKV))
+                gemm_tile_kernel<float, float, float, true><<<grid, 256, 0, st>>>(g);
+            else gemm_tile_kernel<float, float, float><<<grid, 256, 0, st>>>(g);
+            break;
         case 7: gemm_tile_kernel<bf16_t, bf16_t, bf16_t><<<grid, 256, 0, st>>>(g); break;
         case 6: gemm_tile_kernel<bf16_t, bf16_t, float><<<grid, 256, 0, st>>>(g); break;
         case 2: gemm_tile_kernel<float, bf16_t, float><<<grid, 256, 0, st>>>(g); break;
