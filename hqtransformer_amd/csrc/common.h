@@ -180,6 +180,8 @@ struct GemmArgs {
     int a_f32;               // split_gemm_kernel only: A is the fp32 tensor itself ([row][K], lda floats); the hi / lo split happens while the tile is staged
     int b_f32;               // split_gemm_kernel only, with a_f32: Bw is an fp32 tensor too ([n][K], ldb floats; Bw_lo unused)
     int* range_flag;         // a_f32 / b_f32: where an element outside the fp16 range is reported (hqt_range_check)
+    int k_quarters;          // fp32 nn.Linear of the AR loop (set by run_linear for its gemm_* launches): the four-quarter summation order shared by
+                             //   exact_mfma_gemm_kernel (<= 256 rows) and gemm_tile_kernel<..., QUARTERS>; every other fp32 GEMM keeps one chain per output
     int b_tile16;            // exact_mfma_gemm_kernel only: Bw is the fragment-ordered fp32 copy [n / 16][k / 32][chunk][lane][4] (pack_exact_tiles_kernel)
 };
 

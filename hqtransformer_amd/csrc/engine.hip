@@ -942,6 +942,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         }
     }
     g.Bw = l.w32;
+    g.k_quarters = strncmp(tag, "gemm_", 5) == 0;          // the AR loop's nn.Linear launches (gemm_qkv / proj / fc1 / fc2 / head): see GemmArgs.k_quarters
     if (h->gn_ready.tensor == g.C) h->gn_ready.tensor = nullptr;
     if (exact_mfma_ok(g)) {                      // plain fp32 nn.Linear (the AR loop): the fp32 matrix instructions, one tile per wave
         if (l.w32t && g.N % 16 == 0) { g.Bw = l.w32t; g.b_tile16 = 1; }

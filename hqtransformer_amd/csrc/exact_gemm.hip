@@ -6,14 +6,16 @@
 // multiply-add per product, fp32 accumulation.  v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 compute exactly that -- per output a
 // k-ordered chain of fmaf, one rounding per product, no wider internal accumulator (MI355X_MICROARCH.md, 'FP32-input MFMA') -- at the
 // fp32 vector rate, but without the 64 x 64 LDS tile of gemm_tile_kernel (gemm_generic.h), which leaves 72 workgroups for a 64-row
-// GEMM of the body (0.16 TB/s of weights: 15 ms per top position at batch 64).  Here a WAVE owns a T x T output tile (T = 16 or 32)
-// and walks K alone: no workgroup barrier, a register ring of DEPTH 32-k steps in flight (operand paths: at the kernel).
+// GEMM of the body (0.16 TB/s of weights: 15 ms per top position at batch 64).  Here a WORKGROUP owns a (16 MT) x 16 output tile and
+// its four waves a quarter of K each: no barrier until the final sum, a register ring of DEPTH 32-k steps in flight per wave.
 //
-// Summation order.  Element e of a lane's float4 feeds MFMA step e, so inside a 16-wide chunk the k indices enter an output's chain in
-// the order [0 4 8 12 | 1 5 9 13 | 2 6 10 14 | 3 7 11 15] (16x16x4: one instruction per group; 32x32x2: two, (0 4) then (8 12)), chunks
-// ascending.  gemm_tile_kernel (the vector-ALU kernel larger row counts keep) walks its 16-wide chunks in that same order, and a
-// k-ordered fmaf chain is what both compute, so an output's bits do not depend on the kernel the row count selects -- a step's EXACT
-// draws AND logits stay independent of the pass it is merged into (tests/test_gpu_timed_schedule.py compares them bit for bit).
+// Summation order (what makes the result independent of the kernel).  K is cut into steps of 32 and the steps into four contiguous
+// quarters (boundaries (steps x s) / 4); partial s chains its quarter ascending; element e of a lane's float4 feeds matrix instruction
+// e of a 16-wide chunk, so inside a chunk the k indices enter the chain as [0 4 8 12 | 1 5 9 13 | 2 6 10 14 | 3 7 11 15]; the output is
+// (p0 + p1) + (p2 + p3).  gemm_tile_kernel<..., QUARTERS> -- the vector-ALU kernel the same nn.Linear takes above 256 rows -- computes
+// the same four chains in the same order, and a k-ordered fmaf chain is what both instructions are, so an output's BITS do not depend
+// on the kernel its row count selects: a step's EXACT draws and logits are independent of the pass it is merged into
+// (tests/test_gpu_timed_schedule.py compares the logits of a 64-row call with the same rows of a 512 / 2048-row pass bit for bit).
 #include "gemm_generic.h"
 #include "kernels.h"
 #include <algorithm>
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
 bool exact_mfma_small(const GemmArgs& g);
 bool exact_mfma_ok(const GemmArgs& g) {
     static const bool off = getenv("HQT_NO_EXACT_MFMA") != nullptr;                // A/B switch: the 64 x 64 vector-ALU tile kernel for everything
-    if (off || g.conv_taps || g.a_packed_mb || g.a_rows_per_group || g.batch > 1 || g.gn_stats) return false;
+    if (off || !g.k_quarters || g.conv_taps || g.a_packed_mb || g.a_rows_per_group || g.batch > 1 || g.gn_stats) return false;
     if (g.K % 32 != 0 || g.K < 32 || g.lda % 4 != 0 || g.ldb % 4 != 0) return false;
     return (g.store == STORE_ROWS || g.store == STORE_QKV) && exact_mfma_small(g);
 }

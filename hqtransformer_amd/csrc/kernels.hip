@@ -1953,7 +1953,7 @@ hipError_t launch_gemm_generic(const GemmArgs& g, int ta, int tb, int tc, hipStr
     switch (key) {
         case 0:
             // plain fp32 nn.Linear (the AR loop): the four-quarter summation order exact_mfma_gemm_kernel shares (exact_gemm.hip)
-            if (!g.conv_taps && !g.a_packed_mb && !g.a_rows_per_group && g.batch <= 1 && !g.gn_stats && g.K % 32 == 0 && (g.store == STORE_ROWS || g.store == STORE_QKV))
+            if (g.k_quarters && !g.conv_taps && !g.a_packed_mb && !g.a_rows_per_group && g.batch <= 1 && !g.gn_stats && g.K % 32 == 0 && (g.store == STORE_ROWS || g.store == STORE_QKV))
                 gemm_tile_kernel<float, float, float, true><<<grid, 256, 0, st>>>(g);
             else gemm_tile_kernel<float, float, float><<<grid, 256, 0, st>>>(g);
             break;
