@@ -1676,6 +1676,24 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
         const int hw = l.res * l.res;
         GemmArgs g = conv_args(c.cur, n, l.res, l.cin, 9, 0, out, l.cout);
         g.store = STORE_NCHW; g.rows_per_image = hw; g.clamp01 = clamp01;
+        if (md.split && l.conv1.w32) {       // SPLIT: the fp32 tensor is read once -- GroupNorm + swish + the three output channels in one fp32 kernel
+            GemmArgs d = g;
+            d.N = l.conv1.N; d.K = l.conv1.K; d.Bw = l.conv1.w32; d.bias = l.conv1.b32; d.alpha = 1.0f;
+            with_gn(d, c.gn1, l.n1_g, l.n1_b, 1);
+            if (conv_out_direct_ok(d)) {
+                {
+                    Timed t(h, "gn_stats", st);
+                    if (h->gn_ready.tensor == c.cur && h->gn_ready.dbl)
+                        HIPCHK(launch_gn_finalize_tiles_d(reinterpret_cast<const double*>(h->gn_tiles), c.gn1, n, h->gn_ready.tiles, hw, l.cin, 32, 1e-6f, st));
+                    else
+                        HIPCHK(launch_gn_stats_fast(c.cur, c.gn1, h->gn_partial, n, hw, l.cin, 32, 1e-6f, st, DT_F32));
+                }
+                Timed t(h, "conv_out", st);
+                HIPCHK(launch_conv_out_direct(d, st));
+                count_variant(h, "variant:conv_out_direct:conv_out");
+                continue;
+            }
+        }
         CHK(s1_norm(c, c.cur, l.cin, hw, c.gn1, l.n1_g, l.n1_b, 1, &g, &l.conv1));
         CHK(run_linear(h, md, g, l.conv1, adt, DT_F32, st, "conv_out"));
     }

@@ -44,3 +44,6 @@ bool split_stream_ok(const GemmArgs& g);          // g already passed split_conv
 int split_stream_tiles_per_image(const GemmArgs& g);
 hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st);
 hipError_t split_stream_configure();
+// norm_out -> swish -> conv_out (<= 4 channels, NCHW) in one fp32 kernel: g.A = the fp32 NHWC tensor, g.Bw = tap-major fp32 filters, g.gn_* set
+bool conv_out_direct_ok(const GemmArgs& g);
+hipError_t launch_conv_out_direct(const GemmArgs& g, hipStream_t st);

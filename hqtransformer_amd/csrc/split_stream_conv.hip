@@ -39,10 +39,19 @@ constexpr int R_CPITCH = 128 * 4 + 16;                          // fp32 staging 
 constexpr int R_LDS = 4 * R_PLANE;                              // two buffers x two planes = 48 KiB
 static_assert(64 * R_CPITCH <= R_LDS, "epilogue staging (64 pixels at a time) must fit in the patch buffers");
 
-__device__ __forceinline__ void r_xcd_tile(int& tile_m, int& tile_n) {
+__device__ __forceinline__ void r_xcd_tile(int& tile_m, int& tile_n, int panel) {
     const int nx = gridDim.x, total = gridDim.x * gridDim.y;
     int id = blockIdx.x + nx * blockIdx.y;
     if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    if (panel > 0) {
+        // panels of `panel` pixel tiles x all n-tiles; inside a panel the pixel tile runs fastest: the workgroups an XCD holds at one
+        // time walk ONE filter stream together (L2 hits) and each its own patch
+        const int per = panel * nx, p = id / per, r = id - p * per;
+        const int rows = min(panel, (int)gridDim.y - p * panel);
+        tile_n = r / rows;
+        tile_m = p * panel + (r - tile_n * rows);
+        return;
+    }
     tile_m = id / nx;
     tile_n = id - tile_m * nx;
 }
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring16_kernel(GemmArgs g
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fx = lane & 15, fk = lane >> 4;
     int tile_m, tile_n;
-    r_xcd_tile(tile_m, tile_n);
+    r_xcd_tile(tile_m, tile_n, g.tile_panel);
     const int n0 = tile_n * 128;
     const int tiles_x = g.W / R_TX, tiles_y = g.H / R_TY;
     const int img = tile_m / (tiles_x * tiles_y);
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring16_kernel(GemmArgs g
                         if (pr == 2) { HQT_READ_A16(cc, ntapoff, 0); HQT_READ_A16(cc, ntapoff, 1); }
                         else { HQT_READ_A16(cc, ntapoff, 2); HQT_READ_A16(cc, ntapoff, 3); }
                     }
-                    if (pr == 0) load_b(S + H_AHEAD, nslot);            // the slot tap s - 1 released takes the filters of tap s + 2
+                    if (pr == 0 && ABL != 5) load_b(S + H_AHEAD, nslot);            // the slot tap s - 1 released takes the filters of tap s + 2
                     if (pr == 1 && ABL != 2) {
                         // the piece of tap - 2: behind it were issued the filters of tap + 1 (4), the piece of tap - 1 and the filters of tap + 2 (4)
                         if (tap >= 2 && tap - 2 < PPW) {
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv2x2_split_up16_kernel(GemmArgs g) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fx = lane & 15, fk = lane >> 4;
     int tile_m, tile_v;
-    r_xcd_tile(tile_m, tile_v);
+    r_xcd_tile(tile_m, tile_v, g.tile_panel);
     const int NT = g.N / 128;                                       // real 128-channel tiles; the grid is 4 NT wide
     const int phase = tile_v / NT, pa = phase >> 1, pb = phase & 1;
     const int n0 = (tile_v - phase * NT) * 128;
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv2x2_split_up16_kernel(GemmArgs g) 
                 if (ABL != 4) {
                     if (tap == 1 || tap == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(wh[slot][0]), "+v"(wl[slot][0]), "+v"(wh[slot][1]), "+v"(wl[slot][1]));
                     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wh[slot][0]), "+v"(wl[slot][0]), "+v"(wh[slot][1]), "+v"(wl[slot][1]));
-                    load_b(S + 1, nslot);                               // the slot tap s - 1 released takes the filters of tap s + 1: a whole tap of MFMAs ahead
+                    if (ABL != 5) load_b(S + 1, nslot);                               // the slot tap s - 1 released takes the filters of tap s + 1: a whole tap of MFMAs ahead
                 }
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
@@ -845,4 +854,132 @@ hipError_t split_stream_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2x2_split_up16_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_split_out16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
+}
+
+// ---------------------------------------------------------------------------------------------
+// norm_out -> swish -> conv_out (stage1/modules/layers.py:404-410; <= 4 output channels, NCHW fp32 + clamp) in ONE kernel, fp32 FMAs.
+// conv_out is 0.26 % of the decoder's multiply-adds on the decoder's LARGEST tensor: on the matrix cores it needs the tensor as fp16
+// hi / lo planes (an operand pass over 2 x 2.1 GB at batch 64) and pads 3 output channels to a 16-channel MFMA block.  Here the fp32
+// tensor is read ONCE: a workgroup takes a 16 x 16 pixel tile, per 32-channel chunk it applies GroupNorm + swish while it fills the
+// (16 + 2) x (16 + 2) patch in LDS (zero padding = zeros AFTER the normalisation, as nn.Conv2d pads), then every thread accumulates the
+// three outputs of its pixel with packed fp32 FMAs -- filters from scalar registers (uniform addresses), patch rows on a 144-byte pitch
+// (8 consecutive pixels start in 8 different 16-byte bank groups).  The loads of chunk c + 1 are in flight under the FMAs of chunk c.
+// Exact fp32 products: no split, no range to check.  Bounds: 2.1 GB of HBM reads (0.42 ms at batch 64) / ~2.7 G swish evaluations.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int O_T = 16, O_P = O_T + 2, O_CH = 32, O_PITCH = O_CH + 4;          // tile edge, patch edge, channels per chunk, floats per patch row
+constexpr int O_LDS = O_P * O_P * O_PITCH * 4;                                  // 46656 B: three workgroups per CU
+constexpr int O_V4 = O_P * O_P * (O_CH / 4);                                    // float4 slots of a chunk's patch (2592)
+constexpr int O_PER = (O_V4 + 255) / 256;                                       // per thread (11; the last one partial)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+}  // namespace
+
+template <int NO>
+__global__ __launch_bounds__(256, 3) void conv_out_direct_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float* patch = reinterpret_cast<float*>(lds_raw);
+    const int tid = threadIdx.x;
+    const int tiles_x = g.W / O_T, tiles = tiles_x * (g.H / O_T);
+    const int img = blockIdx.x / tiles, trem = blockIdx.x - img * tiles;
+    const int ty0 = (trem / tiles_x) * O_T, tx0 = (trem % tiles_x) * O_T;
+    const int C = g.Cin, NC = C / O_CH;
+    const float* __restrict__ X = reinterpret_cast<const float*>(g.A) + (long long)img * g.H * g.W * C;
+    const float* __restrict__ Wt = reinterpret_cast<const float*>(g.Bw);        // [NO][9][C]
+    // this thread's patch slots: slot = tid + 256 u -> pixel slot / 8, channel quad slot % 8 (the same quad for every u)
+    const int v = tid & 7;
+    int src[O_PER];                                     // element offset of the pixel inside the image (clamped: every load is unconditional)
+    unsigned inside = 0;                                // bit u: slot u is a pixel of the image (else padding / past the patch: zeros)
+#pragma unroll
+    for (int u = 0; u < O_PER; ++u) {
+        const int q = (tid + 256 * u) >> 3;
+        const int qy = q / O_P, qx = q - qy * O_P;
+        const int iy = ty0 + qy - 1, ix = tx0 + qx - 1;
+        const bool in = (q < O_P * O_P) & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+        src[u] = in ? (iy * g.W + ix) * C + v * 4 : v * 4;
+        inside |= in ? 1u << u : 0u;
+    }
+    const int cpg = C / g.gn_groups;
+    const float* stats = g.gn_stats + (long long)img * g.gn_groups * 2;
+    f32x4 r[O_PER];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < O_PER; ++u) r[u] = *reinterpret_cast<const f32x4*>(X + src[u] + c * O_CH);
+    };
+    auto fill = [&](int c) {                            // GroupNorm + swish of the fetched quads into the patch
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = c * O_CH + v * 4 + j;
+            const float mu = stats[(ch / cpg) * 2], rs = stats[(ch / cpg) * 2 + 1];
+            a[j] = rs * g.gn_gamma[ch];
+            b[j] = g.gn_beta[ch] - mu * a[j];
+        }
+#pragma unroll
+        for (int u = 0; u < O_PER; ++u) {
+            const int slot = tid + 256 * u;
+            if (slot >= O_V4) continue;
+            f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (inside >> u & 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = r[u][j] * a[j] + b[j];
+                    if (g.gn_swish) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+                    y[j] = t;
+                }
+            }
+            *reinterpret_cast<f32x4*>(patch + (slot >> 3) * O_PITCH + v * 4) = y;
+        }
+    };
+    const int py = tid >> 4, px = tid & 15;
+    f32x2 acc[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[o] = f32x2{0.0f, 0.0f};
+    fetch(0);
+    for (int c = 0; c < NC; ++c) {
+        if (c > 0) __syncthreads();                     // the FMAs of chunk c - 1 have read the patch
+        fill(c);
+        __syncthreads();
+        if (c + 1 < NC) fetch(c + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* row = patch + ((py + tap / 3) * O_P + px + tap % 3) * O_PITCH;
+            f32x4 x[O_CH / 4];
+#pragma unroll
+            for (int q = 0; q < O_CH / 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(row + q * 4);
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const float* w = Wt + ((long long)o * 9 + tap) * C + c * O_CH;      // uniform: scalar loads
+#pragma unroll
+                for (int q = 0; q < O_CH / 4; ++q) {
+                    acc[o] += f32x2{x[q][0], x[q][1]} * f32x2{w[q * 4], w[q * 4 + 1]};
+                    acc[o] += f32x2{x[q][2], x[q][3]} * f32x2{w[q * 4 + 2], w[q * 4 + 3]};
+                }
+            }
+        }
+    }
+    float* Cb = reinterpret_cast<float*>(g.C);
+    const long long hw = (long long)g.H * g.W, pix = (long long)(ty0 + py) * g.W + tx0 + px;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        float val = (acc[o][0] + acc[o][1]) * g.alpha + (g.bias ? g.bias[o] : 0.0f);
+        if (g.clamp01) val = fminf(fmaxf(0.5f * val + 0.5f, 0.0f), 1.0f);
+        Cb[((long long)img * NO + o) * hw + pix] = val;
+    }
+}
+
+bool conv_out_direct_ok(const GemmArgs& g) {
+    static const bool off = getenv("HQT_CONV_OUT_DIRECT") && atoi(getenv("HQT_CONV_OUT_DIRECT")) == 0;        // A/B switch: 0 = operand pass + conv3x3_split_out16_kernel
+    return !off && g.conv_taps == 9 && g.store == STORE_NCHW && g.N >= 1 && g.N <= 4 && g.Cin % O_CH == 0 && g.H % O_T == 0 && g.W % O_T == 0 &&
+           !g.upsample && !g.conv_stride2 && !g.resid && g.gn_stats && g.gn_groups > 0 && g.Cin % g.gn_groups == 0 &&
+           (long long)g.H * g.W * g.Cin < (1ll << 31);
+}
+hipError_t launch_conv_out_direct(const GemmArgs& g, hipStream_t st) {
+    const int grid = (g.M / (g.H * g.W)) * (g.H / O_T) * (g.W / O_T);
+    switch (g.N) {
+        case 1: conv_out_direct_kernel<1><<<grid, 256, O_LDS, st>>>(g); break;
+        case 2: conv_out_direct_kernel<2><<<grid, 256, O_LDS, st>>>(g); break;
+        case 3: conv_out_direct_kernel<3><<<grid, 256, O_LDS, st>>>(g); break;
+        default: conv_out_direct_kernel<4><<<grid, 256, O_LDS, st>>>(g); break;
+    }
+    return hipGetLastError();
 }

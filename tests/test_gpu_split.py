@@ -1,5 +1,6 @@
 """SPLIT precision (fp32-accurate convolutions on the matrix cores: fp16 hi/lo operands, fp32 accumulation) against the
 CPU oracle and the reference-generated fixtures.  The bar is the EXACT one: decoded pixels within 1e-4 (north_star)."""
+import json
 import os
 
 import numpy as np
@@ -102,6 +103,7 @@ def test_imagenet_size_decoder_all_precisions_vs_oracle():
     tct, tcb = torch.from_numpy(ct), torch.from_numpy(cb)
     split, rep = kernels_run(eng, lambda: np_(eng.decode(tct, tcb, precision=PRECISION_SPLIT)))
     assert 'conv3x3' in rep and rep.get('split_pack', (0, 0))[0] >= 30, rep
+    assert rep.get('variant:conv_out_direct:conv_out', (0, 0))[0] == 1, rep    # norm_out + swish + conv_out: one fp32 kernel
     e_split = np.abs(split - want).max()
     assert e_split <= PIXEL_TOL, e_split
     exact = np_(eng.decode(tct, tcb, precision=PRECISION_EXACT))
@@ -248,6 +250,57 @@ np.save(sys.argv[1], px.cpu().numpy())
         assert err <= PIXEL_TOL, (name, err)
     assert np.abs(out['phase'] - out['nine']).max() <= 2e-5
     assert not np.array_equal(out['phase'], out['nine']), 'HQT_SPLIT_UP=0 did not change the kernel'
+
+
+def test_conv_out_in_one_fp32_kernel_matches_the_matrix_core_form():
+    """SPLIT's last stage -- norm_out, swish, conv_out, clamp -- runs as ONE fp32 kernel on the fp32 tensor (conv_out_direct_kernel: no
+    operand pass over the decoder's largest tensor, no 3 -> 16 channel padding).  HQT_CONV_OUT_DIRECT=0 switches back to the operand pass
+    + conv3x3_split_out16_kernel; both must sit within 1e-4 of the oracle and within 2e-5 of each other (image borders, clamp and a
+    batch that is not a multiple of anything included), and the timing report must name the kernel that ran."""
+    import subprocess
+    import sys
+    import tempfile
+    code = """
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r)
+from hqtransformer_amd import synth
+from hqtransformer_amd._lib import PRECISION_SPLIT
+from hqtransformer_amd.engine import Engine
+from hqtransformer_amd.spec import Stage1Spec
+spec = Stage1Spec(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=64, z_channels=64, embed_dim=32, n_embed=256)
+w = synth.stage1_weights(spec, 51, 'fixture')
+r = np.random.default_rng(52)
+ct, cb = r.integers(0, 256, (5, 8, 8)), r.integers(0, 256, (5, 16, 16))
+e = Engine(None, spec, torch.device('cuda:0'), 3); e.load(stage1=w); e.finalize()
+e.timing(True); e.timing_reset()
+px = e.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_SPLIT)
+torch.cuda.synchronize()
+rep = {k: v[0] for k, v in e.timing_report().items()}
+e.timing(False)
+cl = e.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_SPLIT, clamp01=True)
+np.savez(sys.argv[1], px=px.cpu().numpy(), cl=cl.cpu().numpy(), rep=json.dumps(rep))
+""" % ROOT
+    spec = Stage1Spec(ch=64, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=64, z_channels=64, embed_dim=32, n_embed=256)
+    weights = synth.stage1_weights(spec, 51, 'fixture')
+    r = np.random.default_rng(52)
+    ct, cb = r.integers(0, 256, (5, 8, 8)), r.integers(0, 256, (5, 16, 16))
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (('direct', {}), ('planes', {'HQT_CONV_OUT_DIRECT': '0'})):
+            path = os.path.join(tmp, name + '.npz')
+            rr = subprocess.run([sys.executable, '-c', code, path], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert rr.returncode == 0, (name, rr.stdout[-1500:], rr.stderr[-1500:])
+            z = np.load(path)
+            out[name] = (z['px'], z['cl'], json.loads(str(z['rep'])))
+    for name, (px, cl, rep) in out.items():
+        assert np.abs(px - want).max() <= PIXEL_TOL, (name, np.abs(px - want).max())
+        np.testing.assert_allclose(cl, O.postprocess(want), atol=PIXEL_TOL)
+    # chunks of 3 + 2 images: one launch per chunk
+    assert out['direct'][2].get('variant:conv_out_direct:conv_out') == 2, out['direct'][2]
+    assert 'variant:conv_out_direct:conv_out' not in out['planes'][2], out['planes'][2]
+    assert out['planes'][2]['split_pack'] == out['direct'][2]['split_pack'] + 2        # the operand pass the fused kernel does not need
+    assert np.abs(out['direct'][0] - out['planes'][0]).max() <= 2e-5
 
 
 def test_split_sampler_tiny_fixture_bit_exact():

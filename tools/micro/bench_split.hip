@@ -4,6 +4,7 @@
 #include "../../hqtransformer_amd/csrc/split_conv.hip"
 #include "../../hqtransformer_amd/csrc/split_stream_conv.hip"
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -81,6 +82,37 @@ int main(int argc, char** argv) {
         unsigned x = 777u;
         for (auto& v : wf) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 9) - (1 << 22)) * (1.0f / (1 << 24)); }
         CK(hipMemcpy(W32, wf.data(), wmax * 4, hipMemcpyHostToDevice));
+    }
+    if (argc > 2 && !strcmp(argv[2], "order")) {
+        // workgroup order of the ring16 / up16 kernels: pixel tiles per panel (0 = n-tile fastest), and the kernels without their filter loads
+        static half_t* Wup = nullptr;
+        CK(hipMalloc(&Wup, split_up_elems(512, 512) * 2));
+        const int panels[] = {0, 4, 8, 16, 32, 64, 128};
+        printf("%-22s %-7s |", "layer (batch 64)", "kernel");
+        for (int p : panels) printf(" p=%-5d", p);
+        printf(" | no-filter-loads (p=0)\n");
+        for (const Shape& s : shapes) {
+            GemmArgs g{};
+            g.A = A; g.conv_taps = 9; g.H = s.res; g.W = s.res; g.Cin = s.cin; g.upsample = s.up;
+            g.Bw = Wh; g.Bw_lo = Wl; g.ldb = 9 * s.cin; g.C = C; g.ldc = s.cout; g.M = B * s.res * s.res; g.N = s.cout; g.K = 9 * s.cin; g.batch = 1;
+            g.bias = bias; g.alpha = 1.f; g.store = STORE_ROWS; g.zero_page = zero;
+            CK(launch_pack_split_frag16(W32, Wfrag16, s.cout, s.cin, st));
+            g.Bw_frag16 = Wfrag16;
+            printf("%-22s %-7s |", s.name, "ring16");
+            for (int p : panels) { g.tile_panel = p; printf(" %7.1f", run_ring16<0>(g, st, 5)); }
+            g.tile_panel = 0;
+            printf(" | %7.1f\n", run_ring16<5>(g, st, 5));
+            if (s.up) {
+                CK(hipMemset(Wup, 0, split_up_elems(512, 512) * 2));
+                CK(launch_pack_split_up16(W32, Wup, s.cout, s.cin, st));
+                g.Bw_up16 = Wup;
+                printf("%-22s %-7s |", "", "up16");
+                for (int p : panels) { g.tile_panel = p; printf(" %7.1f", run_up16<0>(g, st, 5)); }
+                g.tile_panel = 0;
+                printf(" | %7.1f\n", run_up16<5>(g, st, 5));
+            }
+        }
+        return 0;
     }
     printf("%-22s %8s | %7s %7s %7s | %7s %7s %7s %7s | %7s %7s\n", "layer (batch 64)", "GF x3", "pc1 us", "TF eq", "pc0 us", "no-epi", "no-dma", "dma", "mfma", "pc0nodma", "pc0 mfma");
     double tot = 0, totf = 0, tot_ring16 = 0, tot_up16 = 0;
