@@ -183,8 +183,8 @@ struct GemmArgs {
     int k_quarters;          // fp32 nn.Linear of the AR loop (set by run_linear for its gemm_* launches): the four-quarter summation order shared by
                              //   exact_mfma_gemm_kernel (<= 256 rows) and gemm_tile_kernel<..., QUARTERS>; every other fp32 GEMM keeps one chain per output
     int b_tile16;            // exact_mfma_gemm_kernel only: Bw is the fragment-ordered fp32 copy [n / 16][k / 32][chunk][lane][4] (pack_exact_tiles_kernel)
-    int tile_panel;          // SPLIT 3x3 convs: pixel tiles per panel of the workgroup order (0: the n-tile runs fastest); inside a panel the n-tile
-                             // (and phase) is the SLOW index, so the workgroups resident on an XCD share one filter stream
+    int tile_panel;          // workgroup-order experiments.  SPLIT 3x3 convs: pixel tiles per panel (0: the n-tile runs fastest; measured: no effect,
+                             // profiles/r04_conv_tile_order.txt).  tile_gemm_kernel: 1 = the round-3 order (HQT_TILE_ORDER=0), see tile_of
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

@@ -76,15 +76,33 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Workgroup id -> (row tile, column tile).  Workgroups b and b + 8 share an XCD (MI355X_MICROARCH.md), and an XCD runs ~32 of them at
-// a time; what its L2 has to pull over the fabric per k-step is one fragment per DISTINCT row tile and column tile among those.
-// Each XCD therefore gets a contiguous run of a grouped order (bands of GM row tiles, walked column by column): the workgroups
-// that run together on an XCD form a compact GM x (32 / GM) block of tiles, not a 32 x 1 column (which made every XCD pull the
-// whole activation panel every k-step: fabric-bound at 4096+ rows).
-__device__ __forceinline__ void tile_of(int id, int total, int TM, int TN, int& tm, int& tn) {
-    const int q = total >> 3, r = total & 7, xcd = id & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    constexpr int GM = 8;
+// Workgroup id -> (split-K slice, row tile, column tile).  Workgroups b and b + 8 share an XCD (MI355X_MICROARCH.md), and an XCD runs ~32 of
+// them at a time; what its L2 has to pull over the fabric is one K-long fragment stream per DISTINCT row tile and column tile among its
+// workgroups (tools/micro/bench_fill: a CU fills at ~135 GB/s from a hot L2 whatever the path, at ~27 GB/s when every CU pulls from beyond it).
+// Each XCD therefore gets a contiguous run of a grouped order (bands of GM row tiles, walked column by column): a compact block of tiles, not a
+// 32 x 1 column (which made every XCD pull the whole activation panel every k-step: fabric-bound at 4096+ rows).
+//   * GM: up to 12 row tiles make ONE band (an XCD then owns whole columns: the weights cross the fabric once, the small activation panel
+//     eight times; bands of 8 left 2 of 10 row tiles at 640 rows to the last XCDs, which pulled two thirds of the weight matrix each);
+//     more row tiles are cut into equal bands of at most 8.
+//   * split-K: with S | 8 slices, XCD x works on slice x % S only (S = 8: every XCD streams ITS eighth of K of both operands, once).
+__device__ __forceinline__ void tile_of(int b, int total, int S, int TM, int TN, int legacy, int& z, int& tm, int& tn) {
+    int t;
+    if (S > 1 && (8 % S) == 0 && !legacy) {
+        const int xcd = b & 7, G = 8 / S, xg = xcd / S;
+        z = xcd - xg * S;
+        const int q = total / G, r = total - q * G;
+        t = (xg < r ? xg * (q + 1) : r * (q + 1) + (xg - r) * q) + (b >> 3);
+    } else {
+        z = b / total;
+        const int id = b - z * total;
+        const int q = total >> 3, r = total & 7, xcd = id & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    int GM = 8;
+    if (!legacy) {
+        const int nb = TM <= 12 ? 1 : (TM + 7) >> 3;
+        GM = (TM + nb - 1) / nb;
+    }
     const int per_group = GM * TN;
     const int group = t / per_group, in_group = t - group * per_group;
     const int first = group * GM, rows = min(TM - first, GM);
@@ -109,12 +127,11 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wm = wave % WGM, wn = wave / WGM;
     const int total = TM * TN;
-    const int z = blockIdx.x / total;                                             // split-K slice (TS_SLAB)
-    int tile_m, tile_n;
-    tile_of(blockIdx.x - z * total, total, TM, TN, tile_m, tile_n);
+    const int S = gridDim.x / total;
+    int z, tile_m, tile_n;                                                        // z: split-K slice (TS_SLAB)
+    tile_of(blockIdx.x, total, S, TM, TN, g.tile_panel, z, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int MB = g.a_packed_mb, KS = g.K >> 4, NTILES = g.N >> 5;
-    const int S = gridDim.x / total;
     const int ks_lo = (int)(((long long)KS * z) / S), ks_hi = (int)(((long long)KS * (z + 1)) / S);
     const int KT = (ks_hi - ks_lo) / KU;                                          // stages of this workgroup (launcher: divisible)
 
@@ -616,9 +633,12 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
 
 hipError_t launch_tile_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, const TilePlan& p, float* slabs, hipStream_t st) {
     (void)a_dt;
-    if (p.geom == 0) return launch_tile_g<Tile128>(g, wpk, c_dt, p.S, slabs, st);
-    if (p.geom == 1) return launch_tile_g<Tile64>(g, wpk, c_dt, p.S, slabs, st);
-    if (p.geom == 2) return launch_tile_g<Tile64W8>(g, wpk, c_dt, p.S, slabs, st);
+    static const int legacy_order = getenv("HQT_TILE_ORDER") && atoi(getenv("HQT_TILE_ORDER")) == 0;    // A/B switch: bands of 8 row tiles, split-K slices spread over all XCDs
+    GemmArgs gg = g;
+    gg.tile_panel = legacy_order;
+    if (p.geom == 0) return launch_tile_g<Tile128>(gg, wpk, c_dt, p.S, slabs, st);
+    if (p.geom == 1) return launch_tile_g<Tile64>(gg, wpk, c_dt, p.S, slabs, st);
+    if (p.geom == 2) return launch_tile_g<Tile64W8>(gg, wpk, c_dt, p.S, slabs, st);
     return hipErrorInvalidValue;
 }
 

@@ -1,0 +1,116 @@
+// Micro-benchmark: how fast can ONE CU pull bytes that sit in L2 / the Infinity Cache, and does the path matter?
+//   mode 0  LDS-DMA          buffer_load_dwordx4 ... lds   (what tile_gemm_kernel stages both operands with)
+//   mode 1  vector registers global_load_dwordx4           (what the ring convs / streaming GEMMs fetch their weights with)
+//   mode 2  both at once     half of the bytes on each path (the structure "weights register-direct, activations through the LDS ring")
+// One workgroup per CU (grid 256) or more, 4 / 8 / 16 waves, D kilobyte-loads in flight per wave.  The question behind it: the
+// 128 x 128 tile GEMM's loop runs at ~53 GB/s of LDS-DMA per CU with one workgroup, ~97 with three -- is that a limit of the DMA path or of the CU?
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/micro/bench_fill.hip -o tools/micro/bench_fill
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <int MODE, int NW, int D>
+__global__ __launch_bounds__(NW * 64) void fill_kernel(const char* __restrict__ src, unsigned region, int nregions, int iters, unsigned* __restrict__ sink) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const char* base = src + (size_t)(blockIdx.x % nregions) * region;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, region, 0x00020000);
+    const int lane16 = lane * 16;
+    constexpr int DV = MODE == 0 ? 0 : (MODE == 1 ? D : D / 2), DL = D - DV;       // loads of a batch on the register / the DMA path
+    u32x4 r[2][DV > 0 ? DV : 1];
+    u32x4 acc = {0, 0, 0, 0};
+    // batch b of this wave: D consecutive kilobytes at ((b * NW + wave) * D) KiB, wrapped inside the region
+    auto issue = [&](int b, int par) {
+        const unsigned o = (unsigned)(((size_t)(b * NW + wave) * D * 1024) % region);
+#pragma unroll
+        for (int u = 0; u < DL; ++u) {
+            char* dst = lds + ((wave * 2 + par) * DL + u) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, lane16, o + u * 1024, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < DV; ++u)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[par][u]) : "v"(lane16 + (DL + u) * 1024), "s"(rs), "s"(o));
+    };
+    auto step = [&](auto parc, int b) {
+        constexpr int par = decltype(parc)::value;
+        if (b + 1 < iters) {
+            issue(b + 1, par ^ 1);
+            // everything of batch b has landed when at most the D loads of batch b + 1 are outstanding
+            if (DV > 0) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[par][0]) : "n"(D)); }
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D) : "memory");
+        } else {
+            if (DV > 0) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[par][0])); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < DV; ++u) {
+            asm volatile("" : "+v"(r[par][u]));
+            acc ^= r[par][u];
+        }
+    };
+    issue(0, 0);
+    for (int b = 0; b < iters; b += 2) {                // iters is even (launcher)
+        step(std::integral_constant<int, 0>{}, b);
+        step(std::integral_constant<int, 1>{}, b + 1);
+    }
+    if (DL > 0) { __syncthreads(); acc[0] ^= reinterpret_cast<const unsigned*>(lds)[threadIdx.x]; }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345679u) sink[0] = acc[0];
+#endif
+}
+
+template <int MODE, int NW, int D>
+static double run(const char* src, unsigned region, int nregions, int grid, size_t bytes_per_wg, unsigned* sink, hipStream_t st) {
+    const int iters = (int)(bytes_per_wg / ((size_t)NW * D * 1024)) & ~1;
+    const int ldsb = MODE == 1 ? 1024 : NW * 2 * (MODE == 0 ? D : D - D / 2) * 1024;
+    auto* k = fill_kernel<MODE, NW, D>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
+    k<<<grid, NW * 64, ldsb, st>>>(src, region, nregions, iters, sink);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, st));
+    k<<<grid, NW * 64, ldsb, st>>>(src, region, nregions, iters, sink);
+    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    // GB/s per CU: the grid's workgroups share 256 CUs
+    return (double)iters * NW * D * 1024 * grid / 256.0 / (ms * 1e-3) * 1e-9;
+}
+
+template <int NW, int D>
+static void row(const char* what, const char* src, unsigned region, int nregions, int grid, unsigned* sink, hipStream_t st) {
+    const size_t per = (size_t)48 << 20;
+    printf("%-34s grid %4d  %2d waves x %2d KiB in flight | DMA %6.1f | registers %6.1f | both %6.1f   GB/s per CU\n", what, grid, NW, D,
+           run<0, NW, D>(src, region, nregions, grid, per, sink, st), run<1, NW, D>(src, region, nregions, grid, per, sink, st),
+           run<2, NW, D>(src, region, nregions, grid, per, sink, st));
+}
+
+int main() {
+    hipStream_t st; CK(hipStreamCreate(&st));
+    const size_t total = (size_t)1 << 30;
+    char* src; unsigned* sink;
+    CK(hipMalloc(&src, total)); CK(hipMalloc(&sink, 64));
+    CK(hipMemset(src, 1, total)); CK(hipMemset(sink, 0, 64));
+    struct { const char* name; unsigned region; int nregions; } cases[] = {
+        {"L2-hot (8 regions x 1 MiB)", 1u << 20, 8},
+        {"Infinity Cache (256 x 512 KiB)", 512u << 10, 256},
+        {"HBM (256 x 4 MiB)", 4u << 20, 256},
+    };
+    for (auto& c : cases) {
+        for (int grid : {256, 512, 768}) {
+            if (grid == 256) {
+                row<4, 8>(c.name, src, c.region, c.nregions, grid, sink, st);
+                row<4, 16>(c.name, src, c.region, c.nregions, grid, sink, st);
+                row<8, 4>(c.name, src, c.region, c.nregions, grid, sink, st);
+                row<8, 8>(c.name, src, c.region, c.nregions, grid, sink, st);
+                row<16, 4>(c.name, src, c.region, c.nregions, grid, sink, st);
+            } else {
+                row<4, 4>(c.name, src, c.region, c.nregions, grid, sink, st);
+                row<8, 2>(c.name, src, c.region, c.nregions, grid, sink, st);
+            }
+        }
+    }
+    return 0;
+}
