@@ -625,6 +625,24 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
     if (w8r && g.store == STORE_RESID && g.K < 3072 && tiles < 256 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
         return TilePlan{2, Tile64::BM, Tile64::BN, 1};
     if (g.store == STORE_RESID && g.K >= 3072 && tiles < 256) {
+        // The wide-K residual producer (fc2).  Measured per (geometry, S) at the row counts the schedules produce (profiles/r04_fc2_plans.txt; GEMM + combine,
+        // ms per pass): what counts is whole ROUNDS of workgroups (128 x 128: one per CU, 8-wave 64 x 128: two) and the slab traffic of the combine.
+        //   * 8-wave 64 x 128 tiles without split-K when they fill the chip evenly (at most one or close to two per CU): 1024 rows 53.4 -> 47.5, 2560 rows 20.2 -> 18.4;
+        //   * S = 4 when 4 x tiles is one round or a whole number of rounds: 512 rows 36.4 -> 34.7, 640 rows 38.0 -> 35.9, 2048 rows 80.9 -> 74.0 (was S = 8 / 8 / 3);
+        //   * else the largest S that keeps the grid under 2.25 rounds.
+        static const char* force = getenv("HQT_TILE_SPLITK_PLAN");            // experiment: "geom,S"
+        if (force) {
+            int fg = 0, fs = 0;
+            if (sscanf(force, "%d,%d", &fg, &fs) == 2 && fs >= 1 && fs <= max_s) {
+                const int ku = fg == 0 ? Tile128::KU : Tile64W8::KU, ns = fg == 0 ? Tile128::NSTAGE : Tile64W8::NSTAGE;
+                if (KS % (ku * fs) == 0 && KS / fs / ku >= 2 * ns) return TilePlan{fg, fg == 0 ? Tile128::BM : Tile64::BM, fg == 0 ? Tile128::BN : Tile64::BN, fs};
+            }
+        }
+        static const int tuned = getenv("HQT_TILE_FC2_PLAN") ? atoi(getenv("HQT_TILE_FC2_PLAN")) : 1;      // A/B switch: 0 = round 3's rule
+        const int t64 = ((g.M + Tile64::BM - 1) / Tile64::BM) * (g.N / Tile64::BN);
+        if (tuned && w8 && ((t64 >= 176 && t64 <= 208) || (t64 >= 448 && t64 <= 512)) && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
+            return TilePlan{2, Tile64::BM, Tile64::BN, 1};
+        if (tuned && (tiles * 4 <= 256 || tiles % 64 == 0) && KS % (Tile128::KU * 4) == 0 && KS / 4 / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = 4; return p; }
         for (int S : {8, 6, 4, 3, 2})
             if (S <= max_s && tiles * S <= 576 && KS % (Tile128::KU * S) == 0 && KS / S / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = S; break; }
     }
