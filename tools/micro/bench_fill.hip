@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -87,6 +88,50 @@ static void row(const char* what, const char* src, unsigned region, int nregions
            run<2, NW, D>(src, region, nregions, grid, per, sink, st));
 }
 
+// Does an XCD's L2 keep what a kernel read for the NEXT kernel of the stream?  256 workgroups (8 waves) read 64 KiB each (16 MiB: 2 MiB per XCD if
+// workgroup b runs on XCD b % 8) and stamp the duration of their load phase.  Launch 1 is cold; launch 2 reads the SAME chunk per workgroup
+// (L2 hit if the L2 survives the kernel boundary and the mapping holds); launch 3 reads the chunk of workgroup b + 1 (another XCD's: L2 miss,
+// Infinity Cache hit); launch 4 the chunk of workgroup b + 8 (same XCD, other CU: L2 hit without L1 help).
+__global__ __launch_bounds__(512) void survive_kernel(const char* __restrict__ src, int shift, long long* __restrict__ out, unsigned* __restrict__ sink) {
+    const int b = (blockIdx.x + shift) & 255, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char* p = src + (size_t)b * 65536 + wave * 8192 + lane * 16;
+    u32x4 r[8];
+    const long long t0 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = *reinterpret_cast<const u32x4*>(p + u * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t1 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 acc = r[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) acc ^= r[u];
+    const unsigned x = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+    if (x == 0x12345679u) sink[0] = x;
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0 + (x == 0x7u ? 1 : 0);
+}
+static void survive(const char* src, unsigned* sink, hipStream_t st) {
+    const int shifts[] = {0, 0, 1, 2, 4, 8, 16, 32, 64, 128, 3, 24};
+    constexpr int NL = sizeof(shifts) / sizeof(shifts[0]);
+    long long* out; CK(hipMalloc(&out, NL * 256 * 8));
+    std::vector<long long> h(NL * 256);
+    for (int l = 1; l < NL; ++l) {
+        // evict everything, read cold (shift 0), then the probe launch
+        fill_kernel<1, 8, 8><<<256, 512, 1024, st>>>(src + ((size_t)512 << 20), 1u << 21, 256, 16, sink);
+        survive_kernel<<<256, 512, 0, st>>>(src, 0, out, sink);
+        survive_kernel<<<256, 512, 0, st>>>(src, shifts[l], out + l * 256, sink);
+    }
+    CK(hipMemcpyAsync(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+    for (int l = 0; l < NL; ++l) {
+        std::vector<long long> v(h.begin() + l * 256, h.begin() + (l + 1) * 256);
+        std::sort(v.begin(), v.end());
+        if (l == 0) printf("L2 across a kernel boundary: cold read                                   load phase %5.2f us median, %5.2f us p90 (100 MHz wall clock)\n", v[128] / 100.0, v[230] / 100.0);
+        else printf("L2 across a kernel boundary: next launch reads the chunk of workgroup b + %-3d load phase %5.2f us median, %5.2f us p90\n", shifts[l], v[128] / 100.0, v[230] / 100.0);
+    }
+}
+
 int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
     const size_t total = (size_t)1 << 30;
@@ -98,6 +143,7 @@ int main() {
         {"Infinity Cache (256 x 512 KiB)", 512u << 10, 256},
         {"HBM (256 x 4 MiB)", 4u << 20, 256},
     };
+    survive(src, sink, st);
     for (auto& c : cases) {
         for (int grid : {256, 512, 768}) {
             if (grid == 256) {

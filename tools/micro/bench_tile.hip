@@ -198,7 +198,7 @@ int main(int argc, char** argv) {
         std::vector<bf16_t*> w(nbuf);
         fill_kernel<<<1024, 256, 0, st>>>(w32, (size_t)sh.N * sh.K, 99u, 0.05f);
         for (auto& p : w) { CK(hipMalloc(&p, bytes)); CK(launch_pack_stream_weights(w32, p, sh.N, sh.K, st)); }
-        for (int M : {512, 1280, 5120}) {
+        for (int M : {512, 640, 1280, 5120}) {
             const int MB = packed_mb(M);
             pack_rows_kernel<<<1024, 256, 0, st>>>(b.x_rows, b.xpk, M, sh.K, MB);
             const double gf = 2.0 * M * sh.N * sh.K * 1e-9;
@@ -209,7 +209,7 @@ int main(int argc, char** argv) {
             T(Tile256, "256x256 k64 x2, fp32 rows") T(Tile256k3, "256x256 k32 x4 , fp32 rows") T(Tile128, "128x128 k32 x3 (3/CU), fp32 rows") T(Tile128k4, "128x128 k64 x2, fp32 rows")
             T(Tile256x128, "256x128 k64 x3, fp32 rows") T(Tile256x128k4, "256x128 k32 x4 , fp32 rows") T(Tile128s3, "128x128 k32 x3 (k32 x4: 2/CU), fp32 rows")
 #undef T
-            if (M == 1280 || M == 5120) {
+            if (M == 640 || M == 1280 || M == 5120) {
                 // in-kernel stamps of one launch: cycles to the first landed stage, main loop, epilogue; wall span of the grid
                 auto stamps = [&](const char* what, int wgs, const std::function<void(GemmArgs&)>& run) {
                     GemmArgs gs = g;
@@ -230,6 +230,9 @@ int main(int argc, char** argv) {
                     printf("   stamps %-30s %4d wgs: prologue %6lld  loop %7lld  epilogue %6lld cycles (median); workgroup life %.2f us, grid span %.2f us\n",
                            what, wgs, med(pro), med(loop), med(epi), med(life) / 100.0, (t1 - t0) / 100.0);
                 };
+                // the product's 8-wave 64 x 128 geometry (two workgroups per CU): what a 640-row pass runs
+                stamps("64x128 8 waves k64 x3 rows", ((M + 63) / 64) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile64W8, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
+                stamps("64x128 8 waves k64 x3 packed bf16", ((M + 63) / 64) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile64W8, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
                 stamps("256x256 k32 x4 rows", ((M + 255) / 256) * (sh.N / 256), [&](GemmArgs& gs) { launch_raw<Tile256, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
                 stamps("256x128 k32 x4 rows", ((M + 255) / 256) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile256x128, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 k32 x3 rows", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
