@@ -679,7 +679,7 @@ def main():
             # matrix work actually issued per algorithmic FLOP: SPLIT evaluates a product with three fp16 MFMAs; the nearest-x2 upsampling convs run as four
             # 2x2 phase convolutions on the low-resolution image (4 taps instead of 9: the same sums, regrouped)
             issued = (3 if dec_prec == 'split' else 1) * work.get('dec_flops_executed', work['dec_flops']) / work['dec_flops']
-            kname = {'split': 'conv3x3_split_ring16_kernel (+ conv2x2_split_up16_kernel for the upsampling convs, conv3x3_split_out16_kernel for conv_out, split_gemm_kernel for the 1x1 convs and the attention GEMMs): '
+            kname = {'split': 'conv3x3_split_ring16_kernel (+ conv2x2_split_up16_kernel for the upsampling convs, split_gemm_kernel for the 1x1 convs and the attention GEMMs; conv_out_direct_kernel -- norm_out + swish + conv_out as fp32 FMAs, 0.26 % of the FLOPs -- is counted in the time of the family): '
                               'HQ-VAE decoder conv family, fp16 hi/lo split operands',
                      'fast': 'conv3x3_halo_kernel (+ conv_glds_kernel for 1x1): HQ-VAE decoder conv family, bf16',
                      'exact': 'gemm_tile_kernel: HQ-VAE decoder conv family, fp32 vector ALUs'}[dec_prec]
