@@ -180,6 +180,8 @@ struct GemmArgs {
     int a_f32;               // split_gemm_kernel only: A is the fp32 tensor itself ([row][K], lda floats); the hi / lo split happens while the tile is staged
     int b_f32;               // split_gemm_kernel only, with a_f32: Bw is an fp32 tensor too ([n][K], ldb floats; Bw_lo unused)
     int* range_flag;         // a_f32 / b_f32: where an element outside the fp16 range is reported (hqt_range_check)
+    int out_split;           // conv3x3_split_ring16_kernel: store the output as fp16 hi / lo operand planes [pixel][2][N] (range-checked: range_flag) instead of the
+                             // fp32 tensor -- the consumer is another SPLIT conv with nothing in between (resblock -> upsampling conv): no operand pass
     // ---- cross-kernel weight prefetch (streaming GEMMs of the 64-row AR chain): the packed weights of the NEXT GEMM of the chain.  A ninth
     //      wave of every workgroup touches one dword per 128-byte line of them while the eight others work, so that the successor finds its
     //      weight stream in L2 instead of waiting an HBM round trip for it (tools/micro/bench_stream: 8.9 -> 6.4 us with warm weights at 64 rows).

@@ -1497,6 +1497,7 @@ struct S1Ctx {
     int adt;
     void *cur, *t1, *t2, *tn;
     float *gn1, *gn2;
+    bool cur_planes = false;   // SPLIT: `cur` already holds fp16 hi / lo operand planes (the producing conv's epilogue emitted them: GemmArgs::out_split)
 };
 
 // SPLIT: can conv / GEMM `g` (A = an fp32 NHWC tensor) with filters `l` run on the matrix cores?  Shapes the split kernels do
@@ -1585,7 +1586,7 @@ static bool s1_split_product(hqt_handle* h, const Mode& md, GemmArgs& sg) {
 }
 
 // kinds 0 conv3, 1 ResnetBlock, 2 AttnBlock, 3 upsample conv, 5 Downsample conv (shared by Decoder.forward and Encoder.forward)
-static int s1_layer(S1Ctx& c, const DecLayer& l) {
+static int s1_layer(S1Ctx& c, const DecLayer& l, const DecLayer* next = nullptr) {
     hqt_handle* h = c.h;
     const Mode& md = c.md;
     hipStream_t st = c.st;
@@ -1595,7 +1596,8 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
     if (l.kind == 0 || l.kind == 3) {
         const int ro = l.kind == 3 ? 2 * res : res;
         GemmArgs g = conv_args(cur, n, ro, l.cin, 9, l.kind == 3, t1, l.cout);
-        CHK(s1_plain(c, &g, l.conv1));
+        if (c.cur_planes) { g.Bw_lo = g.A; c.cur_planes = false; }   // the planes are there (non-NULL Bw_lo marks a SPLIT launch; run_linear substitutes the filters)
+        else CHK(s1_plain(c, &g, l.conv1));
         CHK(run_linear(h, md, g, l.conv1, adt, adt, st, "conv3x3"));
         std::swap(cur, t1);
     } else if (l.kind == 5) {               // Downsample (stage1/modules/layers.py:56-76): pad right / bottom by one, 3x3 stride 2
@@ -1619,8 +1621,20 @@ static int s1_layer(S1Ctx& c, const DecLayer& l) {
         g = conv_args(t1, n, res, l.cout, 9, 0, outbuf, l.cout);
         g.resid = shortcut;
         CHK(s1_norm(c, t1, l.cout, hw, c.gn2, l.n2_g, l.n2_b, 1, &g, &l.conv2));
+        // SPLIT: when the block's only consumer is an upsampling conv (no GroupNorm in between) whose operand would be split by a separate pass, this conv's epilogue
+        // writes the operand planes instead of the fp32 tensor (same bytes, one pass over the tensor less)
+        bool planes = false;
+        if (md.split && g.Bw_lo && next && next->kind == 3 && next->cin == l.cout) {
+            GemmArgs up = conv_args(outbuf, n, 2 * res, next->cin, 9, 1, t1, next->cout);
+            GemmArgs me = g;
+            me.N = l.conv2.N; me.K = l.conv2.K; me.ldb = l.conv2.K; me.zero_page = h->zero_page; me.Bw = l.conv2.w16h; me.Bw_lo = l.conv2.w16l; me.Bw_frag16 = l.conv2.wfrag16;
+            planes = split_shape_ok(h, up, next->conv1) && split_conv3_emits_planes(me);
+        }
+        if (planes) { g.out_split = 1; g.range_flag = h->range_flag; }
         CHK(run_linear(h, md, g, l.conv2, adt, adt, st, "conv3x3"));
         if (outbuf == t2) std::swap(cur, t2);
+        c.cur_planes = planes;
+        if (planes) count_variant(h, "variant:conv3x3_planes_out:conv3x3");
     } else if (l.kind == 2) {               // AttnBlock (stage1/modules/layers.py:163-186)
         const int C = l.cin;
         GemmArgs g = conv_args(cur, n, res, C, 1, 0, h->aq, C);
@@ -1692,8 +1706,9 @@ static int decode_chunk(hqt_handle* h, int n, const int64_t* code_t, const int64
         CHK(s1_plain(c, &g, h->post_quant));
         CHK(run_linear(h, md, g, h->post_quant, adt, adt, st, "conv1x1"));
     }
-    for (auto& l : h->dec) {
-        if (l.kind != 4) { CHK(s1_layer(c, l)); continue; }
+    for (size_t li = 0; li < h->dec.size(); ++li) {
+        const DecLayer& l = h->dec[li];
+        if (l.kind != 4) { CHK(s1_layer(c, l, li + 1 < h->dec.size() ? &h->dec[li + 1] : nullptr)); continue; }
         // norm_out -> swish -> conv_out, NCHW fp32 (+clamp)
         const int hw = l.res * l.res;
         GemmArgs g = conv_args(c.cur, n, l.res, l.cin, 9, 0, out, l.cout);

@@ -41,6 +41,7 @@ hipError_t launch_pack_split_frag16(const float* w_tapmajor, half_t* out, int N,
 size_t split_up_elems(int N, int Cin);
 hipError_t launch_pack_split_up16(const float* w_tapmajor, half_t* out, int N, int Cin, hipStream_t st);
 bool split_stream_ok(const GemmArgs& g);          // g already passed split_conv3_ok
+bool split_conv3_emits_planes(const GemmArgs& g); // g.out_split is honoured (conv3x3_split_ring16_kernel serves g)
 int split_stream_tiles_per_image(const GemmArgs& g);
 hipError_t launch_split_conv3_stream(const GemmArgs& g, hipStream_t st);
 hipError_t split_stream_configure();

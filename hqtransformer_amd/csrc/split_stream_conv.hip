@@ -19,6 +19,7 @@
 //   * the main loop is one basic block of straight-line code with asm loads in flight across its back edge; _lib.build() audits the
 //     generated ISA (csrc/audit_ring.py) and refuses to link a library whose loops the compiler has touched.
 #include "split_kernels.h"
+#include "split_device.h"
 #include "gemm_generic.h"
 #include <algorithm>
 #include <cstdlib>
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring16_kernel(GemmArgs g
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = (g.bias && nn + e < g.N) ? g.bias[nn + e] : 0.0f;
+    bool bad = false;
     float gs[8], gq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gs[e] = 0.0f; gq[e] = 0.0f; }
@@ -338,9 +340,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring16_kernel(GemmArgs g
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] += r0[p4][e]; v[4 + e] += r1[p4][e]; }
                 }
-                const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                *reinterpret_cast<f32x4*>(Cb + moff[p4]) = o0;
-                *reinterpret_cast<f32x4*>(Cb + moff[p4] + 4) = o1;
+                if (g.out_split) {                      // uniform: the consumer is a SPLIT conv with no GroupNorm in front -- its operand planes leave from here
+                    unsigned hi[4], lo[4];
+                    split8_checked(v, hi, lo, bad);
+                    half_t* P = reinterpret_cast<half_t*>(g.C) + 2 * moff[p4] - nn;         // pixel * 2 N + channel (ldc == N)
+                    *reinterpret_cast<u32x4*>(P) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                    *reinterpret_cast<u32x4*>(P + g.N) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+                } else {
+                    const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *reinterpret_cast<f32x4*>(Cb + moff[p4]) = o0;
+                    *reinterpret_cast<f32x4*>(Cb + moff[p4] + 4) = o1;
+                }
                 if (g.gn_part_out_d) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { gs[e] += v[e]; gq[e] += v[e] * v[e]; }
@@ -348,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_ring16_kernel(GemmArgs g
             }
         }
     }
+    if (bad && g.range_flag) atomicOr(g.range_flag, 1);
     if (g.gn_part_out_d) {                              // uniform branch (kernel argument): barriers are safe here
         __syncthreads();
         float* redw = reinterpret_cast<float*>(lds_raw);                    // [16 pixel rows][128 channels][2]; zeros from idle threads
@@ -828,6 +839,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_out16_kernel(GemmArgs g)
     }
 }
 
+// can the conv's epilogue emit operand planes (GemmArgs::out_split)?  Only conv3x3_split_ring16_kernel does: g must take that kernel.
+bool split_conv3_emits_planes(const GemmArgs& g) {
+    static const bool off = getenv("HQT_SPLIT_PLANES_OUT") && atoi(getenv("HQT_SPLIT_PLANES_OUT")) == 0;        // A/B switch: 0 = fp32 tensor + operand pass
+    return !off && split_stream_ok(g) && g.store == STORE_ROWS && !g.upsample && g.ldc == g.N && g.N % 8 == 0;
+}
 bool split_stream_ok(const GemmArgs& g) {
     if (!g.Bw_frag16) return false;
     if (g.H % R_TY != 0 || g.W % R_TX != 0 || g.Cin % 64 != 0) return false;      // an even number of 32-channel chunks (static ring slots)

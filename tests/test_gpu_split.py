@@ -303,6 +303,54 @@ np.savez(sys.argv[1], px=px.cpu().numpy(), cl=cl.cpu().numpy(), rep=json.dumps(r
     assert np.abs(out['direct'][0] - out['planes'][0]).max() <= 2e-5
 
 
+def test_resblock_epilogue_emits_the_upsampling_convs_operand_planes():
+    """A ResnetBlock whose only consumer is an upsampling conv (no GroupNorm in between) writes fp16 hi / lo operand planes from its second conv's epilogue
+    (GemmArgs::out_split) instead of the fp32 tensor + a separate operand pass.  Same split of the same fp32 values: HQT_SPLIT_PLANES_OUT=0 (the operand pass) must give
+    the SAME pixels bit for bit; the timing report must show the passes that disappeared (the block in front of an attention layer is not eligible)."""
+    import subprocess
+    import sys
+    import tempfile
+    code = """
+import sys, json, numpy as np, torch
+sys.path.insert(0, %r)
+from hqtransformer_amd import synth
+from hqtransformer_amd._lib import PRECISION_SPLIT
+from hqtransformer_amd.engine import Engine
+from hqtransformer_amd.spec import Stage1Spec
+spec = Stage1Spec(ch=128, ch_mult=[1, 1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=128, z_channels=64, embed_dim=32, n_embed=256, use_init_downsample=True)
+w = synth.stage1_weights(spec, 71, 'fixture')
+r = np.random.default_rng(72)
+ct, cb = r.integers(0, 256, (3, 8, 8)), r.integers(0, 256, (3, 16, 16))
+e = Engine(None, spec, torch.device('cuda:0'), 3); e.load(stage1=w); e.finalize()
+e.timing(True); e.timing_reset()
+px = e.decode(torch.from_numpy(ct), torch.from_numpy(cb), precision=PRECISION_SPLIT)
+torch.cuda.synchronize()
+e.range_check()
+rep = {k: v[0] for k, v in e.timing_report().items()}
+np.savez(sys.argv[1], px=px.cpu().numpy(), rep=json.dumps(rep))
+""" % ROOT
+    spec = Stage1Spec(ch=128, ch_mult=[1, 1, 2], num_res_blocks=1, attn_resolutions=[16], resolution=128, z_channels=64, embed_dim=32, n_embed=256,
+                      use_init_downsample=True)
+    weights = synth.stage1_weights(spec, 71, 'fixture')
+    r = np.random.default_rng(72)
+    ct, cb = r.integers(0, 256, (3, 8, 8)), r.integers(0, 256, (3, 16, 16))
+    want = O.OracleStage1(spec, weights).decode_code(ct, cb)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, env in (('planes', {}), ('pass', {'HQT_SPLIT_PLANES_OUT': '0'})):
+            path = os.path.join(tmp, name + '.npz')
+            rr = subprocess.run([sys.executable, '-c', code, path], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert rr.returncode == 0, (name, rr.stdout[-1500:], rr.stderr[-1500:])
+            z = np.load(path)
+            out[name] = (z['px'], json.loads(str(z['rep'])))
+    assert np.abs(out['planes'][0] - want).max() <= PIXEL_TOL
+    assert np.array_equal(out['planes'][0], out['pass'][0])
+    n = out['planes'][1].get('variant:conv3x3_planes_out:conv3x3', 0)
+    assert n == 2, out['planes'][1]                                # the 32 x 32 and 64 x 64 levels; the 16 x 16 level ends in an attention block
+    assert 'variant:conv3x3_planes_out:conv3x3' not in out['pass'][1]
+    assert out['pass'][1]['split_pack'] == out['planes'][1]['split_pack'] + n
+
+
 def test_split_sampler_tiny_fixture_bit_exact():
     """HQT_PRECISION_SPLIT on the stage-2 entry point (round 4): the EXACT launch sequence with every nn.Linear on the matrix cores
     (fp32 activation rows split into fp16 hi / lo while staged, fp16 hi / lo weight planes, three MFMAs per term) -- the reference
