@@ -59,7 +59,7 @@ timeout 300 python tools/split_step_probe.py > $O/split_step_probe.json 2>/dev/n
 (for d in 0 1; do HQT_TILE_W8=$d timeout 300 python tools/ar_pass_time.py --rows 512 640 --policy 1 --breakdown --by-rows; echo; done) > $O/tile_variants.txt 2>/dev/null
 # this round's A/B switches: workgroup order + fc2 plan of the tile GEMM, conv_out in one fp32 kernel, the weight-prefetch wave
 (for v in "HQT_TILE_ORDER=0" "HQT_TILE_FC2_PLAN=0" "A=default"; do echo "$v"; env $v timeout 300 python tools/ar_pass_time.py --rows 512 640 1024 2048 --policy 1 --breakdown --by-rows; echo; done) > $O/tile_order_and_fc2_plan.txt 2>/dev/null
-(for v in "HQT_CONV_OUT_DIRECT=0" "A=default"; do echo "$v"; env $v timeout 300 python tools/bench_decode.py --precision split; echo; done) > $O/decode_conv_out_direct_ab.txt 2>/dev/null
+(for v in "HQT_CONV_OUT_DIRECT=0" "HQT_SPLIT_PLANES_OUT=0" "A=default"; do echo "$v"; env $v timeout 300 python tools/bench_decode.py --precision split; echo; done) > $O/decode_conv_out_direct_ab.txt 2>/dev/null
 (for v in "A=default" "HQT_WEIGHT_PREFETCH=1" "A=default" "HQT_WEIGHT_PREFETCH=1"; do echo "$v"; env $v timeout 300 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline --no-exact-mode --no-roofline | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['like_for_like']['phase_ms'])"; done) > $O/weight_prefetch_ab.txt 2>/dev/null
 # ---- micro-benchmarks
 timeout 300 tools/micro/bench_split > $O/micro_split_conv_variants.txt 2>&1
