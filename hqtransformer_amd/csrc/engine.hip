@@ -1046,6 +1046,7 @@ static NextW next_w(const bf16_t* wpk, int N, int K) {
 static void with_pf(GemmArgs& g, const NextW& n) { g.pf_w = n.w; g.pf_bytes = n.bytes; g.pf_slice = n.slice; }
 // what a deferred-LayerNorm block reads first: its fused [query; key; value] weights -- the key / value rows only when the block runs the
 // single-key shortcut (run_block_dln)
+static bool single_key_on() { static const bool on = !getenv("HQT_NO_SINGLE_KEY"); return on; }
 static NextW next_qkv(const BlockW& bw, bool single_key, int D) {
     if (single_key) return next_w(bw.qkv.wpk_ln ? bw.qkv.wpk_ln + (size_t)D * bw.qkv.K : nullptr, 2 * D, bw.qkv.K);
     return next_w(bw.qkv.wpk_ln, bw.qkv.N, bw.qkv.K);
@@ -1122,7 +1123,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
         void* vc = (char*)h->vcache + l * kv_layer;
         // what follows this block's fc2: the next block's [query; key; value], or -- behind ln_f -- the depth head's first block (its key / value rows:
         // depth sub-step 0 runs the single-key shortcut)
-        const NextW after = l + 1 < cf.n_layers ? next_qkv(h->body[l + 1], false, D) : next_qkv(h->depth[0], !getenv("HQT_NO_SINGLE_KEY"), D);
+        const NextW after = l + 1 < cf.n_layers ? next_qkv(h->body[l + 1], false, D) : next_qkv(h->depth[0], single_key_on(), D);
         if (dln_body) CHK(run_block_dln(h, c, h->body[l], h->x, h->xpk, h->parts, &h->nparts, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1, after));
         else CHK(run_block(h, c, h->body[l], h->x, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
     }
@@ -1144,7 +1145,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     for (int l = 0; l < cf.n_layers_depth; ++l) {
         void* kc = (char*)h->dk + l * dkv_layer;
         void* vc = (char*)h->dv + l * dkv_layer;
-        const NextW after = l + 1 < cf.n_layers_depth ? next_qkv(h->depth[l + 1], !getenv("HQT_NO_SINGLE_KEY"), D) : next_w(h->head_top.wpk_ln, h->head_top.N, h->head_top.K);
+        const NextW after = l + 1 < cf.n_layers_depth ? next_qkv(h->depth[l + 1], single_key_on(), D) : next_w(h->head_top.wpk_ln, h->head_top.N, h->head_top.K);
         if (dln1) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, 1, kc, vc, 5, 0, nullptr, 0, after));
         else CHK(run_block(h, c, h->depth[l], h->xd, 1, kc, vc, 5, 0, nullptr, 0));
     }
