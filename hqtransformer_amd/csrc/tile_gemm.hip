@@ -570,6 +570,7 @@ typedef TileGeom<2, 2, 1, 2, 2, 3> Tile64;
 // the ring depth (6 stages in flight instead of 2 measured within 1 %: profiles/r04_tile_variants.txt) -- what paces it is the ISSUE of its
 // LDS-DMA pieces, ~150 cycles per 1-KiB piece and wave; eight waves issue the same pieces twice as fast.
 typedef TileGeom<2, 4, 1, 1, 4, 3> Tile64W8;
+typedef TileGeom<2, 2, 1, 1, 4, 3> Tile64x64;     // 64 x 64, 4 waves of 32 x 32, stages of 64 k: 48 KiB ring, three workgroups per CU (proj at 640 rows: tile_gemm_plan)
 
 template <class G, int STORE, bool DLN, typename TC>
 static hipError_t launch_tile_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
@@ -616,6 +617,11 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
     static const int w8 = getenv("HQT_TILE_W8") ? atoi(getenv("HQT_TILE_W8")) : 1;                   // A/B runs: 0 = 4-wave 64 x 128 tiles
     TilePlan p{0, Tile128::BM, Tile128::BN, 1};
     const int KS = g.K / 16, tiles = ((g.M + p.bm - 1) / p.bm) * (g.N / p.bn);
+    // the narrow residual producer (proj: N = K = D) at the driver's 640 rows: 240 tiles of 64 x 64 (4 waves, three workgroups per CU) instead of 120 of 64 x 128 --
+    // every CU gets one, half the matrix work per workgroup: 18.9 -> 16.5 ms per pass (1024 rows: 384 such tiles lose to 192 of 64 x 128, 21.4 vs 19.4).  HQT_TILE_64X64=0: off
+    static const int x64 = getenv("HQT_TILE_64X64") ? atoi(getenv("HQT_TILE_64X64")) : 1;
+    if (x64 && g.store == STORE_RESID && g.K < 3072 && ((g.M + 63) / 64) * (g.N / 64) <= 256 && KS % Tile64x64::KU == 0 && KS / Tile64x64::KU >= 2 * Tile64x64::NSTAGE)
+        return TilePlan{3, 64, 64, 1};
     if (max_geom >= 1 && g.store != STORE_RESID && tiles < 256 && KS / Tile64::KU >= Tile64::NSTAGE) {
         const int t64 = ((g.M + Tile64::BM - 1) / Tile64::BM) * (g.N / Tile64::BN);
         if (w8 && t64 <= 512 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE) return TilePlan{2, Tile64::BM, Tile64::BN, 1};
@@ -657,6 +663,7 @@ hipError_t launch_tile_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int 
     if (p.geom == 0) return launch_tile_g<Tile128>(gg, wpk, c_dt, p.S, slabs, st);
     if (p.geom == 1) return launch_tile_g<Tile64>(gg, wpk, c_dt, p.S, slabs, st);
     if (p.geom == 2) return launch_tile_g<Tile64W8>(gg, wpk, c_dt, p.S, slabs, st);
+    if (p.geom == 3) return launch_tile_g<Tile64x64>(gg, wpk, c_dt, p.S, slabs, st);
     return hipErrorInvalidValue;
 }
 
@@ -694,5 +701,6 @@ hipError_t tile_gemm_configure() {
     hipError_t e = configure_g<Tile128>();
     if (e == hipSuccess) e = configure_g<Tile64>();
     if (e == hipSuccess) e = configure_g<Tile64W8>();
+    if (e == hipSuccess) e = configure_g<Tile64x64>();
     return e;
 }
