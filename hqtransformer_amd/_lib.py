@@ -13,7 +13,7 @@ from typing import List, Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'tile_gemm.hip', 'exact_gemm.hip', 'mfma_gemm.hip', 'split_conv.hip', 'split_stream_conv.hip']
+SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'persist.hip', 'tile_gemm.hip', 'exact_gemm.hip', 'mfma_gemm.hip', 'split_conv.hip', 'split_stream_conv.hip']
 ABI_VERSION = 6
 
 PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT = 0, 1, 2

@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include "fast_kernels.h"
 #include "split_kernels.h"
+#include "persist.h"
 
 #include <algorithm>
 #include <cmath>
@@ -89,6 +90,16 @@ struct DecLayer {
     const float *n1_g = nullptr, *n1_b = nullptr, *n2_g = nullptr, *n2_b = nullptr;
 };
 
+// One program of the persistent AR chain (persist.h): the weight streams belong to the root handle, the phase table holds
+// workspace pointers and is bound per handle (a clone binds its own).
+struct PersistProg {
+    std::vector<PersistPhase> phases;         // host copy; pointers filled by persist_bind
+    char* stream = nullptr;
+    unsigned long long* d_cu_off = nullptr;
+    PersistPhase* d_phases = nullptr;
+    bool ok = false;
+};
+
 struct TimingSlot {
     std::string name;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -159,6 +170,13 @@ struct hqt_handle {
     hqt_handle* parent = nullptr;
     int n_clones = 0;
     int policy = 0;                           // HQT_POLICY_*: tile choice of the streaming GEMMs (part of the graph key)
+    // ---- persistent AR chain (FAST precision, up to 64 rows, latency policy, root handle): body blocks / depth sub-step 0 + head_top
+    PersistProg pbody, pdepth0;
+    int ncu = 0;
+    unsigned* persist_counters = nullptr;     // workspace: barrier + quad counters (zeroed by every launch)
+    unsigned* persist_err = nullptr;          // workspace: set by a launch that gave up on a barrier
+    float* persist_slabs = nullptr;           // workspace: K-split partials
+    bool persist_used = false;                // a persistent launch was queued since the last check of persist_err
     // ---- timing
     bool timing = false;
     std::vector<TimingSlot> slots;
@@ -424,6 +442,10 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), (void**)&h->xdpk, rows_pk * D * 2, true));
         CHK(dev_alloc(h.get(), (void**)&h->parts, (D / 32 + 1) * rows_pk * 2 * 4, true));
         CHK(dev_alloc(h.get(), (void**)&h->partsd, (D / 32 + 1) * rows_pk * 2 * 4, true));
+        CHK(dev_alloc(h.get(), (void**)&h->persist_counters, PERSIST_COUNTER_BYTES, true));
+        CHK(dev_alloc(h.get(), (void**)&h->persist_err, 256, true));
+        HIPCHK(hipMemset(h->persist_err, 0, 256));
+        CHK(dev_alloc(h.get(), (void**)&h->persist_slabs, persist_slab_floats(256) * 4, true));
     }
     if (c.has_stage1) {
         std::vector<DecLayer> both(h->dec);                 // decoder and encoder share the activation / attention / statistics buffers
@@ -492,6 +514,8 @@ extern "C" int hqt_clone(hqt_handle* src, hqt_handle** out) {
     for (int i = 0; i < hqt_handle::ROWS_RING; ++i) { h->rows_pinned[i] = nullptr; h->rows_ev[i] = nullptr; h->rows_busy[i] = false; }
     h->rows_next = 0;
     h->nparts = h->npartsd = 0;
+    h->pbody.d_phases = nullptr; h->pdepth0.d_phases = nullptr;      // phase tables hold workspace pointers: bound per handle (persist_bind)
+    h->persist_used = false;
     h->policy = HQT_POLICY_LATENCY;              // a lane's tile choice never depends on what the root ran when it was cloned
     const int rc = alloc_workspace(h.get());
     if (rc != HQT_OK) { for (void* p : h->owned) hipFree(p); return rc; }
@@ -702,6 +726,7 @@ static int load_encoder(hqt_handle* h) {
 static std::string key2(const hqt_handle* h, const char* name);
 
 static int finalize_impl(hqt_handle* h);
+static int persist_build(hqt_handle* h);
 extern "C" int hqt_finalize_weights(hqt_handle* h) {
     if (!h) return fail(HQT_ERR_INVALID, "null handle");
     if (h->finalized) return HQT_OK;
@@ -717,6 +742,7 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
         for (size_t i = owned_before; i < h->owned.size(); ++i) hipFree(h->owned[i]);
         h->owned.resize(owned_before);
         h->body.clear(); h->depth.clear();
+        h->pbody = PersistProg(); h->pdepth0 = PersistProg();
         h->head_top = h->head_bot = h->head_l2 = h->post_quant = h->quant_conv = Lin();
         for (auto& l : h->dec) { l.conv1 = l.conv2 = l.nin = l.q = l.k = l.v = l.proj = Lin(); }
         for (auto& l : h->enc) { l.conv1 = l.conv2 = l.nin = l.q = l.k = l.v = l.proj = Lin(); }
@@ -779,6 +805,7 @@ static int finalize_impl(hqt_handle* h) {
             }
             HIPCHK(hipDeviceSynchronize());          // fold_tmp is released by hqt_finalize_weights on every exit
         }
+        CHK(persist_build(h));                       // weight streams of the persistent AR chain (FAST, up to 64 rows)
         if (c.cond_type == HQT_COND_CLASS) CHK(get_w(h, "stage2.sos.weight", {c.n_classes, D}, &t));
         else if (c.cond_type == HQT_COND_TEXT) {
             CHK(get_w(h, "stage2.tok_emb_txt.weight", {c.vocab_txt, D}, &t));
@@ -991,6 +1018,148 @@ static std::string key2(const hqt_handle* h, const char* name) {
 }
 static const float* W(hqt_handle* h, const char* name) { return h->w[key2(h, name)].d; }
 
+
+// ------------------------------------------------------------------------------------------ persistent AR chain (persist.h)
+// FAST precision, up to 64 rows, decode steps (one token per sample), root handle under the latency policy: the twelve body blocks of a top
+// position run as ONE launch, and depth sub-step 0 (single-key blocks) + head_top as a second one.  Everything else -- merged passes, lanes,
+// EXACT / SPLIT, the text prefill, depth sub-step 1 (256 rows: MI355X_MICROARCH.md's verdict for 256-row blocks is "cut at every seam") --
+// keeps the launch chain.  HQT_PERSIST=0 switches it off (A/B).
+struct PackSrc { const float* w; const float* gamma; };
+static bool persist_env_on() { const char* e = getenv("HQT_PERSIST"); return !(e && atoi(e) == 0); }      // read per call: tests switch it between calls (part of the graph key)
+static bool persist_depth0_env_on() { const char* e = getenv("HQT_PERSIST_DEPTH0"); return !(e && atoi(e) == 0); }
+
+static void persist_block_shapes(hqt_handle* h, const BlockW& bw, bool single_key, int cache_T, int* k4, std::vector<PersistPhase>& out, std::vector<PackSrc>& src) {
+    const int D = h->cfg.embed_dim;
+    PersistPhase ph{};
+    if (single_key) {        // depth sub-step 0: one query over one key -- the attention output IS the value row (run_block_dln); only [key; value] is computed
+        ph.type = PP_KV1; ph.N = 2 * D; ph.K = D; ph.dln = 1; ph.cache_T = cache_T; ph.kv_row = 0;
+        out.push_back(ph); src.push_back({bw.qkv.w32 + (size_t)D * D, bw.ln1_g});
+    } else {
+        ph.type = PP_QKV; ph.N = 3 * D; ph.K = D; ph.dln = 1; ph.cache_T = cache_T;
+        out.push_back(ph); src.push_back({bw.qkv.w32, bw.ln1_g});
+        ph = PersistPhase{}; ph.type = PP_ATTN; ph.cache_T = cache_T;
+        out.push_back(ph); src.push_back({nullptr, nullptr});
+    }
+    ph = PersistPhase{}; ph.type = PP_RESID; ph.map = PP_MAP_QUAD; ph.N = D; ph.K = D;
+    out.push_back(ph); src.push_back({bw.proj.w32, nullptr});
+    ph = PersistPhase{}; ph.type = PP_GELU; ph.N = 4 * D; ph.K = D; ph.dln = 1; ph.act = h->cfg.gelu_approx ? ACT_GELU_SIGMOID : ACT_GELU_ERF;
+    out.push_back(ph); src.push_back({bw.fc1.w32, bw.ln2_g});
+    ph = PersistPhase{}; ph.type = PP_RESID_K4; ph.map = PP_MAP_K4; ph.N = D; ph.K = 4 * D; ph.k4_epoch = ++*k4;
+    out.push_back(ph); src.push_back({bw.fc2.w32, nullptr});
+}
+
+static int persist_build_one(hqt_handle* h, PersistProg& pr, const std::vector<PackSrc>& src) {
+    const hqt_config& c = h->cfg;
+    pr.ok = false;
+    if (!persist_program_ok(pr.phases, c.embed_dim, 64, c.n_heads, h->ncu)) return HQT_OK;
+    std::vector<unsigned long long> cu_off, tile_off;
+    const size_t bytes = persist_layout(pr.phases, h->ncu, cu_off, tile_off);
+    CHK(dev_alloc(h, (void**)&pr.stream, bytes + 1024, false));
+    CHK(dev_alloc(h, (void**)&pr.d_cu_off, cu_off.size() * 8, false));
+    HIPCHK(hipMemcpy(pr.d_cu_off, cu_off.data(), cu_off.size() * 8, hipMemcpyHostToDevice));
+    unsigned long long* d_tile = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tile, tile_off.size() * 8));
+    hipError_t e = hipMemcpy(d_tile, tile_off.data(), tile_off.size() * 8, hipMemcpyHostToDevice);
+    for (size_t p = 0; p < pr.phases.size() && e == hipSuccess; ++p)
+        if (src[p].w) e = launch_persist_pack(src[p].w, src[p].gamma, pr.phases[p], h->ncu, pr.stream, d_tile + p * h->ncu, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    hipFree(d_tile);
+    HIPCHK(e);
+    pr.ok = true;
+    return HQT_OK;
+}
+
+// finalize (root): the weight streams of both programs
+static int persist_build(hqt_handle* h) {
+    const hqt_config& c = h->cfg;
+    h->pbody = PersistProg(); h->pdepth0 = PersistProg();
+    if (!c.has_stage2 || getenv("HQT_PERSIST_BUILD_OFF")) return HQT_OK;
+    HIPCHK(hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device));
+    for (auto& b : h->body) if (!b.qkv.bias_ln || !b.fc1.bias_ln) return HQT_OK;        // no deferred-LayerNorm layouts for these shapes: launch chain
+    for (auto& b : h->depth) if (!b.qkv.bias_ln || !b.fc1.bias_ln) return HQT_OK;
+    std::vector<PackSrc> src;
+    int k4 = 0;
+    for (auto& b : h->body) persist_block_shapes(h, b, false, h->Tmax, &k4, h->pbody.phases, src);
+    CHK(persist_build_one(h, h->pbody, src));
+    if (c.code_levels != 3 && h->head_top.bias_ln) {
+        src.clear(); k4 = 0;
+        for (auto& b : h->depth) persist_block_shapes(h, b, true, 5, &k4, h->pdepth0.phases, src);
+        PersistPhase ph{};
+        ph.type = PP_ROWS; ph.N = c.vocab_top; ph.K = c.embed_dim; ph.dln = 1;
+        h->pdepth0.phases.push_back(ph); src.push_back({h->head_top.w32, h->w[key2(h, "ln_top.weight")].d});
+        CHK(persist_build_one(h, h->pdepth0, src));
+    }
+    HIPCHK(persist_configure());
+    return HQT_OK;
+}
+
+// per handle (a clone binds its own workspace): the phase tables with this handle's buffers.  Outside stream capture.
+static int persist_bind(hqt_handle* h) {
+    const hqt_config& c = h->cfg;
+    const size_t D = c.embed_dim;
+    auto upload = [&](PersistProg& pr) -> int {
+        CHK(dev_alloc(h, (void**)&pr.d_phases, pr.phases.size() * sizeof(PersistPhase), true));
+        HIPCHK(hipMemcpy(pr.d_phases, pr.phases.data(), pr.phases.size() * sizeof(PersistPhase), hipMemcpyHostToDevice));
+        return HQT_OK;
+    };
+    if (h->pbody.ok && !h->pbody.d_phases) {
+        const size_t kv_layer = (size_t)c.max_batch * h->Tmax * D;              // bf16 elements
+        size_t p = 0;
+        for (int l = 0; l < c.n_layers; ++l) {
+            const BlockW& bw = h->body[l];
+            bf16_t* kc = reinterpret_cast<bf16_t*>(h->kcache) + l * kv_layer;
+            bf16_t* vc = reinterpret_cast<bf16_t*>(h->vcache) + l * kv_layer;
+            PersistPhase* ph = &h->pbody.phases[p];
+            ph[0].A = h->xpk; ph[0].bias = bw.qkv.bias_ln; ph[0].colsum = bw.qkv.colsum; ph[0].out = h->qbuf; ph[0].kc = kc; ph[0].vc = vc;
+            ph[1].A = reinterpret_cast<bf16_t*>(h->qbuf); ph[1].out = h->abuf; ph[1].kc = kc; ph[1].vc = vc;
+            ph[2].A = reinterpret_cast<bf16_t*>(h->abuf); ph[2].bias = bw.proj.b32; ph[2].out = h->xpk;
+            ph[3].A = h->xpk; ph[3].bias = bw.fc1.bias_ln; ph[3].colsum = bw.fc1.colsum; ph[3].out = h->mbuf;
+            ph[4].A = reinterpret_cast<bf16_t*>(h->mbuf); ph[4].bias = bw.fc2.b32; ph[4].out = h->xpk;
+            p += 5;
+        }
+        CHK(upload(h->pbody));
+    }
+    if (h->pdepth0.ok && !h->pdepth0.d_phases) {
+        const size_t dkv_layer = (size_t)c.max_batch * 5 * D;
+        size_t p = 0;
+        for (int l = 0; l < c.n_layers_depth; ++l) {
+            const BlockW& bw = h->depth[l];
+            PersistPhase* ph = &h->pdepth0.phases[p];
+            ph[0].A = h->xdpk; ph[0].bias = bw.qkv.bias_ln + D; ph[0].colsum = bw.qkv.colsum + D;
+            ph[0].kc = reinterpret_cast<bf16_t*>(h->dk) + l * dkv_layer; ph[0].vc = reinterpret_cast<bf16_t*>(h->dv) + l * dkv_layer;
+            ph[0].vpk = reinterpret_cast<bf16_t*>(h->abuf);
+            ph[1].A = reinterpret_cast<bf16_t*>(h->abuf); ph[1].bias = bw.proj.b32; ph[1].out = h->xdpk;
+            ph[2].A = h->xdpk; ph[2].bias = bw.fc1.bias_ln; ph[2].colsum = bw.fc1.colsum; ph[2].out = h->mbuf;
+            ph[3].A = reinterpret_cast<bf16_t*>(h->mbuf); ph[3].bias = bw.fc2.b32; ph[3].out = h->xdpk;
+            p += 4;
+        }
+        PersistPhase& hd = h->pdepth0.phases[p];
+        hd.A = h->xdpk; hd.bias = h->head_top.bias_ln; hd.colsum = h->head_top.colsum; hd.out = h->logits;
+        CHK(upload(h->pdepth0));
+    }
+    return HQT_OK;
+}
+
+static bool persist_on(hqt_handle* h, const SampleCtx& c, const PersistProg& pr) {
+    return persist_env_on() && pr.ok && pr.d_phases && c.md.fast && c.B <= 64 && h->policy == HQT_POLICY_LATENCY && !h->parent;
+}
+
+static int run_persist(hqt_handle* h, const SampleCtx& c, const PersistProg& pr, float* x32, int write_back, const int* t_dev, const char* slot) {
+    Timed t(h, slot, c.st);
+    PersistArgs a{};
+    a.phases = pr.d_phases; a.n_phases = (int)pr.phases.size(); a.wstream = pr.stream; a.cu_off = pr.d_cu_off;
+    a.counters = h->persist_counters; a.err = h->persist_err; a.x32 = x32; a.slabs = h->persist_slabs;
+    a.D = h->cfg.embed_dim; a.M = c.B; a.MB = packed_mb(c.B); a.n_heads = h->cfg.n_heads; a.head_dim = h->cfg.embed_dim / h->cfg.n_heads;
+    a.t_base = 0; a.t_base_dev = t_dev; a.write_back = write_back;
+    static const bool nt = !(getenv("HQT_PERSIST_NT") && atoi(getenv("HQT_PERSIST_NT")) == 0);
+    a.nt_weights = nt ? 1 : 0;
+    persist_default_fill(a);
+    HIPCHK(launch_persist(a, h->ncu, c.st));
+    h->persist_used = true;
+    count_variant(h, "variant:%s", slot);
+    return HQT_OK;
+}
+
 static int run_ln(hqt_handle* h, hipStream_t st, float* x, const float* g, const float* b, const float* add, void* y, int M,
                   int D, int in_rpg, int in_off, int out_dt, int out_pk) {
     Timed t(h, "layernorm", st);
@@ -1118,7 +1287,10 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     // deferred LayerNorm needs the packed copy + row statistics of x from the caller's embedding kernel: embed_step emits
     // them (decode steps, Tq = 1); the text prefill's embed_text does not, so the prefill pass takes the classic path
     const bool dln_body = Tq_body == 1 && dln_ok(h, c, h->body[0], B * Tq_body);
-    for (int l = 0; l < cf.n_layers; ++l) {
+    // the twelve body blocks as ONE persistent launch (persist.h): decode steps of up to 64 samples
+    const bool pbody = dln_body && body_tbase_from_state && body_t_base == 0 && persist_on(h, c, h->pbody);
+    if (pbody) CHK(run_persist(h, c, h->pbody, h->x, 1, tb_dev, "persist_body"));
+    for (int l = 0; l < (pbody ? 0 : cf.n_layers); ++l) {
         void* kc = (char*)h->kcache + l * kv_layer;
         void* vc = (char*)h->vcache + l * kv_layer;
         // what follows this block's fc2: the next block's [query; key; value], or -- behind ln_f -- the depth head's first block (its key / value rows:
@@ -1141,8 +1313,10 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     const size_t dkv_layer = (size_t)cf.max_batch * 5 * D * esz;
     const int pk1 = (c.md.fast && B <= PACKED_MAX_ROWS && h->head_top.wpk) ? packed_mb(B) : 0;
     const int pk4 = (c.md.fast && 4 * B <= PACKED_MAX_ROWS && h->head_bot.wpk) ? packed_mb(4 * B) : 0;
-    // ---- depth sub-step 0: top code
-    for (int l = 0; l < cf.n_layers_depth; ++l) {
+    // ---- depth sub-step 0: top code.  Persistent form: the four single-key blocks + head_top as one launch
+    const bool pdepth0 = dln1 && !getenv("HQT_NO_SINGLE_KEY") && persist_depth0_env_on() && persist_on(h, c, h->pdepth0);
+    if (pdepth0) CHK(run_persist(h, c, h->pdepth0, h->xd, 0, nullptr, "persist_depth0"));
+    for (int l = 0; l < (pdepth0 ? 0 : cf.n_layers_depth); ++l) {
         void* kc = (char*)h->dk + l * dkv_layer;
         void* vc = (char*)h->dv + l * dkv_layer;
         const NextW after = l + 1 < cf.n_layers_depth ? next_qkv(h->depth[l + 1], single_key_on(), D) : next_w(h->head_top.wpk_ln, h->head_top.N, h->head_top.K);
@@ -1157,7 +1331,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
         g.A = h->hbuf; g.a_packed_mb = pk1;
     }
     g.M = B; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
-    CHK(run_linear(h, c.md, g, h->head_top, adt, DT_F32, c.st, "gemm_head"));
+    if (!pdepth0) CHK(run_linear(h, c.md, g, h->head_top, adt, DT_F32, c.st, "gemm_head"));
     {
         Timed t(h, "sampler", c.st);
         SamplerArgs s{h->logits, B, V, 1, B, c.o.temperature_top, c.o.top_k_top, c.o.top_p_top, c.noise, 0,
@@ -1401,6 +1575,7 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
     const float* noise = c.noise;
     float* logits_out = c.logits_out;
     HIPCHK(sampler_configure(cf.vocab_top, opts->top_p_top > 0.f || opts->top_p_bot > 0.f));
+    CHK(persist_bind(h));
     HIPCHK(launch_set_step(h->state, 0, 0, c.st));
     if (opts->row_seeds || opts->row_offsets) {      // merged steps: per-row Philox keys (host arrays, staged through pinned-free pageable copies: B <= max_batch entries)
         if (!opts->row_seeds || !opts->row_offsets) return fail(HQT_ERR_INVALID, "row_seeds and row_offsets come together");
@@ -1439,7 +1614,8 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
         std::vector<uint64_t> key = {(uint64_t)G, (uint64_t)B, (uint64_t)(cond != nullptr), (uint64_t)noise, (uint64_t)c.feed_top, (uint64_t)c.feed_bot,
                                      (uint64_t)logits_out, (uint64_t)opts->precision,
                                      (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot,
-                                     (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2], (uint64_t)h->policy};
+                                     (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2], (uint64_t)h->policy,
+                                     (uint64_t)(persist_env_on() ? 1 + (persist_depth0_env_on() ? 1 : 0) + (getenv("HQT_NO_SINGLE_KEY") ? 4 : 0) : 0)};
         { uint32_t f3[2]; memcpy(f3, &c.top_p[2], 4); memcpy(f3 + 1, &c.temperature[2], 4); key.push_back(f3[0]); key.push_back(f3[1]); }
         uint32_t f[4];
         memcpy(f, &opts->top_p_top, 4); memcpy(f + 1, &opts->top_p_bot, 4);
@@ -1877,6 +2053,16 @@ extern "C" int hqt_range_check(hqt_handle* h, void* stream) {
     ON_DEVICE(h);
     int flag = 0;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (h->persist_used && h->persist_err) {     // a persistent AR launch that gave up on a barrier (2 s: the GPU was shared with something that kept its workgroups out)
+        unsigned pe = 0;
+        HIPCHK(hipMemcpy(&pe, h->persist_err, sizeof pe, hipMemcpyDeviceToHost));
+        h->persist_used = false;
+        if (pe) {
+            HIPCHK(hipMemset(h->persist_err, 0, sizeof pe));
+            return fail(HQT_ERR_STATE, "a persistent AR launch on this handle gave up at the grid barrier in front of phase %u (its workgroups were not all resident within 2 s): "
+                                       "the codes of that call are invalid; repeat it, or set HQT_PERSIST=0", pe - 1);
+        }
+    }
     HIPCHK(hipMemcpy(&flag, h->range_flag, sizeof flag, hipMemcpyDeviceToHost));
     if (!flag) return HQT_OK;
     HIPCHK(hipMemset(h->range_flag, 0, sizeof flag));
