@@ -486,6 +486,8 @@ def main():
         for k in range(n):
             i = args.warmup + k
             with torch.cuda.stream(s_ar):
+                if k > 0:
+                    s_ar.wait_event(ev[3 * k - 1])     # the reference harness runs sample -> decode -> sample ...: nothing of step k + 1 starts before step k's pixels are done
                 ev[3 * k].record()
                 ct, cb = sample_codes(i, not args.no_graph, ar_prec=ar_prec)
                 ev[3 * k + 1].record()
@@ -501,6 +503,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         model.stage1.range_check()             # SPLIT decode: an activation outside the fp16 range would invalidate the pixels (raises)
+        model.stage2.range_check()             # SPLIT AR passes above 256 rows saturate out-of-range activations and only flag them; also a persistent AR launch that gave up
         a_ms = sum(ev[3 * k].elapsed_time(ev[3 * k + 1]) for k in range(n)) / n
         d_ms = sum(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]) for k in range(n)) / n
         if dist is not None:
@@ -520,12 +523,16 @@ def main():
     if fast and not args.no_exact_mode and not args.positions:
         xprec = dec_prec if dec_prec != 'fast' else 'split'
         what = {'exact': 'EXACT: fp32 weights / activations / accumulation on the vector ALUs -- codes bit-identical to the oracle (tests/test_gpu_timed_schedule.py)',
-                'split': 'SPLIT: the EXACT launch sequence with every nn.Linear on the matrix cores (fp32 activations split into fp16 hi / lo while staged, fp16 hi / lo weight planes, '
-                         '3 MFMAs per term, fp32 accumulation); fp32 LayerNorm / attention / softmax / sampler -- codes bit-identical to the oracle, logits <= 2e-4 (same tests)'}
+                'split': 'SPLIT API: the EXACT launch sequence with every nn.Linear on the matrix cores -- up to 256 rows per GEMM the fp32 matrix instructions (exact_mfma_gemm_kernel: the SAME '
+                         'kernels as `exact`, so a one-step-at-a-time record of `split` times what `exact` times), above 256 rows fp16 hi / lo operands with 3 MFMAs per term '
+                         '(split_gemm_kernel); fp32 accumulation, LayerNorm, attention, softmax and sampler -- codes bit-identical to the oracle wherever the draw is well-conditioned '
+                         '(winner / runner-up margin >= 1.00001: include/hqt.h), logits <= 2e-4 (same tests)'}
         exact_mode = {}
         for arp in ('split', 'exact'):
             ex = one_at_a_time(3, arp, xprec, gather=False)
             ex['precision'] = {'ar': what[arp], 'decode': xprec}
+            ex['ar_gemm_kernels'] = ('exact_mfma_gemm_kernel (fp32 matrix instructions): every AR GEMM of a batch-%d step has <= 256 rows' % B) if 4 * B <= 256 else (
+                'split_gemm_kernel above 256 rows, exact_mfma_gemm_kernel up to 256' if arp == 'split' else 'gemm_tile_kernel above 256 rows, exact_mfma_gemm_kernel up to 256')
             ex['note'] = '3 batch-%d steps one at a time on one lane' % B
             rec = {'like_for_like': ex}
             if merge > 1:
@@ -631,9 +638,9 @@ def main():
             for k, v in e.timing_report().items():
                 rep[k] = (rep.get(k, (0, 0.0))[0] + v[0], rep.get(k, (0, 0.0))[1] + v[1])
             e.timing(False)
-        gemm = {k: v for k, v in rep.items() if k.startswith('gemm_')}
+        gemm = {k: v for k, v in rep.items() if k.startswith('gemm_') or k.startswith('persist_')}     # persist_*: the persistent AR chain (one launch = the GEMMs, attention and epilogues of 12 body blocks / of depth sub-step 0 + head_top)
         conv = {k: v for k, v in rep.items() if k in ('conv3x3', 'conv1x1', 'conv_out', 'attn_gemm')}
-        ar_classes = [k for k in rep if k.startswith('gemm_') or k in ('layernorm', 'attention', 'sampler', 'embed')]
+        ar_classes = [k for k in rep if k.startswith('gemm_') or k.startswith('persist_') or k in ('layernorm', 'attention', 'sampler', 'embed')]
         ar_eager_ms = sum(rep[k][1] for k in ar_classes)
         # The timed region replays the AR loop from a hipGraph; the per-launch events can only be recorded in an un-graphed
         # pass, where every launch carries an extra event record and the eager launch gap.  Both passes are timed with HIP
@@ -654,7 +661,10 @@ def main():
             # Which roofline bounds an AR GEMM depends on the rows of the pass: its intensity is ~rows FLOP per weight byte, the ridge of the
             # part 2500 TFLOP/s / 8 TB/s = 312 FLOP/B.  Below 256 rows the launches are weight streams (HBM); merged passes are matrix work.
             mfma_bound = Bm >= 256
-            rec = {'kernel': (f'tile_gemm_kernel / stream_gemm_kernel: AR GEMM family (qkv / proj / fc1 / fc2 / heads + split-K combine; {Bm}-row passes, {4 * Bm} rows in depth sub-step 1)'),
+            persist = any(k.startswith('persist_') for k in gemm)
+            rec = {'kernel': (('persist_kernel (the 12 body blocks of a top position as ONE launch, depth sub-step 0 + head_top as a second: GEMMs + attention + epilogues; '
+                               f'csrc/persist.hip) + stream_gemm_kernel (depth sub-step 1 at {4 * Bm} rows, head_bot): AR weight-streaming family, {Bm}-row passes') if persist else
+                              f'tile_gemm_kernel / stream_gemm_kernel: AR GEMM family (qkv / proj / fc1 / fc2 / heads + split-K combine; {Bm}-row passes, {4 * Bm} rows in depth sub-step 1)'),
                    'bound': 'mfma' if mfma_bound else 'hbm',
                    'achieved': round(tf, 1) if mfma_bound else round(hbm, 1), 'peak': MFMA_BF16_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
                    'unit': 'TFLOP/s' if mfma_bound else 'GB/s',

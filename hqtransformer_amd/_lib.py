@@ -114,45 +114,77 @@ _lib: Optional[C.CDLL] = None
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libhqt.so for gfx950 in-tree with hipcc (cross-compiles without a GPU): one object per source, the stale
-    ones in parallel, then one link."""
+    ones in parallel, then one link.  "Stale" is decided by CONTENT, not by file times: every object carries a stamp = SHA-256 of its
+    source, every header, the flags and `hipcc --version` (build/<name>.stamp), and libhqt.so one over the objects' stamps -- an object or
+    a library shipped from another checkout, or left behind by an older source with a newer mtime, is rebuilt instead of loaded."""
+    import hashlib
     from concurrent.futures import ThreadPoolExecutor
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(os.path.dirname(HERE), 'include', 'hqt.h')]
+    hdrs = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(os.path.dirname(HERE), 'include', 'hqt.h')])
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     flags = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
     objdir = os.path.join(CSRC, 'build')
     os.makedirs(objdir, exist_ok=True)
+    ver = subprocess.run([hipcc, '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    common = hashlib.sha256()
+    for f in hdrs:
+        with open(f, 'rb') as fp:
+            common.update(os.path.basename(f).encode() + b'\0' + fp.read())
+    common.update(' '.join(flags).encode() + ver.encode())
 
-    def stale(out, deps):
-        return force or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps)
+    def read(path):
+        try:
+            with open(path) as fp:
+                return fp.read().strip()
+        except OSError:
+            return ''
+
+    def stamp_of(name):
+        hh = common.copy()
+        with open(os.path.join(CSRC, name), 'rb') as fp:
+            hh.update(name.encode() + b'\0' + fp.read())
+        return hh.hexdigest()
 
     def compile_one(name):
         src, obj = os.path.join(CSRC, name), os.path.join(objdir, name.replace('.hip', '.o'))
-        if not stale(obj, [src] + hdrs):
-            return obj
+        stamp, want = obj[:-2] + '.stamp', stamp_of(name)
+        if not force and os.path.exists(obj) and read(stamp) == want:
+            return obj, want
+        if os.path.exists(stamp):
+            os.remove(stamp)
         cmd = [hipcc] + flags + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if proc.returncode != 0:
             raise HqtLibraryError(f'hipcc failed on {name}:\n' + proc.stdout)
-        return obj
+        with open(stamp, 'w') as fp:
+            fp.write(want + '\n')
+        return obj, want
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES) + 1, max(1, (os.cpu_count() or 2) - 1))) as pool:
         audit = pool.submit(audit_hand_scheduled_loops, hipcc, flags, hdrs, force, verbose)
-        objs = list(pool.map(compile_one, SOURCES))
+        built = list(pool.map(compile_one, SOURCES))
         audit.result()                               # raises HqtLibraryError: no library without a valid audit of the ISA it contains
-    if stale(LIB_PATH, objs):
+    objs = [o for o, _ in built]
+    lib_want = hashlib.sha256('\n'.join(st for _, st in built).encode()).hexdigest()
+    lib_stamp = os.path.join(objdir, 'libhqt.stamp')
+    if force or not os.path.exists(LIB_PATH) or read(lib_stamp) != lib_want:
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if proc.returncode != 0:
             raise HqtLibraryError('link failed:\n' + proc.stdout)
+        with open(lib_stamp, 'w') as fp:
+            fp.write(lib_want + '\n')
     return LIB_PATH
 
 
-# kernels of split_stream_conv.hip whose main loop keeps inline-asm loads in flight across its back edge (mangled names)
-AUDITED_KERNELS = ('_Z27conv3x3_split_ring16_kernelILi0EEv8GemmArgs', '_Z25conv2x2_split_up16_kernelILi0EEv8GemmArgs', '_Z26conv3x3_split_out16_kernel8GemmArgs')
+# kernels of split_stream_conv.hip whose main loop keeps inline-asm loads in flight across its back edge: EVERY instantiation the
+# object holds is audited -- the symbols are taken from the generated ISA by name pattern, not from a list that a new template
+# argument would silently miss
+AUDITED_PATTERN = r'^\s*\.amdhsa_kernel\s+(\S*(?:conv3x3_split_ring16_kernel|conv2x2_split_up16_kernel|conv3x3_split_out16_kernel)\S*)'
+AUDITED_MIN = 3                                   # at least the three kernels of round 4 must be there (a pattern that matches nothing is a broken audit)
 
 
 def audit_hand_scheduled_loops(hipcc: str, flags: List[str], hdrs: List[str], force: bool = False, verbose: bool = False) -> None:
@@ -176,7 +208,7 @@ def audit_hand_scheduled_loops(hipcc: str, flags: List[str], hdrs: List[str], fo
     hh.update(' '.join(flags).encode())
     ver = subprocess.run([hipcc, '--version'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     hh.update(ver.stdout.encode())
-    hh.update(' '.join(AUDITED_KERNELS).encode())
+    hh.update(AUDITED_PATTERN.encode())
     key = hh.hexdigest()
     if not force and os.path.exists(stamp) and open(stamp).read().strip() == 'ok ' + key:
         return
@@ -190,7 +222,12 @@ def audit_hand_scheduled_loops(hipcc: str, flags: List[str], hdrs: List[str], fo
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if proc.returncode != 0:
             raise HqtLibraryError('hipcc -S failed on split_stream_conv.hip (ISA audit):\n' + proc.stdout)
-        for kernel in AUDITED_KERNELS:
+        import re
+        with open(asm) as fp:
+            kernels = sorted(set(m.group(1) for m in re.finditer(AUDITED_PATTERN, fp.read(), re.M)))
+        if len(kernels) < AUDITED_MIN:
+            raise HqtLibraryError(f'ISA audit: found {kernels} in the ISA of split_stream_conv.hip, expected at least {AUDITED_MIN} ring kernels')
+        for kernel in kernels:
             r = subprocess.run([sys.executable, tool, asm, kernel], capture_output=True, text=True)
             if r.returncode != 0:
                 raise HqtLibraryError(f'ISA audit of {kernel} failed -- the hand-scheduled loop is not safe with this toolchain:\n{r.stdout}{r.stderr}')

@@ -182,13 +182,6 @@ struct GemmArgs {
     int* range_flag;         // a_f32 / b_f32: where an element outside the fp16 range is reported (hqt_range_check)
     int out_split;           // conv3x3_split_ring16_kernel: store the output as fp16 hi / lo operand planes [pixel][2][N] (range-checked: range_flag) instead of the
                              // fp32 tensor -- the consumer is another SPLIT conv with nothing in between (resblock -> upsampling conv): no operand pass
-    // ---- cross-kernel weight prefetch (streaming GEMMs of the 64-row AR chain): the packed weights of the NEXT GEMM of the chain.  A ninth
-    //      wave of every workgroup touches one dword per 128-byte line of them while the eight others work, so that the successor finds its
-    //      weight stream in L2 instead of waiting an HBM round trip for it (tools/micro/bench_stream: 8.9 -> 6.4 us with warm weights at 64 rows).
-    //      pf_slice = bytes of one 32-column n-tile (K' / 16 KiB); workgroup b of the successor (XCD b % 8) reads n-tile b, so n-tile j is
-    //      touched from an XCD-(j % 8) workgroup of this launch.  NULL: no prefetch.
-    const void* pf_w;
-    unsigned pf_bytes, pf_slice;
     int k_quarters;          // fp32 nn.Linear of the AR loop (set by run_linear for its gemm_* launches): the four-quarter summation order shared by
                              //   exact_mfma_gemm_kernel (<= 256 rows) and gemm_tile_kernel<..., QUARTERS>; every other fp32 GEMM keeps one chain per output
     int b_tile16;            // exact_mfma_gemm_kernel only: Bw is the fragment-ordered fp32 copy [n / 16][k / 32][chunk][lane][4] (pack_exact_tiles_kernel)

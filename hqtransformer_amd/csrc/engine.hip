@@ -1204,29 +1204,16 @@ static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float*
 
 // FAST block with deferred LayerNorm (5 launches instead of 7): the residual stream is kept as an fp32 master row plus
 // a bf16 packed copy with partial row statistics; qkv / fc1 consume the copy with gamma-folded weights and normalise in
-// their epilogue, proj / fc2 update all three in theirs.
-// The packed weights the NEXT streaming GEMM of the AR chain will read (GemmArgs::pf_w: the predecessor's prefetch wave warms L2 with them)
-struct NextW { const void* w = nullptr; unsigned bytes = 0, slice = 0; };
-static NextW next_w(const bf16_t* wpk, int N, int K) {
-    NextW n;
-    if (wpk && K % 128 == 0) { n.w = wpk; n.bytes = (unsigned)((size_t)N * K * 2); n.slice = (unsigned)K * 64; }
-    return n;
-}
-static void with_pf(GemmArgs& g, const NextW& n) { g.pf_w = n.w; g.pf_bytes = n.bytes; g.pf_slice = n.slice; }
-// what a deferred-LayerNorm block reads first: its fused [query; key; value] weights -- the key / value rows only when the block runs the
-// single-key shortcut (run_block_dln)
+// their epilogue, proj / fc2 update all three in theirs.  (Round 4's ninth "prefetch" wave, which touched the NEXT launch's weights
+// from inside this one, bought nothing -- profiles/r04_micro_weight_prefetch.txt -- and left with its switch in round 5.)
 static bool single_key_on() { static const bool on = !getenv("HQT_NO_SINGLE_KEY"); return on; }
-static NextW next_qkv(const BlockW& bw, bool single_key, int D) {
-    if (single_key) return next_w(bw.qkv.wpk_ln ? bw.qkv.wpk_ln + (size_t)D * bw.qkv.K : nullptr, 2 * D, bw.qkv.K);
-    return next_w(bw.qkv.wpk_ln, bw.qkv.N, bw.qkv.K);
-}
 static bool dln_ok(hqt_handle* h, const SampleCtx& c, const BlockW& bw, int M) {
     static const bool off = getenv("HQT_NO_DLN") != nullptr;      // debugging / A-B switch: classic LayerNorm kernels
     if (off) return false;
     return c.md.fast && M <= PACKED_MAX_ROWS && bw.qkv.wpk_ln && bw.fc1.wpk_ln && bw.proj.wpk && bw.fc2.wpk && h->cfg.embed_dim % 32 == 0;
 }
 static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float* x32, bf16_t* xpk, float* parts, int* nparts,
-                         int Tq, void* kc, void* vc, int Tcache, int t_base, const int* t_base_dev, int causal, const NextW& after = NextW()) {
+                         int Tq, void* kc, void* vc, int Tcache, int t_base, const int* t_base_dev, int causal) {
     const int D = h->cfg.embed_dim, M = c.B * Tq, pk = packed_mb(M);
     GemmArgs g{};
     g.A = xpk; g.M = M; g.batch = 1; g.a_packed_mb = pk;
@@ -1238,7 +1225,6 @@ static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, fl
     // the fused weight (rows [D, 3D) only), appends K/V to the cache for sub-step 1 and writes V straight into the
     // projection's operand; no attention launch.
     const bool single_key = Tq == 1 && t_base == 0 && !t_base_dev && !getenv("HQT_NO_SINGLE_KEY");
-    with_pf(g, next_w(bw.proj.wpk, bw.proj.N, bw.proj.K));          // (the attention launch in between is short and streams the K / V cache past L2)
     if (single_key) {
         g.qkv_first = 1; g.qkv_v_pk = reinterpret_cast<bf16_t*>(h->abuf); g.c_packed_mb = pk;
         Lin kv = bw.qkv;
@@ -1257,7 +1243,6 @@ static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, fl
     g = GemmArgs{};
     g.A = h->abuf; g.M = M; g.batch = 1; g.a_packed_mb = pk;
     g.C = x32; g.ldc = D; g.store = STORE_RESID; g.resid_pk = xpk; g.resid_parts = parts; g.c_packed_mb = pk;
-    with_pf(g, next_w(bw.fc1.wpk_ln, bw.fc1.N, bw.fc1.K));
     CHK(run_linear(h, c.md, g, bw.proj, DT_BF16, DT_F32, c.st, "gemm_proj"));
     *nparts = h->resid_nparts;
     g = GemmArgs{};
@@ -1265,12 +1250,10 @@ static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, fl
     g.ln_parts = parts; g.ln_nparts = *nparts; g.ln_colsum = bw.fc1.colsum; g.ln_eps = 1e-5f;
     g.C = h->mbuf; g.ldc = 4 * D; g.store = STORE_PACKED; g.c_packed_mb = pk;
     g.act = h->cfg.gelu_approx ? ACT_GELU_SIGMOID : ACT_GELU_ERF;
-    with_pf(g, next_w(bw.fc2.wpk, bw.fc2.N, bw.fc2.K));
     CHK(run_linear(h, c.md, g, bw.fc1, DT_BF16, DT_BF16, c.st, "gemm_fc1"));
     g = GemmArgs{};
     g.A = h->mbuf; g.M = M; g.batch = 1; g.a_packed_mb = pk;
     g.C = x32; g.ldc = D; g.store = STORE_RESID; g.resid_pk = xpk; g.resid_parts = parts; g.c_packed_mb = pk;
-    with_pf(g, after);
     CHK(run_linear(h, c.md, g, bw.fc2, DT_BF16, DT_F32, c.st, "gemm_fc2"));
     *nparts = h->resid_nparts;
     return HQT_OK;
@@ -1293,10 +1276,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     for (int l = 0; l < (pbody ? 0 : cf.n_layers); ++l) {
         void* kc = (char*)h->kcache + l * kv_layer;
         void* vc = (char*)h->vcache + l * kv_layer;
-        // what follows this block's fc2: the next block's [query; key; value], or -- behind ln_f -- the depth head's first block (its key / value rows:
-        // depth sub-step 0 runs the single-key shortcut)
-        const NextW after = l + 1 < cf.n_layers ? next_qkv(h->body[l + 1], false, D) : next_qkv(h->depth[0], single_key_on(), D);
-        if (dln_body) CHK(run_block_dln(h, c, h->body[l], h->x, h->xpk, h->parts, &h->nparts, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1, after));
+        if (dln_body) CHK(run_block_dln(h, c, h->body[l], h->x, h->xpk, h->parts, &h->nparts, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
         else CHK(run_block(h, c, h->body[l], h->x, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
     }
     const bool dln1 = dln_ok(h, c, h->depth[0], B) && h->head_top.wpk_ln;
@@ -1319,8 +1299,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     for (int l = 0; l < (pdepth0 ? 0 : cf.n_layers_depth); ++l) {
         void* kc = (char*)h->dk + l * dkv_layer;
         void* vc = (char*)h->dv + l * dkv_layer;
-        const NextW after = l + 1 < cf.n_layers_depth ? next_qkv(h->depth[l + 1], single_key_on(), D) : next_w(h->head_top.wpk_ln, h->head_top.N, h->head_top.K);
-        if (dln1) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, 1, kc, vc, 5, 0, nullptr, 0, after));
+        if (dln1) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, 1, kc, vc, 5, 0, nullptr, 0));
         else CHK(run_block(h, c, h->depth[l], h->xd, 1, kc, vc, 5, 0, nullptr, 0));
     }
     GemmArgs g{};

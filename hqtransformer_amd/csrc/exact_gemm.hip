@@ -73,11 +73,16 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
         // rows -> fragments through the wave's patch (in-order LDS: the reads below see the writes above, the next step's writes follow these reads)
 #pragma unroll
         for (int t = 0; t < 2 * MT; ++t) *reinterpret_cast<f32x4*>(pw + 8 * t * PITCH) = xg[slot][t];
+        // other lanes read what this lane wrote: say so to the compiler (both compile to nothing; the DS unit executes a wave's accesses in order)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         f32x4 xf[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) xf[mt][ch] = *reinterpret_cast<const f32x4*>(pr + 16 * mt * PITCH + 16 * ch);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // ... and the next step's stores stay behind these loads
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch)                   // the two 16-k chunks of the step, ascending; per output ONE chain, whatever MT
 #pragma unroll

@@ -96,42 +96,6 @@ __device__ inline void ln_partial_stats(const GemmArgs& g, float& ln_s, float& l
     }
 }
 
-// The prefetch wave of a streaming GEMM (GemmArgs::pf_w): units of 8 KiB (64 lines, one per lane) of the successor's n-tiles j = r (mod 8),
-// r = this workgroup's XCD, dealt round-robin to the workgroups of that XCD.  At most 56 loads in flight (vmcnt is a 6-bit counter).
-#ifndef HQT_PF_DELAY
-#define HQT_PF_DELAY 100
-#endif
-#ifndef HQT_PF_STRIDE
-#define HQT_PF_STRIDE 128              // bytes between the touched dwords (tools/micro/bench_stream compiles 128 / 64 / 32: how much of a line does one touch bring in?)
-#endif
-__device__ __forceinline__ unsigned stream_prefetch_wave(const GemmArgs& g) {
-    // The loads are never waited for inside the loop, so their destination must stay reserved while they are in flight: ONE register, tied
-    // through every asm statement ("+v") and consumed by the caller after the workgroup's barriers (a plain "=v" output is dead to the
-    // compiler at once -- it reused the register for the next address, and the returning load then overwrote it: memory fault).
-    unsigned dead = 0;
-    constexpr int UNIT = 64 * HQT_PF_STRIDE;          // bytes one wave instruction touches
-    const int lane = threadIdx.x & 63;
-    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nwg = gridDim.x * gridDim.y * gridDim.z;
-    const int r = id & 7, q = id >> 3, Q = nwg >> 3;
-    if (q >= Q || !g.pf_w) return dead;
-    const int upg = (int)(g.pf_slice / UNIT), G8 = (int)(g.pf_bytes / g.pf_slice) >> 3;
-    const int units = upg * G8;
-    const char* base = reinterpret_cast<const char*>(g.pf_w) + lane * HQT_PF_STRIDE;
-    int issued = 0;
-    // the workgroup's own loads go first (~3 us: the successor's slice plus this launch's exceed an XCD's 4 MiB of L2, and a line prefetched one launch ago
-    // is older than a line prefetched now -- started together, the prefetch evicted what the eight waves were about to read; bench_stream, fc1 at 64 rows:
-    // 9.19 us without the wave, 9.33 / 9.20 / 8.61 / 10.67 us with a delay of 20 / 50 / 100 / 200 x 64 cycles)
-    __builtin_amdgcn_s_sleep(HQT_PF_DELAY > 127 ? 127 : HQT_PF_DELAY);
-    if (HQT_PF_DELAY > 127) __builtin_amdgcn_s_sleep(HQT_PF_DELAY - 127);
-    for (int v = q; v < units; v += Q, ++issued) {
-        const int grp = v / upg, j = r + 8 * grp;
-        const char* p = base + (size_t)j * g.pf_slice + (size_t)(v - grp * upg) * UNIT;
-        if (issued >= 48 && (issued & 15) == 0) asm volatile("s_waitcnt vmcnt(32)" : "+v"(dead));      // vmcnt is a 6-bit counter
-        asm volatile("global_load_dword %0, %1, off" : "+v"(dead) : "v"(p));
-    }
-    return dead;
-}
-
 // Tile of one workgroup: (32 NT) weight rows x (32 MBW) activation rows x K / gridDim.z; the NW waves
 // split that K range into contiguous runs.  gridDim = (N / (32 NT), MB_total / MBW, S).  With S > 1
 // (cross-workgroup split-K) the fp32 partial tile goes to slab z of `slabs` ([S][Mpad][N]) and the
@@ -145,18 +109,9 @@ constexpr int stream_min_waves(int MBW, int NT, int NW, int U) {
 // PIPE: the wave's k-steps run as a software pipeline of depth U (k-step i + U is fetched into the registers k-step i just
 // released) instead of load-a-run / wait / multiply-a-run: the variants of the merged passes (M = 256 .. 1024), whose
 // per-wave K range is several runs long.  Needs cnt % U == 0 (the planner checks).
-// PF: a ninth wave that prefetches the successor's weights (GemmArgs::pf_w) -- its own instantiation, because the larger workgroup lowers the
-// register budget of all of them (9 waves: 3 per SIMD, 170 registers; <2, 1, 8, 12> needs 215)
-template <int MBW, int NT, int NW, int U, typename TC, int ABL = 0, bool PIPE = false, bool PF = false>   // ABL: ablation switches of tools/micro/bench_stream
-__global__ __launch_bounds__((NW + (PF ? 1 : 0)) * 64, stream_min_waves(MBW, NT, NW, U)) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
+template <int MBW, int NT, int NW, int U, typename TC, int ABL = 0, bool PIPE = false>   // ABL: ablation switches of tools/micro/bench_stream
+__global__ __launch_bounds__(NW * 64, stream_min_waves(MBW, NT, NW, U)) void stream_gemm_kernel(GemmArgs g, const u32x4* __restrict__ wpk, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    if (PF && threadIdx.x >= NW * 64) {                               // the prefetch wave
-        unsigned dead = stream_prefetch_wave(g);
-        __builtin_amdgcn_s_barrier();                                 // the workgroup's barriers, without the memory waits of __syncthreads():
-        if (g.ln_parts) __builtin_amdgcn_s_barrier();                 // this wave's loads are fire-and-forget
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(dead));              // (landed long ago; keeps their destination register reserved until here)
-        return;
-    }
     float* red = reinterpret_cast<float*>(smem_raw);                  // [NW][NT][MBW][m32][RP]: row m holds its 32 n, padded to 36 floats
     constexpr int TILE = NT * MBW * 1024;                             // outputs per workgroup
     constexpr int RP = 36;                                            // row pitch: 8 lanes x ds_write_b128 land on 8 distinct 4-bank groups
@@ -577,21 +532,12 @@ bool stream_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
            g.K % 16 == 0 && g.a_packed_mb == packed_mb(g.M);
 }
 
-template <int MBW, int NT, int NW, int U, typename TC, bool PIPE = false, bool PF = false>
+template <int MBW, int NT, int NW, int U, typename TC, bool PIPE = false>
 static hipError_t launch_stream_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
     const size_t smem = stream_gemm_lds(MBW, NT, NW);
     const dim3 grid(g.N / (32 * NT), g.a_packed_mb / MBW, S);
-    GemmArgs gg = g;
-    if (!PF) gg.pf_w = nullptr;
-    stream_gemm_kernel<MBW, NT, NW, U, TC, 0, PIPE, PF><<<grid, (NW + (PF ? 1 : 0)) * 64, smem, st>>>(gg, reinterpret_cast<const u32x4*>(wpk), slabs);
+    stream_gemm_kernel<MBW, NT, NW, U, TC, 0, PIPE><<<grid, NW * 64, smem, st>>>(g, reinterpret_cast<const u32x4*>(wpk), slabs);
     return hipGetLastError();
-}
-// The prefetch wave rides along when the launch leaves every workgroup a CU to itself (a ninth wave would not leave room for a second 8-wave
-// workgroup) and nothing else synchronises the workgroup.
-static bool stream_prefetch_wanted(const GemmArgs& g, int workgroups) {
-    // OFF by default: measured, it buys nothing (profiles/r04_micro_weight_prefetch.txt).  HQT_WEIGHT_PREFETCH=1 turns it on.
-    static const bool off = !(getenv("HQT_WEIGHT_PREFETCH") && atoi(getenv("HQT_WEIGHT_PREFETCH")) == 1);
-    return !off && g.pf_w && g.pf_slice >= 8192 && g.pf_slice % 8192 == 0 && g.pf_bytes >= 8 * g.pf_slice && workgroups <= 256 && !g.chain.wait && !g.chain.signal;
 }
 // configuration table (tools/micro/bench_stream on MI355X): per-CU L2->L1 bandwidth (~40 GB/s) bounds these
 // kernels, so the decomposition maximises the number of busy CUs; narrow-N GEMMs split K across
@@ -629,15 +575,12 @@ static hipError_t launch_stream_c(const GemmArgs& g, const bf16_t* wpk, int S, f
     }
     const int wgs2 = (g.N / 32) * (g.a_packed_mb / 2);
     if (S == 1 && g.a_packed_mb == 2 && wgs2 >= 128) {
-        // (with the successor's weights to prefetch: 6-step runs -- 118 registers, room for the ninth wave; warm weights 5.7 vs 6.4 us, cold 8.9 both)
-        if (stream_prefetch_wanted(g, g.N / 32)) return launch_stream_t<2, 1, 8, 6, TC, false, true>(g, wpk, 1, nullptr, st);
         return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);
     }
     if (S == 1 && g.a_packed_mb >= 4) {                 // M = 128..256 (depth sub-step 1): 64-row activation tiles halve the weight re-reads
         if (g.N >= 3072) return launch_stream_t<2, 1, 8, 6, TC>(g, wpk, 1, nullptr, st);      // qkv / fc1 / heads: 18-20 us vs 20-25 us
         return launch_stream_t<2, 1, 8, 12, TC>(g, wpk, 1, nullptr, st);                        // proj / fc2: 8.7 / 20 us vs 9.3 / 25 us
     }
-    if (S == 1 && stream_prefetch_wanted(g, (g.N / 32) * g.a_packed_mb)) return launch_stream_t<1, 1, 8, 12, TC, false, true>(g, wpk, 1, nullptr, st);
     return launch_stream_t<1, 1, 8, 12, TC>(g, wpk, S, slabs, st);
 }
 hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, int S, float* slabs, hipStream_t st) {
@@ -654,12 +597,6 @@ hipError_t stream_gemm_configure() {
     STREAM_CASES(CFG, bf16_t)
     STREAM_CASES(CFG, float)
 #undef CFG
-#define CFGF(MBW, NT, NW, U, TC)                                                                                   \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, TC, 0, false, true>), \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_gemm_lds(MBW, NT, NW));      \
-    if (e != hipSuccess) return e;
-    CFGF(2, 1, 8, 6, bf16_t) CFGF(2, 1, 8, 6, float) CFGF(1, 1, 8, 12, bf16_t) CFGF(1, 1, 8, 12, float)
-#undef CFGF
 #define CFGP(MBW, NT, NW, U, TC)                                                                                   \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, TC, 0, true>),        \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_gemm_lds(MBW, NT, NW));      \

@@ -85,9 +85,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 //     eight times; bands of 8 left 2 of 10 row tiles at 640 rows to the last XCDs, which pulled two thirds of the weight matrix each);
 //     more row tiles are cut into equal bands of at most 8.
 //   * split-K: with S | 8 slices, XCD x works on slice x % S only (S = 8: every XCD streams ITS eighth of K of both operands, once).
-__device__ __forceinline__ void tile_of(int b, int total, int S, int TM, int TN, int legacy, int& z, int& tm, int& tn) {
+__device__ __forceinline__ void tile_of(int b, int total, int S, int TM, int TN, int& z, int& tm, int& tn) {
     int t;
-    if (S > 1 && (8 % S) == 0 && !legacy) {
+    if (S > 1 && (8 % S) == 0) {
         const int xcd = b & 7, G = 8 / S, xg = xcd / S;
         z = xcd - xg * S;
         const int q = total / G, r = total - q * G;
@@ -98,11 +98,8 @@ __device__ __forceinline__ void tile_of(int b, int total, int S, int TM, int TN,
         const int q = total >> 3, r = total & 7, xcd = id & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
     }
-    int GM = 8;
-    if (!legacy) {
-        const int nb = TM <= 12 ? 1 : (TM + 7) >> 3;
-        GM = (TM + nb - 1) / nb;
-    }
+    const int nb = TM <= 12 ? 1 : (TM + 7) >> 3;
+    const int GM = (TM + nb - 1) / nb;
     const int per_group = GM * TN;
     const int group = t / per_group, in_group = t - group * per_group;
     const int first = group * GM, rows = min(TM - first, GM);
@@ -129,7 +126,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     const int total = TM * TN;
     const int S = gridDim.x / total;
     int z, tile_m, tile_n;                                                        // z: split-K slice (TS_SLAB)
-    tile_of(blockIdx.x, total, S, TM, TN, g.tile_panel, z, tile_m, tile_n);
+    tile_of(blockIdx.x, total, S, TM, TN, z, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int MB = g.a_packed_mb, KS = g.K >> 4, NTILES = g.N >> 5;
     const int ks_lo = (int)(((long long)KS * z) / S), ks_hi = (int)(((long long)KS * (z + 1)) / S);
@@ -602,9 +599,8 @@ bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
     if (g.store == STORE_QKV) return c_dt == DT_BF16 && g.qkv_D % 128 == 0 && g.rows_per_group > 0;
     if (g.store == STORE_PACKED) return c_dt == DT_BF16 && g.c_packed_mb > 0;
     // (proj, K = D: one short K loop over 48 column-tile rows.  Below 640 rows the streaming kernel's 64-row tiles win (23.5 vs 25.2 us at 512 rows); from 640
-    //  rows the 8-wave 64 x 128 tiles do (27.8 -> 24.9 us at 640, 30.0 -> 26.8 at 768, 37.5 -> 29.3 at 1024; HQT_TILE_W8_RESID=0: round 3's choice))
-    static const int w8r = getenv("HQT_TILE_W8_RESID") ? atoi(getenv("HQT_TILE_W8_RESID")) : 1;
-    if (g.store == STORE_RESID) return c_dt == DT_F32 && g.c_packed_mb > 0 && !g.ln_parts && g.resid_pk && g.resid_parts && g.N == g.ldc && (g.K >= 3072 || g.M >= (w8r ? 640 : 1024));
+    //  rows the 8-wave 64 x 128 tiles do (27.8 -> 24.9 us at 640, 30.0 -> 26.8 at 768, 37.5 -> 29.3 at 1024))
+    if (g.store == STORE_RESID) return c_dt == DT_F32 && g.c_packed_mb > 0 && !g.ln_parts && g.resid_pk && g.resid_parts && g.N == g.ldc && (g.K >= 3072 || g.M >= 640);
     if (g.store == STORE_ROWS) return g.rows_per_group == 0;
     return false;
 }
@@ -613,22 +609,18 @@ bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
 // slots empty; the slices leave fp32 slabs that resid_combine_kernel finishes (one extra launch: not worth it at K = D).
 TilePlan tile_gemm_plan(const GemmArgs& g) {
     constexpr int max_s = 8;
-    static const int max_geom = getenv("HQT_TILE_GEOM") ? atoi(getenv("HQT_TILE_GEOM")) : 1;         // A/B runs: 0 = 128 x 128 tiles only
-    static const int w8 = getenv("HQT_TILE_W8") ? atoi(getenv("HQT_TILE_W8")) : 1;                   // A/B runs: 0 = 4-wave 64 x 128 tiles
     TilePlan p{0, Tile128::BM, Tile128::BN, 1};
     const int KS = g.K / 16, tiles = ((g.M + p.bm - 1) / p.bm) * (g.N / p.bn);
     // the narrow residual producer (proj: N = K = D) at the driver's 640 rows: 240 tiles of 64 x 64 (4 waves, three workgroups per CU) instead of 120 of 64 x 128 --
-    // every CU gets one, half the matrix work per workgroup: 18.9 -> 16.5 ms per pass (1024 rows: 384 such tiles lose to 192 of 64 x 128, 21.4 vs 19.4).  HQT_TILE_64X64=0: off
-    static const int x64 = getenv("HQT_TILE_64X64") ? atoi(getenv("HQT_TILE_64X64")) : 1;
-    if (x64 && g.store == STORE_RESID && g.K < 3072 && ((g.M + 63) / 64) * (g.N / 64) <= 256 && KS % Tile64x64::KU == 0 && KS / Tile64x64::KU >= 2 * Tile64x64::NSTAGE)
+    // every CU gets one, half the matrix work per workgroup: 18.9 -> 16.5 ms per pass (1024 rows: 384 such tiles lose to 192 of 64 x 128, 21.4 vs 19.4)
+    if (g.store == STORE_RESID && g.K < 3072 && ((g.M + 63) / 64) * (g.N / 64) <= 256 && KS % Tile64x64::KU == 0 && KS / Tile64x64::KU >= 2 * Tile64x64::NSTAGE)
         return TilePlan{3, 64, 64, 1};
-    if (max_geom >= 1 && g.store != STORE_RESID && tiles < 256 && KS / Tile64::KU >= Tile64::NSTAGE) {
+    if (g.store != STORE_RESID && tiles < 256 && KS / Tile64::KU >= Tile64::NSTAGE) {
         const int t64 = ((g.M + Tile64::BM - 1) / Tile64::BM) * (g.N / Tile64::BN);
-        if (w8 && t64 <= 512 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE) return TilePlan{2, Tile64::BM, Tile64::BN, 1};
+        if (t64 <= 512 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE) return TilePlan{2, Tile64::BM, Tile64::BN, 1};
         return TilePlan{1, Tile64::BM, Tile64::BN, 1};
     }
-    static const int w8r = getenv("HQT_TILE_W8_RESID") ? atoi(getenv("HQT_TILE_W8_RESID")) : 1;      // the narrow residual producer (proj) on 8-wave 64 x 128 tiles
-    if (w8r && g.store == STORE_RESID && g.K < 3072 && tiles < 256 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
+    if (g.store == STORE_RESID && g.K < 3072 && tiles < 256 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
         return TilePlan{2, Tile64::BM, Tile64::BN, 1};
     if (g.store == STORE_RESID && g.K >= 3072 && tiles < 256) {
         // The wide-K residual producer (fc2).  Measured per (geometry, S) at the row counts the schedules produce (profiles/r04_fc2_plans.txt; GEMM + combine,
@@ -636,19 +628,10 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
         //   * 8-wave 64 x 128 tiles without split-K when they fill the chip evenly (at most one or close to two per CU): 1024 rows 53.4 -> 47.5, 2560 rows 20.2 -> 18.4;
         //   * S = 4 when 4 x tiles is one round or a whole number of rounds: 512 rows 36.4 -> 34.7, 640 rows 38.0 -> 35.9, 2048 rows 80.9 -> 74.0 (was S = 8 / 8 / 3);
         //   * else the largest S that keeps the grid under 2.25 rounds.
-        static const char* force = getenv("HQT_TILE_SPLITK_PLAN");            // experiment: "geom,S"
-        if (force) {
-            int fg = 0, fs = 0;
-            if (sscanf(force, "%d,%d", &fg, &fs) == 2 && fs >= 1 && fs <= max_s) {
-                const int ku = fg == 0 ? Tile128::KU : Tile64W8::KU, ns = fg == 0 ? Tile128::NSTAGE : Tile64W8::NSTAGE;
-                if (KS % (ku * fs) == 0 && KS / fs / ku >= 2 * ns) return TilePlan{fg, fg == 0 ? Tile128::BM : Tile64::BM, fg == 0 ? Tile128::BN : Tile64::BN, fs};
-            }
-        }
-        static const int tuned = getenv("HQT_TILE_FC2_PLAN") ? atoi(getenv("HQT_TILE_FC2_PLAN")) : 1;      // A/B switch: 0 = round 3's rule
         const int t64 = ((g.M + Tile64::BM - 1) / Tile64::BM) * (g.N / Tile64::BN);
-        if (tuned && w8 && ((t64 >= 176 && t64 <= 208) || (t64 >= 448 && t64 <= 512)) && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
+        if (((t64 >= 176 && t64 <= 208) || (t64 >= 448 && t64 <= 512)) && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
             return TilePlan{2, Tile64::BM, Tile64::BN, 1};
-        if (tuned && (tiles * 4 <= 256 || tiles % 64 == 0) && KS % (Tile128::KU * 4) == 0 && KS / 4 / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = 4; return p; }
+        if ((tiles * 4 <= 256 || tiles % 64 == 0) && KS % (Tile128::KU * 4) == 0 && KS / 4 / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = 4; return p; }
         for (int S : {8, 6, 4, 3, 2})
             if (S <= max_s && tiles * S <= 576 && KS % (Tile128::KU * S) == 0 && KS / S / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = S; break; }
     }
@@ -657,9 +640,7 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
 
 hipError_t launch_tile_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, const TilePlan& p, float* slabs, hipStream_t st) {
     (void)a_dt;
-    static const int legacy_order = getenv("HQT_TILE_ORDER") && atoi(getenv("HQT_TILE_ORDER")) == 0;    // A/B switch: bands of 8 row tiles, split-K slices spread over all XCDs
-    GemmArgs gg = g;
-    gg.tile_panel = legacy_order;
+    const GemmArgs& gg = g;
     if (p.geom == 0) return launch_tile_g<Tile128>(gg, wpk, c_dt, p.S, slabs, st);
     if (p.geom == 1) return launch_tile_g<Tile64>(gg, wpk, c_dt, p.S, slabs, st);
     if (p.geom == 2) return launch_tile_g<Tile64W8>(gg, wpk, c_dt, p.S, slabs, st);

@@ -345,3 +345,52 @@ def test_merged_steps_reject_a_mismatched_step_without_losing_the_queue(model):
     torch.cuda.synchronize()
     alone = sampling_ihqgpt(model.stage2, 2, 3, use_fp16=False, is_tqdm=False, max_seq_len=64, seed=1, given_top_code=given.clone())
     assert (x.get()[0] == alone[0]).all() and (x.get()[1] == alone[1]).all() and tuple(y.get()[0].shape) == (2, 64)
+
+
+def test_measure_throughput_txt_counterpart(capsys, tmp_path):
+    """measure_throughput_txt counterpart (measure_throughput_txt/__main__.py:83-188) on the tiny text-conditional config: synthetic
+    prompts, the harness's quality-mode sampler (top-k clipped to the vocabulary, top-p 1.0), H1's loop accounting and printed lines;
+    then real captions through the BPE front-end, several iterations in flight, and the refusal of a class-conditional config."""
+    import json
+    from hqtransformer_amd import measure_throughput_txt as mtt
+    tiny_txt = os.path.join(ROOT, 'configs', 'tiny-txt.yaml')
+    out = mtt.main(parse_dotlist([f'model_path={tiny_txt}', 'batch_size=500', 'n_loop=2', 'warmup=1', 'top_k=100'], mtt.EXPERIMENT_DEFAULTS))
+    text = capsys.readouterr().out
+    assert 'bs500, sampling loops 2-2' in text and 'transformer size:' in text and 'ms/sample (ar:' in text
+    assert out['ms_per_sample'] > 0 and abs(out['ms_ar'] + out['ms_decode'] - out['ms_per_sample']) / out['ms_per_sample'] < 0.2
+    vocab = {'[UNK]': 0, 'a</w>': 1, 'c': 2, 'a': 3, 't</w>': 4, 'ca': 5, 'cat</w>': 6, 'd': 7, 'o': 8, 'g</w>': 9, 'do': 10, 'dog</w>': 11}
+    (tmp_path / 'v.json').write_text(json.dumps(vocab))
+    (tmp_path / 'm.txt').write_text('#version: 0.2\nc a\nca t</w>\nd o\ndo g</w>\n')
+    (tmp_path / 'caps.txt').write_text('x.jpg\ta cat\ny.jpg\ta dog\n')
+    out2 = mtt.main(parse_dotlist([f'model_path={tiny_txt}', 'batch_size=250', 'n_loop=2', 'warmup=1', 'top_k=100', 'inflight=2',
+                                   f'captions={tmp_path / "caps.txt"}', f'tokenizer_vocab={tmp_path / "v.json"}', f'tokenizer_merges={tmp_path / "m.txt"}'],
+                                  mtt.EXPERIMENT_DEFAULTS))
+    assert 'bs250, sampling loops 2-2' in capsys.readouterr().out and out2['ms_per_sample'] > 0
+    with pytest.raises(ValueError):
+        mtt.main(parse_dotlist([f'model_path={TINY}', 'batch_size=50', 'n_loop=1', 'warmup=0'], mtt.EXPERIMENT_DEFAULTS))
+
+
+def test_reference_token_ids_through_the_text_conditional_sampler():
+    """Fixture G10 holds the ids the REFERENCE's tokenizer + dataset padding / truncation produced for 20 captions (64-token form,
+    16k vocabulary, incl. an empty and an over-long caption).  Those ids -- not a vocabulary file -- go through sampling_ihqgpt on a tiny
+    model with the released text front-end's geometry (vocab_size_txt 16384, ctx_len_txt 64): the 64-row causal prefill and 8 decode
+    steps in EXACT arithmetic draw bit-identical codes to the CPU oracle on the same ids, and FAST stays within its logits gate."""
+    from tests.helpers import gate, load
+    fx = load('g10_tokenizer.npz')
+    ids = fx['ids_64'].astype(np.int64)
+    assert ids.shape == (20, 64) and ids.max() < 16384
+    m = ImageGPT2(load_config(os.path.join(ROOT, 'configs', 'tiny-txt-bpe16k.yaml')), seed=7).to('cuda').eval()
+    s2 = m.stage2.spec
+    assert (s2.vocab_txt, s2.ctx_len_txt) == (16384, 64)
+    w2 = {k: v.numpy() for k, v in m.stage2.state_dict().items()}
+    B, n = ids.shape[0], 8
+    noise = synth.exp_noise(5, n, B, s2.vocab_top)
+    ct, cb = sampling_ihqgpt(m.stage2, num_candidates=1, cond=torch.from_numpy(ids), use_fp16=False, is_tqdm=False, max_seq_len=n,
+                             noise=torch.from_numpy(noise))
+    want = O.OracleStage2(s2, w2).sample(ids, B, n, noise, return_logits=True)
+    assert (ct.cpu().numpy() == want[0]).all() and (cb.cpu().numpy() == want[1]).all()
+    assert (want[0][0] != want[0][1]).any()                      # two different captions do not draw the same codes
+    eng = m.stage2.engine(B, n)
+    _, _, lf = eng.sample(B, torch.from_numpy(ids), n, precision=1, noise=torch.from_numpy(noise), force_top=torch.from_numpy(want[0]),
+                          force_bot=torch.from_numpy(want[1]), return_logits=True, use_graph=True)
+    gate('g10_ids.fast_logits_vs_oracle', np.abs(lf.cpu().numpy() - want[2]).max(), 0.15)

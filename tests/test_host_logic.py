@@ -154,3 +154,31 @@ def test_released_configs_match_the_reference_state_dict(name):
     n = sum(int(np.prod(v)) for v in got.values())
     unused = sum(int(np.prod(want['shapes'][k])) for k in ignore)
     assert n + unused == want['n_params']
+
+
+def test_measure_throughput_txt_host_logic(tmp_path):
+    """measure_throughput_txt counterpart, host side (no GPU): the reference's loop count (measure_throughput_txt/__main__.py:103), its
+    Experiment keys, synthetic prompt batches inside the text vocabulary, and captions cycled through the BPE front-end."""
+    import json
+    from types import SimpleNamespace
+    from hqtransformer_amd import measure_throughput_txt as mtt
+    from hqtransformer_amd.config import parse_dotlist
+    assert mtt.iterations_per_loop(50) == 20 and mtt.iterations_per_loop(64) == 16 and mtt.iterations_per_loop(1000) == 1
+    args = parse_dotlist(['batch_size=8', 'top_resolution=8', 'dataset=cc3m'], mtt.EXPERIMENT_DEFAULTS)
+    assert (args.batch_size, args.n_loop, args.warmup, args.top_k, args.top_p) == (8, 6, 1, 2048, 1.0)       # the reference's defaults
+    spec = SimpleNamespace(ctx_len_txt=16, vocab_txt=300)
+    gen = mtt.prompt_batches(args, spec)
+    a, b = next(gen), next(gen)
+    assert a.dtype.is_floating_point is False and tuple(a.shape) == (8, 16) and int(a.min()) >= 0 and int(a.max()) < 300 and not (a == b).all()
+    vocab = {'[UNK]': 0, 'a</w>': 1, 'c': 2, 'a': 3, 't</w>': 4, 'ca': 5, 'cat</w>': 6, 'd': 7, 'o': 8, 'g</w>': 9, 'do': 10, 'dog</w>': 11}
+    (tmp_path / 'v.json').write_text(json.dumps(vocab))
+    (tmp_path / 'm.txt').write_text('#version: 0.2\nc a\nca t</w>\nd o\ndo g</w>\n')
+    (tmp_path / 'caps.txt').write_text('x.jpg\ta cat\ny.jpg\ta dog\nz.jpg\ta cat a dog\n')
+    args = parse_dotlist(['batch_size=4', f'captions={tmp_path / "caps.txt"}', f'tokenizer_vocab={tmp_path / "v.json"}',
+                          f'tokenizer_merges={tmp_path / "m.txt"}'], mtt.EXPERIMENT_DEFAULTS)
+    gen = mtt.prompt_batches(args, spec)
+    c, d = next(gen), next(gen)
+    assert tuple(c.shape) == (4, 16) and (c[0] == c[3]).all() and (d[0] == c[1]).all()        # 3 captions cycled over batches of 4
+    import pytest
+    with pytest.raises(ValueError):
+        next(mtt.prompt_batches(parse_dotlist([f'captions={tmp_path / "caps.txt"}'], mtt.EXPERIMENT_DEFAULTS), spec))

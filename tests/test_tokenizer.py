@@ -15,6 +15,15 @@ from tests.helpers import load
 REF = os.environ.get('HQT_REFERENCE', '/root/reference')
 
 
+def vocab_pair():
+    """HQT_BPE16K_VOCAB / HQT_BPE16K_MERGES name the two files directly (any host that has them: the test then RUNS, and fails if they are
+    unreadable); otherwise the reference checkout under HQT_REFERENCE or /root/reference; None = neither is present."""
+    v, m = os.environ.get('HQT_BPE16K_VOCAB'), os.environ.get('HQT_BPE16K_MERGES')
+    if v or m:
+        return (v or '', m or '')
+    return text.find_reference_vocab(REF)
+
+
 def test_fixture_is_self_consistent():
     fx = load('g10_tokenizer.npz')
     caps = [str(c) for c in fx['captions']]
@@ -28,10 +37,11 @@ def test_fixture_is_self_consistent():
     assert (fx['ids_64'][:, :32] == fx['ids_32'])[fx['ids_32'][:, -1] == int(fx['pad_id_32'])].all()   # short captions: the 32-id form is a prefix
 
 
-@pytest.mark.skipif(text.find_reference_vocab(REF) is None, reason='the reference checkout (bpe-16k vocabulary) is not present')
+@pytest.mark.skipif(vocab_pair() is None, reason='neither HQT_BPE16K_VOCAB / HQT_BPE16K_MERGES nor a reference checkout (bpe-16k vocabulary) is present')
 def test_build_tokenizer_reproduces_the_reference_ids():
     fx = load('g10_tokenizer.npz')
-    vocab, merges = text.find_reference_vocab(REF)
+    vocab, merges = vocab_pair()
+    assert os.path.isfile(vocab) and os.path.isfile(merges), f'the vocabulary files named by the environment do not exist: {vocab!r}, {merges!r}'
     caps = [str(c) for c in fx['captions']]
     for ctx in (64, 32):
         tok = text.build_tokenizer(vocab, merges, context_length=ctx)

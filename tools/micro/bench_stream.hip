@@ -35,35 +35,6 @@ static float run(const Shape& sh, int M, int S, const std::vector<bf16_t*>& wbuf
     return 1000.f * ms / (3 * iters);
 }
 
-// the same chain with the ninth (prefetch) wave: launch i warms L2 with the weights of launch i + 1
-template <int MBW, int NT, int NW, int U>
-static float run_pf(const Shape& sh, int M, const std::vector<bf16_t*>& wbufs, bf16_t* x, float* y, hipStream_t st, bool prefetch) {
-    const int MB = packed_mb(M);
-    const size_t smem = stream_gemm_lds(MBW, NT, NW);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_gemm_kernel<MBW, NT, NW, U, float, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    GemmArgs g{};
-    g.A = x; g.a_packed_mb = MB; g.M = M; g.N = sh.N; g.K = sh.K; g.batch = 1; g.C = y; g.ldc = sh.N; g.alpha = 1.f; g.store = STORE_ROWS;
-    const dim3 grid(sh.N / (32 * NT), MB / MBW, 1);
-    const int iters = (int)wbufs.size();
-    hipGraph_t graph; hipGraphExec_t ge;
-    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < iters; ++i) {
-        GemmArgs gi = g;
-        if (prefetch) { gi.pf_w = wbufs[(i + 1) % iters]; gi.pf_bytes = (unsigned)((size_t)sh.N * sh.K * 2); gi.pf_slice = (unsigned)sh.K * 64; }
-        stream_gemm_kernel<MBW, NT, NW, U, float, 0, false, true><<<grid, (NW + 1) * 64, smem, st>>>(gi, reinterpret_cast<const u32x4*>(wbufs[i]), nullptr);
-    }
-    CK(hipStreamEndCapture(st, &graph));
-    CK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
-    CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
-    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    CK(hipEventRecord(a, st));
-    for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, st));
-    CK(hipEventRecord(b, st)); CK(hipStreamSynchronize(st));
-    float ms; CK(hipEventElapsedTime(&ms, a, b));
-    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(graph));
-    return 1000.f * ms / (3 * iters);
-}
-
 template <int MBW, int NT, int NW, int U, bool PIPE = false>
 static void stamps(const Shape& sh, int M, int S, bf16_t* w, bf16_t* x, float* y, float* slabs, hipStream_t st) {
     const int MB = packed_mb(M);
@@ -112,9 +83,6 @@ int main() {
                 const float c1 = run<2, 1, 8, 12>(sh, M, 1, w, x, y, slabs, st), h1 = run<2, 1, 8, 12>(sh, M, 1, same, x, y, slabs, st);
                 const float c2 = run<1, 1, 8, 12>(sh, M, 1, w, x, y, slabs, st), h2 = run<1, 1, 8, 12>(sh, M, 1, same, x, y, slabs, st);
                 const float c3 = run<2, 1, 8, 6>(sh, M, 1, w, x, y, slabs, st), h3 = run<2, 1, 8, 6>(sh, M, 1, same, x, y, slabs, st);
-                printf("   ninth wave: <2,1,8,6> cold %.2f us, cold + prefetch of the next launch's weights %.2f us; <1,1,8,12> %.2f -> %.2f us\n",
-                       run_pf<2, 1, 8, 6>(sh, M, w, x, y, st, false), run_pf<2, 1, 8, 6>(sh, M, w, x, y, st, true),
-                       run_pf<1, 1, 8, 12>(sh, M, w, x, y, st, false), run_pf<1, 1, 8, 12>(sh, M, w, x, y, st, true));
                 printf("   cold -> warm weights: <2,1,8,12> %.2f -> %.2f us, <1,1,8,12> %.2f -> %.2f us, <2,1,8,6> %.2f -> %.2f us\n", c1, h1, c2, h2, c3, h3);
             }
             if (M == 64 && false) {} if (M == 64) { V(2, 1, 8, 12, 1) V(1, 1, 8, 12, 1) V(1, 1, 16, 12, 1) V(1, 1, 16, 6, 1) V(2, 1, 16, 6, 1) V(2, 1, 16, 4, 1) V(1, 1, 8, 6, 1) V(2, 1, 8, 4, 1) }
