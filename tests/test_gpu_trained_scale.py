@@ -1,0 +1,144 @@
+"""Parity at the scale of trained checkpoints ("every full-size check uses random-init weights").
+
+Released checkpoints cannot be fetched offline; hqtransformer_amd.synth's 'trained' profile draws what they have and random initialisation
+lacks: LayerNorm / GroupNorm gains spread around 1 with outlier channels, non-zero shifts and biases, a residual stream ~20x its input,
+logits of std 3-4, decoder activations of |x| ~ 1e2.  Fixture G12 (tools/gen_golden_trained.py, the REFERENCE on such weights) pins
+the oracle there; these tests hold the GPU paths to the same bars at that scale: EXACT / SPLIT codes bit-identical and pixels within
+1e-4, FAST inside gates set at about twice the measured figures (profiles/r05_fast_gates.txt)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hqtransformer_amd import synth
+from hqtransformer_amd._lib import PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT
+from hqtransformer_amd.engine import Engine
+from hqtransformer_amd.spec import Stage1Spec, Stage2Spec
+from oracle import hqt_oracle as O
+from tests.helpers import gate, load
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOGIT_TOL = 2e-4
+PIXEL_TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def engine(s2=None, w2=None, s1=None, w1=None, max_batch=8, max_steps=None):
+    e = Engine(s2, s1, dev(), max_batch, max_steps or (s2.ctx_len_img if s2 else 64))
+    e.load(stage2=w2, stage1=w1)
+    e.finalize()
+    return e
+
+
+def test_g12_reference_fixture_on_the_gpu():
+    """G12 itself: EXACT and SPLIT draw the reference's codes bit for bit (logits within 2e-4), FAST teacher-forced within its gate; the
+    64-pixel decode within 1e-4 in EXACT and SPLIT."""
+    fx = load('g12_trained.npz')
+    s2, s1 = Stage2Spec(**json.loads(str(fx['spec2']))), Stage1Spec(**json.loads(str(fx['spec1'])))
+    w2 = synth.stage2_weights(s2, int(fx['weight_seed2']), 'trained')
+    w1 = synth.stage1_weights(s1, int(fx['weight_seed1']), 'trained')
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = torch.from_numpy(synth.exp_noise(int(fx['noise_seed']), n, B, s2.vocab_top))
+    eng = engine(s2, w2, s1, w1, max_batch=B, max_steps=n)
+    for prec in (PRECISION_EXACT, PRECISION_SPLIT):
+        for graph in (False, True):
+            ct, cb, lg = eng.sample(B, torch.full((B,), 7), n, precision=prec, noise=noise, return_logits=True, use_graph=graph)
+            assert (np_(ct) == fx['codes_top']).all() and (np_(cb) == fx['codes_bot']).all(), (prec, graph)
+            assert np.abs(np_(lg) - fx['logits']).max() <= LOGIT_TOL, (prec, np.abs(np_(lg) - fx['logits']).max())
+    _, _, lf = eng.sample(B, torch.full((B,), 7), n, precision=PRECISION_FAST, noise=noise, force_top=torch.from_numpy(fx['codes_top'].copy()),
+                          force_bot=torch.from_numpy(fx['codes_bot'].copy()), return_logits=True, use_graph=True)
+    gate('trained.g12.fast_logits', np.abs(np_(lf) - fx['logits']).max(), 0.45)         # logits of std 3.6 behind a 20x residual stream; measured 0.21
+    tct, tcb = torch.from_numpy(fx['code_t']), torch.from_numpy(fx['code_b'])
+    for prec in (PRECISION_EXACT, PRECISION_SPLIT):
+        px = np_(eng.decode(tct, tcb, precision=prec))
+        assert np.abs(px - fx['pixels']).max() <= PIXEL_TOL, (prec, np.abs(px - fx['pixels']).max())
+    d = np.abs(np_(eng.decode(tct, tcb, precision=PRECISION_FAST)) - fx['pixels'])
+    gate('trained.g12.fast_pixels.max', d.max(), 0.05)                # measured 0.022
+    eng.range_check()
+
+
+def imagenet_specs():
+    from hqtransformer_amd.config import load_config
+    from hqtransformer_amd.spec import stage1_spec_from_config, stage2_spec_from_config
+    cfg = load_config(os.path.join(ROOT, 'configs', 'imagenet-12l.yaml'))
+    return stage2_spec_from_config(cfg), stage1_spec_from_config(cfg)
+
+
+def test_imagenet_model_trained_scale_vs_oracle():
+    """The benchmark's 12 + 4-layer model (D = 1536) with 'trained' weights, B = 8, three positions: EXACT and SPLIT codes bit-identical to the
+    oracle and logits within 2e-4 (logits of std 3.7 against 0.8 of the 'bench' weights; measured 3.4e-5); FAST teacher-forced: logits, KL and the
+    share of identical draws gated at about twice the measured figures."""
+    s2, _ = imagenet_specs()
+    w2 = synth.stage2_weights(s2, 0, 'trained')
+    B, n = 8, 3
+    noise = synth.exp_noise(4, n, B, s2.vocab_top)
+    cond = synth.class_ids(5, B, s2.n_classes)
+    want = O.OracleStage2(s2, w2).sample(cond, B, n, noise, return_logits=True)
+    eng = engine(s2, w2, max_batch=B, max_steps=8)
+    tn, tc = torch.from_numpy(noise), torch.from_numpy(cond)
+    for name, prec in (('exact', PRECISION_EXACT), ('split', PRECISION_SPLIT)):
+        ct, cb, lg = eng.sample(B, tc, n, precision=prec, noise=tn, return_logits=True, use_graph=False)
+        err = np.abs(np_(lg) - want[2]).max()
+        gate(f'trained.imagenet.{name}_logits_vs_oracle', err, LOGIT_TOL)      # the bar of the unit-scale tests holds here too: measured 3.4e-5
+        assert (np_(ct) == want[0]).all() and (np_(cb) == want[1]).all(), f'{name} codes differ from the oracle at trained scale'
+    _, _, lf = eng.sample(B, tc, n, precision=PRECISION_FAST, noise=tn, force_top=torch.from_numpy(want[0]), force_bot=torch.from_numpy(want[1]),
+                          return_logits=True, use_graph=True)
+    le, lf = want[2].astype(np.float64), np_(lf).astype(np.float64)
+    gate('trained.imagenet.logit_std', want[2].std(), 2.0, '>=')
+    gate('trained.imagenet.fast_logits', np.abs(le - lf).max(), 0.35)             # measured 0.174 on logits of std 3.7 (bench weights: 0.028 on std 0.8)
+    pe = np.exp(le - le.max(-1, keepdims=True)); pe /= pe.sum(-1, keepdims=True)
+    pf = np.exp(lf - lf.max(-1, keepdims=True)); pf /= pf.sum(-1, keepdims=True)
+    kl = (pe * (np.log(np.maximum(pe, 1e-300)) - np.log(np.maximum(pf, 1e-300)))).sum(-1)
+    gate('trained.imagenet.fast_kl_max', kl.max(), 3e-3)                         # measured 1.2e-3 nats
+    q = noise.astype(np.float64)
+    gate('trained.imagenet.fast_identical_draws', (np.argmax(pe / q, -1) == np.argmax(pf / q, -1)).mean(), 0.97, '>=')   # measured 0.992
+    eng.range_check()
+
+
+def test_imagenet_merged_pass_split_trained_scale():
+    """A 320-sample pass (1280 rows in depth sub-step 1: the fp16 hi / lo GEMMs of SPLIT, not the fp32 matrix instructions) with 'trained'
+    weights: SPLIT draws EXACT's codes (>= 99.9 %: a draw decided by the last fp32 bit may differ) and its logits stay within 2e-4; no
+    activation leaves the fp16 range."""
+    s2, _ = imagenet_specs()
+    w2 = synth.stage2_weights(s2, 0, 'trained')
+    B, n = 320, 2
+    eng = engine(s2, w2, max_batch=B, max_steps=8)
+    noise = torch.from_numpy(synth.exp_noise(6, n, B, s2.vocab_top))
+    cond = torch.from_numpy(synth.class_ids(7, B, s2.n_classes))
+    ct, cb, le = eng.sample(B, cond, n, precision=PRECISION_EXACT, noise=noise, return_logits=True, use_graph=False)
+    st, sb, ls = eng.sample(B, cond, n, precision=PRECISION_SPLIT, noise=noise, force_top=ct, force_bot=cb, return_logits=True, use_graph=False)
+    eng.range_check()
+    gate('trained.imagenet_rows320.split_logits_vs_exact', (ls - le).abs().max().item(), LOGIT_TOL)     # measured 4.3e-5
+    agree = ((st == ct).float().mean().item() + (sb == cb).float().mean().item()) / 2
+    gate('trained.imagenet_rows320.split_code_agreement', agree, 0.999, '>=')
+
+
+def test_imagenet_decoder_trained_scale_vs_oracle():
+    """The benchmark's decoder (53.95 M parameters, 256 x 256) with 'trained' weights -- GroupNorm gains with outliers, activations up to
+    ~240, pixels spanning [-0.7, 0.9] -- on 2 images against the CPU oracle: EXACT and SPLIT within north_star's 1e-4, FAST gated."""
+    _, s1 = imagenet_specs()
+    w1 = synth.stage1_weights(s1, 0, 'trained')
+    r = np.random.default_rng(1)
+    ct, cb = r.integers(0, s1.n_embed, (2, 8, 8)), r.integers(0, s1.n_embed, (2, 16, 16))
+    want = O.OracleStage1(s1, w1).decode_code(ct, cb)
+    eng = engine(s1=s1, w1=w1, max_batch=2)
+    tct, tcb = torch.from_numpy(ct), torch.from_numpy(cb)
+    for name, prec in (('exact', PRECISION_EXACT), ('split', PRECISION_SPLIT)):
+        err = np.abs(np_(eng.decode(tct, tcb, precision=prec)) - want).max()
+        gate(f'trained.decoder.{name}_pixels', err, PIXEL_TOL)
+    eng.range_check()
+    d = np.abs(np_(eng.decode(tct, tcb, precision=PRECISION_FAST)) - want)
+    gate('trained.decoder.pixel_span', want.max() - want.min(), 1.0, '>=')
+    gate('trained.decoder.fast_pixels.max', d.max(), 0.05)           # measured 0.022
+    gate('trained.decoder.fast_pixels.mean', d.mean(), 6e-3)         # measured 0.0024

@@ -245,3 +245,28 @@ def test_encode_side_vs_reference(name):
     # decode(encode(x)) closes the loop through the decode-side oracle
     rec = orc.decode_codes3(out['codes']) if L == 3 else orc.decode_code(out['codes'][0], out['codes'][1])
     assert np.abs(rec - fx['reconstruction']).max() <= 1e-4
+
+
+# ----------------------------------------------------------------------------------------- G12: trained-like statistics
+def _g12():
+    from hqtransformer_amd.spec import Stage1Spec, Stage2Spec
+    fx = load('g12_trained.npz')
+    s2 = Stage2Spec(**json.loads(str(fx['spec2'])))
+    s1 = Stage1Spec(**json.loads(str(fx['spec1'])))
+    return fx, s2, synth.stage2_weights(s2, int(fx['weight_seed2']), 'trained'), s1, synth.stage1_weights(s1, int(fx['weight_seed1']), 'trained')
+
+
+def test_trained_profile_oracle_vs_reference():
+    """Fixture G12 (tools/gen_golden_trained.py): the REFERENCE on weights with trained-like statistics -- LayerNorm / GroupNorm gains with
+    outlier channels, a residual stream ~20x its input (largest block output 20.8), logits of std 3.6, decoder activations up to 77 -- pins
+    the oracle at the scale of real checkpoints: codes bit-exact, logits within the 2e-4 bar of the unit-scale fixtures (measured 2.0e-5),
+    pixels within north_star's 1e-4 (measured 2.8e-6)."""
+    fx, s2, w2, s1, w1 = _g12()
+    assert float(fx['stream_max']) > 15 and float(fx['act_max']) > 50 and float(fx['margin']) > 1.00005
+    B, n = int(fx['B']), int(fx['n_steps'])
+    noise = synth.exp_noise(int(fx['noise_seed']), n, B, s2.vocab_top)
+    ct, cb, lg = O.OracleStage2(s2, w2).sample(np.full(B, 7), B, n, noise, return_logits=True)
+    assert (ct == fx['codes_top']).all() and (cb == fx['codes_bot']).all()
+    assert np.abs(lg - fx['logits']).max() <= LOGIT_TOL, np.abs(lg - fx['logits']).max()
+    px = O.OracleStage1(s1, w1).decode_code(fx['code_t'], fx['code_b'])
+    assert np.abs(px - fx['pixels']).max() <= PIXEL_TOL, np.abs(px - fx['pixels']).max()

@@ -69,7 +69,7 @@ class AD(dict):
         return AD(copy.deepcopy(dict(self), memo))
 
 
-def build_stage2(spec: Stage2Spec, seed: int):
+def build_stage2(spec: Stage2Spec, seed: int, profile: str = 'fixture'):
     hp = AD(embed_dim=spec.embed_dim, n_layers=spec.n_layers, n_heads=spec.n_heads, n_dense_layers=spec.n_layers,
             ctx_len=None, ctx_len_img=spec.ctx_len_img, ctx_len_txt=spec.ctx_len_txt, embd_pdrop=0.0,
             resid_pdrop=0.1, attn_pdrop=0.0, mlp_bias=True, attn_bias=True, gelu_use_approx=spec.gelu_approx,
@@ -81,14 +81,14 @@ def build_stage2(spec: Stage2Spec, seed: int):
         hp_dec = copy.deepcopy(hp)
         hp_dec.n_layers = spec.n_layers_depth
     m = iHQGPT(spec.vocab_top, spec.vocab_bot, spec.vocab_txt, 4, spec.cond == 1, spec.cond == 2, 'parallel', hp, hp_dec)
-    sd = {k: torch.from_numpy(v) for k, v in synth.stage2_weights(spec, seed, 'fixture').items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.stage2_weights(spec, seed, profile).items()}
     ref_shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert ref_shapes == {k: tuple(v.shape) for k, v in sd.items()}, 'spec.stage2_param_shapes != reference state_dict'
     m.load_state_dict(sd, strict=True)
     return m.eval(), ref_shapes
 
 
-def build_stage1(spec: Stage1Spec, seed: int):
+def build_stage1(spec: Stage1Spec, seed: int, profile: str = 'fixture'):
     hp = AD(double_z=False, z_channels=spec.z_channels, resolution=spec.resolution, in_channels=3, out_ch=spec.out_ch,
             ch=spec.ch, ch_mult=list(spec.ch_mult), num_res_blocks=spec.num_res_blocks,
             attn_resolutions=list(spec.attn_resolutions), pdrop=0.0, use_init_downsample=spec.use_init_downsample,
@@ -96,7 +96,7 @@ def build_stage1(spec: Stage1Spec, seed: int):
     aux = AD(upsample='pixelshuffle', shared_codebook=False, bottom_start=10 ** 11, decoding_type='concat',
              restart_unused_codes=None, code_levels=None)
     g = SimRQGAN2Generator(spec.n_embed, spec.embed_dim, True, hp, aux)
-    sd = {k: torch.from_numpy(v) for k, v in synth.stage1_weights(spec, seed, 'fixture').items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.stage1_weights(spec, seed, profile).items()}
     ref_shapes = {k: tuple(v.shape) for k, v in g.state_dict().items() if not stage1_is_ignored(k)}
     assert ref_shapes == {k: tuple(v.shape) for k, v in sd.items()}, 'spec.stage1_param_shapes != reference state_dict'
     missing, unexpected = g.load_state_dict(sd, strict=False)
