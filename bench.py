@@ -304,6 +304,11 @@ def main():
         # HQT_BENCH_SHARE_GPU=1 maps the ranks onto the visible devices round-robin and rendezvous runs over gloo
         share = bool(os.environ.get('HQT_BENCH_SHARE_GPU'))
         if share:
+            # several ranks on one device: the persistent AR chain needs every CU of the GPU for its one-workgroup-per-CU grid, and two such
+            # launches from two processes keep each other out (each gives up after 1 s and the call reports it).  One process per GPU -- the
+            # real multi-GPU run -- is unaffected; the shared-device rehearsal takes the launch chain.
+            os.environ['HQT_PERSIST'] = '0'
+        if share:
             local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         if share:
@@ -352,6 +357,26 @@ def main():
             print(f'[bench] rank {rank}: --gather {args.gather} failed in the pre-flight ({type(e).__name__}: {e}); continuing without it', file=sys.stderr)
             args.gather = f'none (requested gather failed: {type(e).__name__})'
 
+    # The gather never rides on a lane's compute stream: the collective is queued on a stream of its own behind an event of the finished
+    # decode, so the lane goes on with its next pass while the pixels travel -- a slow rank-0 receive (7 x 50 MB per step at 8 GPUs) cannot
+    # stall anybody's decode.  Every rank issues its collectives in submission order, i.e. in the same order.
+    s_gather = torch.cuda.Stream(device=dev) if (dist is not None and not str(args.gather).startswith('none')) else None
+
+    def gather_step(ct, px):
+        if s_gather is None:
+            return
+        cur = torch.cuda.current_stream(dev)
+        done = torch.cuda.Event()
+        done.record(cur)
+        s_gather.wait_event(done)
+        with torch.cuda.stream(s_gather):
+            if args.gather == 'pixels':
+                dist.gather(px, gathered, dst=0)
+                px.record_stream(s_gather)
+            elif args.gather == 'codes':
+                dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+                ct.record_stream(s_gather)
+
     three = s2.levels == 3
     samp_kw = (dict(top_k=[tk] * 3, top_p=[tp] * 3, softmax_temperature=[T] * 3) if three else
                dict(top_k_top=tk, top_p_top=tp, top_k_bot=tk, top_p_bot=tp, softmax_temperature=[T, T]))
@@ -388,10 +413,7 @@ def main():
     def step(i, graph=True, nb=None):
         ct, cb = sample_codes(i, graph and not args.no_graph, nb)
         px = decode(ct, cb)
-        if dist is not None and args.gather == 'pixels':
-            dist.gather(px, gathered, dst=0)
-        elif dist is not None and args.gather == 'codes':
-            dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+        gather_step(ct, px)
         return ct, cb, px
 
     def barrier():
@@ -420,10 +442,7 @@ def main():
     pipe = InflightSampler(model, lanes=inflight, device=dev, merge=merge)
 
     def after(ct, cb, px):
-        if dist is not None and args.gather == 'pixels':
-            dist.gather(px, gathered, dst=0)
-        elif dist is not None and args.gather == 'codes':
-            dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+        gather_step(ct, px)
 
     debug_short = n_pos < n_full            # --positions (counter collection): the padded decode of step(), one lane, no pipeline
     for li in range(0 if debug_short else max(inflight, args.warmup) * merge):  # every lane at least once: workspace, graph capture
@@ -495,10 +514,8 @@ def main():
                 s_dec.wait_event(ev[3 * k + 1])
                 px = decode(ct, cb, prec=prec)
                 ev[3 * k + 2].record()
-                if gather and dist is not None and args.gather == 'pixels':
-                    dist.gather(px, gathered, dst=0)
-                elif gather and dist is not None and args.gather == 'codes':
-                    dist.all_gather_into_tensor(torch.empty((world * B, n_pos), dtype=torch.int64, device=dev), ct)
+                if gather:
+                    gather_step(ct, px)
             keep.append((ct, cb, px))
         barrier()
         el = time.perf_counter() - t0
@@ -583,7 +600,7 @@ def main():
                                                          '(the reference harness decodes in fp32, outside autocast)',
                                                 'fast': 'FAST: bf16 MFMA (0.04 max pixel error: NOT the reference harness\'s fp32 decode)',
                                                 'exact': 'EXACT: fp32 FMA chains on the vector ALUs'}[dec_prec]},
-                       'gather': (args.gather + (' (RCCL, every step, inside the timed region)' if args.gather in ('pixels', 'codes') else '')) if dist is not None else 'n/a', 'hip_graph': not args.no_graph,
+                       'gather': (args.gather + (' (RCCL, every step, inside the timed region, on a stream of its own behind an event of the finished decode)' if args.gather in ('pixels', 'codes') else '')) if dist is not None else 'n/a', 'hip_graph': not args.no_graph,
                        'pipeline': (f'{inflight} passes in flight per GPU (round-robin over {inflight} lanes: own HIP stream, KV cache and '
                                     f'activations, shared weights, throughput-oriented GEMM tiles)') if inflight > 1 else 'one pass at a time',
                        'merge': (f'{merge} consecutive batch-{B} steps execute as ONE device pass of {merge * B} rows (own class id, Philox seed and global row indices per step).  In EXACT (fp32) arithmetic '

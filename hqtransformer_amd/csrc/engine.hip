@@ -1154,6 +1154,7 @@ static int run_persist(hqt_handle* h, const SampleCtx& c, const PersistProg& pr,
     static const bool nt = !(getenv("HQT_PERSIST_NT") && atoi(getenv("HQT_PERSIST_NT")) == 0);
     a.nt_weights = nt ? 1 : 0;
     persist_default_fill(a);
+    if (const char* f = getenv("HQT_PERSIST_FAULT")) a.fault = atoi(f);        // test hook: tests/test_gpu_persist.py::test_a_launch_that_cannot_finish_gives_up_and_says_so
     HIPCHK(launch_persist(a, h->ncu, c.st));
     h->persist_used = true;
     count_variant(h, "variant:%s", slot);
@@ -2038,7 +2039,7 @@ extern "C" int hqt_range_check(hqt_handle* h, void* stream) {
         h->persist_used = false;
         if (pe) {
             HIPCHK(hipMemset(h->persist_err, 0, sizeof pe));
-            return fail(HQT_ERR_STATE, "a persistent AR launch on this handle gave up at the grid barrier in front of phase %u (its workgroups were not all resident within 2 s): "
+            return fail(HQT_ERR_STATE, "a persistent AR launch on this handle gave up at the grid barrier in front of phase %u (its workgroups were not all resident within 1 s: the GPU is shared with a process or stream that keeps compute units busy): "
                                        "the codes of that call are invalid; repeat it, or set HQT_PERSIST=0", pe - 1);
         }
     }

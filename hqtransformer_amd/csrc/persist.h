@@ -55,6 +55,7 @@ struct PersistArgs {
     int write_back;
     int nt_weights;                         // non-temporal weight DMA
     int fill_s1, fill_s3;                   // loader budgets (1-KiB pieces) behind the barriers S1 / S3 of a phase (persist_default_fill)
+    int fault;                              // test hook (HQT_PERSIST_FAULT=c+1): CU c never signals its first phase, so every other CU runs into the time limit
     long long* stamps;                      // tools/micro only: [ncu][n_phases][8] wall-clock stamps of wave 0 (NULL in the product)
 };
 

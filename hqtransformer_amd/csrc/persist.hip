@@ -38,7 +38,7 @@ constexpr int CB_OFF = XS_OFF + 64 * 8 * 4;              // 2 x ([32] bias, [32]
 constexpr int ONES_OFF = CB_OFF + 2 * 64 * 4;            // 8 x bf16(1.0): what lane 31 of the weight operand reads in a deferred-LayerNorm phase
 constexpr int FLAG_OFF = ONES_OFF + 16;                  // [0] give-up flag, [1] waves that drained their stores (S4), [2] ... their K-split partials (S3b)
 constexpr int LDS_BYTES = FLAG_OFF + 16;
-constexpr long long SPIN_LIMIT = 200000000ll;            // 2 s of the 100 MHz wall clock: a barrier that waits longer gives up
+constexpr long long SPIN_LIMIT = 100000000ll;            // 1 s of the 100 MHz wall clock: a barrier that waits longer gives up
 constexpr int NR = 4;                                    // k16-steps of one A round of a consumer wave
 constexpr int WB = 4;                                    // k16-steps whose W fragments are read from the ring together
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -163,6 +163,9 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
     const int wave = rfl(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cu = blockIdx.x, ncu = gridDim.x;
     volatile int* flag = reinterpret_cast<volatile int*>(lds + FLAG_OFF);
+    // a launch that gave up leaves its mark until the host has read it (hqt_range_check): every later launch returns at once instead of
+    // waiting out its own time limit (a GPU shared with another process that keeps some CUs busy would otherwise cost a second per launch)
+    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     if (wave == 8) {
         persist_loader(a, lds, cu, ncu, lane);
         return;
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
         stamp(p, 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
         stamp(p, 5);
-        if (last_wave(drained, 8u * (unsigned)(p + 1)) && p + 1 < a.n_phases && lane < 8)   // ... and the last one to have done so signals
+        if (last_wave(drained, 8u * (unsigned)(p + 1)) && p + 1 < a.n_phases && lane < 8 && !(a.fault == cu + 1 && p == 0))   // ... and the last one to have done so signals
             __hip_atomic_fetch_add(a.counters + ((cu & 7) * 8 + lane) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stamp(p, 6);
     }

@@ -97,14 +97,17 @@ class Engine:
         _lib.check(self.lib.hqt_set_policy(self.h, int(policy)))
         self.policy = int(policy)
 
-    def _note_split(self, precision: int, stream: int) -> None:
-        if int(precision) == _lib.PRECISION_SPLIT:
+    def _note_split(self, precision: int, stream: int, ar_rows: int = 0) -> None:
+        # calls whose validity the device reports after the fact: SPLIT (an activation outside the fp16 range) and FAST sampling of up to
+        # 64 rows (the persistent AR chain: a launch that could not get the whole GPU gives up after 1 s instead of hanging)
+        if int(precision) == _lib.PRECISION_SPLIT or (int(precision) == _lib.PRECISION_FAST and 0 < ar_rows <= 64):
             self._split_streams = getattr(self, '_split_streams', set()) | {int(stream or 0)}
 
     def range_check(self) -> None:
-        """hqt_range_check for every stream SPLIT-precision calls of this engine were enqueued on since the last check: waits for them and
-        raises HqtError (HQT_ERR_RANGE) if an activation left the fp16 range (the output of such a call is invalid).  No-op -- and no
-        synchronisation -- when no SPLIT call is pending."""
+        """hqt_range_check for every stream SPLIT-precision calls (and FAST sampling calls of up to 64 rows) of this engine were enqueued on
+        since the last check: waits for them and raises HqtError if an activation left the fp16 range (HQT_ERR_RANGE) or a persistent AR
+        launch gave up on its grid barrier (HQT_ERR_STATE) -- the output of such a call is invalid.  No-op -- and no synchronisation --
+        when no such call is pending."""
         streams, self._split_streams = getattr(self, '_split_streams', set()), set()
         err = None
         with torch.cuda.device(self.device):
@@ -252,7 +255,7 @@ class Engine:
         with torch.cuda.device(dev):
             _lib.check(self.lib.hqt_sample(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(force_top), _ptr(force_bot),
                                            _ptr(logits), _ptr(out_top), _ptr(out_bot), C.c_void_p(stream)))
-            self._note_split(precision, stream)
+            self._note_split(precision, stream, ar_rows=B)
         # inputs must outlive the asynchronous launches
         self._keep = (cond, noise, force_top, force_bot, rows)
         self._trust(out_top, out_bot, bound=max(self.s2.vocab_top, self.s2.vocab_bot))     # the sampler only writes ids inside the vocabulary

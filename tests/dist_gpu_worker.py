@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 def main():
     out_path, gb, steps, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    os.environ['HQT_PERSIST'] = '0'        # the ranks of this test share ONE GPU: the persistent AR chain wants the device to itself (bench.py does the same)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from hqtransformer_amd import synth
     from hqtransformer_amd.config import load_config

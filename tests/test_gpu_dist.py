@@ -60,17 +60,40 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run(tmp_path, mode):
     print('host ms per submitted step (3 lanes) per rank:', [round(v, 3) for v in info['host_ms_per_submit_3_lanes']])
 
 
-def _bench_two_ranks(extra_env, gpus_needed):
+def test_eight_ranks_ragged_global_batch_equal_the_unsharded_run(tmp_path):
+    """The 8-rank shape of BASELINE configs[2] on one GPU: a global batch of 13 samples over 8 processes (slices 2 2 2 2 2 1 1 1), every
+    rank its own engine on the shared device, one gather to rank 0 -- codes and pixels equal the unsharded run bit for bit (EXACT)."""
+    gb, steps = 13, 64
+    got, info = run_ranks(tmp_path, 8, gb, steps, 'exact')
+    sys.path.insert(0, ROOT)
+    from hqtransformer_amd import synth
+    from hqtransformer_amd.config import load_config
+    from hqtransformer_amd.models import ImageGPT2
+    from hqtransformer_amd.sampling import sampling_ihqgpt
+    dev = torch.device('cuda:0')
+    model = ImageGPT2(load_config(os.path.join(ROOT, 'configs', 'tiny-cls.yaml')), seed=5).to(dev)
+    cond = torch.from_numpy(synth.class_ids(7, gb, model.stage2.spec.n_classes))
+    ct, cb = sampling_ihqgpt(model.stage2, num_candidates=gb, cond=cond, top_k_top=50, top_p_top=0.9, top_k_bot=None, top_p_bot=None,
+                             softmax_temperature=[1.0, 0.9], use_fp16=False, is_tqdm=False, max_seq_len=steps, seed=1234, sample_offset=0)
+    px = model.stage1.decode_sequences(ct, cb, precision='exact')
+    torch.cuda.synchronize()
+    assert got['codes_top'].shape[0] == gb
+    assert np.array_equal(got['codes_top'], ct.cpu().numpy()) and np.array_equal(got['codes_bot'], cb.cpu().numpy())
+    assert np.array_equal(got['pixels'], px.cpu().numpy())
+    assert len(info['host_ms_per_submit_3_lanes']) == 8
+
+
+def _bench_two_ranks(extra_env, gpus_needed, world=2):
     if torch.cuda.device_count() < gpus_needed:
         pytest.skip(f'needs {gpus_needed} visible GPUs (this box has {torch.cuda.device_count()})')
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--merge', '2', '--inflight', '2',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '6', '--warmup', '2', '--merge', '2', '--inflight', '2',
            '--config', os.path.join(ROOT, 'configs', 'tiny-cls.yaml'), '--no-cpu-baseline', '--no-roofline']
-    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env), capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     return json.loads(line)
@@ -86,6 +109,19 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     # gloo cannot gather device tensors: the pre-flight then drops the gather and says so -- the fallback the RCCL run relies on
     assert d['config']['gather'].startswith(('pixels', 'none (requested gather failed')), d['config']['gather']
     assert len(d['host_ms_per_step_ranks']) == 2 and d['value'] > 0
+
+
+def test_bench_eight_ranks_control_flow_on_one_gpu():
+    """The driver's 8-GPU launch (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`) rehearsed on ONE GPU: eight processes share
+    the visible device (HQT_BENCH_SHARE_GPU=1, gloo rendezvous).  What runs: rank / world bookkeeping, the gather pre-flight and its
+    fall-back (gloo cannot gather device tensors), rank 0's receive buffers for 8 ranks, the barrier + max-over-ranks timing, eight per-rank
+    host costs (the box grants 16 cores to the 8 processes), ONE JSON line from rank 0 with n_gpus = 8 and a weak-scaling global batch.
+    The numbers mean nothing: eight engines time-share one GPU."""
+    d = _bench_two_ranks({'HQT_BENCH_SHARE_GPU': '1'}, 1, world=8)
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 8 * d['config']['per_gpu_batch'] and d['scaling'] == 'weak'
+    assert d['config']['gather'].startswith(('pixels', 'none (requested gather failed')), d['config']['gather']
+    assert len(d['host_ms_per_step_ranks']) == 8 and all(v > 0 for v in d['host_ms_per_step_ranks']) and d['value'] > 0
+    print('8 ranks on one GPU: host ms per step per rank', d['host_ms_per_step_ranks'], 'unthrottled', d.get('host_ms_per_step_unthrottled'))
 
 
 def test_bench_two_gpus_over_rccl():

@@ -143,3 +143,33 @@ def test_full_sampling_run_persistent_vs_chain(B):
     first = (a[0][:, 0] == c[0][:, 0]).float().mean().item()       # position 0 sees identical inputs in both forms
     gate(f'persist.free_run_B{B}.first_position_agreement', first, 0.97, '>=')
     eng.range_check()
+
+
+def test_a_launch_that_cannot_finish_gives_up_and_says_so():
+    """Every spin of the persistent kernel is bounded (1 s).  HQT_PERSIST_FAULT=1 makes CU 0 withhold its first grid-barrier signal: the
+    other CUs must give up instead of hanging the GPU, every later launch of the call must return at once (the mark of the first one is
+    still set: no second per launch), range_check must report it -- and after that the same engine samples correctly again."""
+    import time
+    from hqtransformer_amd import _lib
+    fx = load('g4_tiny_cls.npz')
+    spec, weights = stage2_from_fixture(fx)
+    eng = engine_s2(spec, weights, 8)
+    B, n = 4, 16
+    noise = torch.from_numpy(synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:n])
+    cond = torch.full((B,), 7)
+    good = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=False)
+    eng.range_check()
+    os.environ['HQT_PERSIST_FAULT'] = '1'
+    try:
+        t0 = time.perf_counter()
+        eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=False)
+        torch.cuda.synchronize()
+        took = time.perf_counter() - t0
+    finally:
+        del os.environ['HQT_PERSIST_FAULT']
+    assert 0.5 < took < 10.0, f'{took:.2f} s: one bounded wait (1 s), not one per launch ({2 * n} launches) and not a hang'
+    with pytest.raises(_lib.HqtError, match='gave up at the grid barrier'):
+        eng.range_check()
+    again = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=False)
+    eng.range_check()
+    assert torch.equal(again[0], good[0]) and torch.equal(again[1], good[1])
