@@ -73,6 +73,9 @@ def parse():
                    'Default (neither --merge nor --inflight given): the K timed steps are split over 2 lanes in passes of up to 32 steps '
                    '(merge = min(32, ceil(K / 2))): K = 20 -> 2 passes of 10, K = 96 -> 3 passes of 32; text-conditional and three-level configs: 8 x 3 lanes.  '
                    'With only one of the two given the other defaults to --merge 8 / --inflight 3')
+    p.add_argument('--ar-priority', type=int, default=None, choices=[0, 1],
+                   help='1: the AR loop of every lane runs on a stream of the highest priority (its decode stays on the lane stream behind an event): an AR kernel '
+                        'gets a freed compute unit before the other lane\'s convolution workgroups do.  Default: 1 when several lanes are in flight (see DEFAULT_AR_PRIORITY)')
     p.add_argument('--overlap', action='store_true', help='EXPERIMENT: run the decode of batch k on a second stream underneath the AR '
                    'loop of batch k+1 (measured slower on MI355X: the decoder starves the latency-bound AR kernels)')
     p.add_argument('--skip-decode', action='store_true', help='DEBUG ONLY (counter collection of the AR kernels at large row counts): no decode; the line is marked invalid')
@@ -237,6 +240,9 @@ def pmc_traffic(family, rows=None):
     if rows is None:
         return doc.get(family)
     return doc.get('by_rows', {}).get(str(int(rows)), {}).get(family)
+
+
+DEFAULT_AR_PRIORITY = False      # measured: profiles/r05_ar_priority.txt
 
 
 def default_schedule(steps, merge=None, inflight=None, wide=False):
@@ -439,7 +445,8 @@ def main():
     if args.positions:
         merge = 1                                  # debug runs (counter collection) sample a few positions of one pass
     rem = args.steps % merge                       # K need not be a multiple: the last pass of the timed region then holds `rem` steps
-    pipe = InflightSampler(model, lanes=inflight, device=dev, merge=merge)
+    ar_priority = bool(args.ar_priority) if args.ar_priority is not None else (DEFAULT_AR_PRIORITY and inflight > 1)
+    pipe = InflightSampler(model, lanes=inflight, device=dev, merge=merge, ar_high_priority=ar_priority)
 
     def after(ct, cb, px):
         gather_step(ct, px)

@@ -1372,7 +1372,9 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
     const size_t kv_layer = (size_t)cf.max_batch * h->Tmax * D * esz;
     const int* tb_dev = body_tbase_from_state ? &h->state->t_base : nullptr;
     const bool dln_body = Tq_body == 1 && dln_ok(h, c, h->body[0], B * Tq_body);
-    for (int l = 0; l < cf.n_layers; ++l) {
+    const bool pbody = dln_body && body_tbase_from_state && body_t_base == 0 && persist_on(h, c, h->pbody);      // the body is the two-level model's: one persistent launch
+    if (pbody) CHK(run_persist(h, c, h->pbody, h->x, 1, tb_dev, "persist_body"));
+    for (int l = 0; l < (pbody ? 0 : cf.n_layers); ++l) {
         void* kc = (char*)h->kcache + l * kv_layer;
         void* vc = (char*)h->vcache + l * kv_layer;
         if (dln_body) CHK(run_block_dln(h, c, h->body[l], h->x, h->xpk, h->parts, &h->nparts, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));

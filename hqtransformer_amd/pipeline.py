@@ -52,7 +52,8 @@ class Pending:
 
 
 class InflightSampler:
-    def __init__(self, model, lanes: int = 3, device: Optional[torch.device] = None, merge: int = 1, record_phases: bool = False):
+    def __init__(self, model, lanes: int = 3, device: Optional[torch.device] = None, merge: int = 1, record_phases: bool = False,
+                 ar_high_priority: bool = False):
         if lanes < 1 or merge < 1:
             raise ValueError('lanes and merge must be >= 1')
         self.model = model
@@ -63,6 +64,15 @@ class InflightSampler:
         self.n = int(lanes)
         self.device = device if device is not None else model.stage2._device
         self.streams: List[torch.cuda.Stream] = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
+        # ar_high_priority: a lane's AR loop runs on a stream of the highest priority, its decode on the lane's own stream behind an event.
+        # The AR kernels of a pass are thousands of short dependent launches; on equal terms each of them queues behind the other lane's
+        # convolution workgroups for compute units (tools/diag_overlap.py: 4 % overlap).  Priority decides who gets a freed slot first.
+        self.ar_streams: List[torch.cuda.Stream] = []
+        if ar_high_priority:
+            hi = -1
+            if hasattr(torch.cuda.Stream, 'priority_range'):
+                hi = torch.cuda.Stream.priority_range()[1]
+            self.ar_streams = [torch.cuda.Stream(device=self.device, priority=hi) for _ in range(self.n)]
         self.k = 0
 
     def submit(self, num_candidates: int, cond, *, seed: Optional[int] = None, max_seq_len: int = 64, use_fp16: bool = True,
@@ -153,10 +163,13 @@ class InflightSampler:
             eng = self.model.stage2.engine(num_candidates, max_seq_len, lane)
             if eng.policy != POLICY_THROUGHPUT:
                 eng.set_policy(POLICY_THROUGHPUT)
-        with torch.cuda.stream(st):
+        ast = self.ar_streams[lane] if self.ar_streams else st
+        three = getattr(self.model.stage2.spec, 'levels', 2) == 3
+        if ast is not st:
+            ast.wait_stream(st)                      # the lane stays one in-order sequence: AR of this pass behind the lane's previous decode
+        with torch.cuda.stream(ast):
             if phase_events is not None:
-                phase_events[0].record(st)
-            three = getattr(self.model.stage2.spec, 'levels', 2) == 3
+                phase_events[0].record(ast)
             if three:                                # HQTransformer: (codes0, [codes1, codes2]) keeps the 4-tuple shape of the result
                 codes = sampling_hqtransformer(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
                                                use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, precision=ar_precision, **sample_kw)
@@ -165,7 +178,12 @@ class InflightSampler:
                 ct, cb = sampling_ihqgpt(self.model.stage2, num_candidates=num_candidates, cond=cond, seed=seed, max_seq_len=max_seq_len,
                                          use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, precision=ar_precision, **sample_kw)
             if phase_events is not None:
-                phase_events[1].record(st)
+                phase_events[1].record(ast)
+        if ast is not st:
+            st.wait_stream(ast)
+            for t in (ct, *(cb if isinstance(cb, (list, tuple)) else (cb,))):
+                t.record_stream(st)
+        with torch.cuda.stream(st):
             px = None
             if decode:
                 px = self.model.stage1.decode_sequences([ct] + list(cb) if three else ct, None if three else cb,

@@ -24,6 +24,7 @@ def main():
     p.add_argument('--lanes', type=int, default=3)
     p.add_argument('--passes', type=int, default=9)
     p.add_argument('--decode-precision', default='split')
+    p.add_argument('--ar-priority', action='store_true', help='AR loops on streams of the highest priority')
     a = p.parse_args()
     dev = torch.device('cuda:0')
     model = ImageGPT2(load_config(a.config), seed=0).to(dev).eval()
@@ -31,7 +32,7 @@ def main():
     cond = torch.arange(R) % 1000
     out = {}
     for lanes in sorted({1, a.lanes}):
-        pipe = InflightSampler(model, lanes=lanes, device=dev)
+        pipe = InflightSampler(model, lanes=lanes, device=dev, ar_high_priority=a.ar_priority)
 
         def run(kind, n):
             t0 = None
@@ -55,6 +56,7 @@ def main():
         out[f'decode_only_lanes{lanes}_ms_per_pass'] = round(run('decode', a.passes)[0], 2)
         out[f'both_lanes{lanes}_ms_per_pass'] = round(run('both', a.passes)[0], 2)
     out['rows'] = R
+    out['ar_priority'] = bool(a.ar_priority)
     out['images_per_s_both'] = round(R / out[f'both_lanes{a.lanes}_ms_per_pass'] * 1e3, 1)
     print(json.dumps(out))
 
