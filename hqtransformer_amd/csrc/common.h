@@ -185,8 +185,10 @@ struct GemmArgs {
     int k_quarters;          // fp32 nn.Linear of the AR loop (set by run_linear for its gemm_* launches): the four-quarter summation order shared by
                              //   exact_mfma_gemm_kernel (<= 256 rows) and gemm_tile_kernel<..., QUARTERS>; every other fp32 GEMM keeps one chain per output
     int b_tile16;            // exact_mfma_gemm_kernel only: Bw is the fragment-ordered fp32 copy [n / 16][k / 32][chunk][lane][4] (pack_exact_tiles_kernel)
+    int k_slices;            // split_gemm_kernel<fp32 A> only (plain fp32 rows out, one batch): > 1 = blockIdx.z takes a slice of K and leaves its raw partial as
+    float* k_slabs;          //   fp32 [slice][M][N] in k_slabs; split_rows_combine_kernel adds the slices in index order, the bias and the residual (launch_split_gemm)
     int tile_panel;          // workgroup-order experiments.  SPLIT 3x3 convs: pixel tiles per panel (0: the n-tile runs fastest; measured: no effect,
-                             // profiles/r04_conv_tile_order.txt).  tile_gemm_kernel: 1 = the round-3 order (HQT_TILE_ORDER=0), see tile_of
+                             // profiles/r04_conv_tile_order.txt)
 };
 
 struct StepState {           // lives in device memory; lets one captured graph serve every position AND every call

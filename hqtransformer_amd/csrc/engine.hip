@@ -963,8 +963,13 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         GemmArgs sg = g;
         sg.a_f32 = 1; sg.Bw = l.w16h; sg.Bw_lo = l.w16l; sg.range_flag = h->range_flag;
         if (split_gemm_ok(sg)) {
+            // few tiles (fc2 / proj at 640 rows: 60): K slices into the split-K workspace, summed in index order by the combine launch
+            static const bool no_slices = getenv("HQT_SPLIT_KSLICES_OFF") != nullptr;
+            const int S = no_slices ? 1 : split_gemm_slices(sg);
+            if (S > 1 && (size_t)S * sg.M * sg.N <= h->splitk_elems) { sg.k_slices = S; sg.k_slabs = h->splitk; }
             HIPCHK(launch_split_gemm(sg, st));
-            count_variant(h, "variant:split_gemm:%s", tag);
+            if (sg.k_slices > 1) count_variant(h, "variant:split_gemm_kslices%d:%s", sg.k_slices, tag);
+            else count_variant(h, "variant:split_gemm:%s", tag);
             return HQT_OK;
         }
     }

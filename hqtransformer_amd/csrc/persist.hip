@@ -89,8 +89,16 @@ __device__ __forceinline__ void dma_unit(__amdgpu_buffer_rsrc_t rs, char* dst, i
 // the consumers do (a piece costs 60-180 cycles of issue, and the 64th outstanding one blocks the wave until an older one has landed).
 __device__ void persist_loader(const PersistArgs& a, char* lds, int cu, int ncu, int lane) {
     const auto rs = rsrc_of(a.wstream + a.cu_off[cu]);
-    int total = 0;
-    for (int p = 0; p < a.n_phases; ++p) total += rfl(persist_tile_units(a.phases[p], cu, ncu));
+    // KiB of every phase's tile, lane l holding phases l and 64 + l: all descriptor reads in flight together (one after the other -- 60
+    // dependent round trips -- they kept the consumers of phase 0 waiting 33 us per launch: profiles/r05_micro_persist.txt)
+    int units_lo = 0, units_hi = 0;
+    if (lane < a.n_phases) units_lo = persist_tile_units(a.phases[lane], cu, ncu);
+    if (lane + 64 < a.n_phases) units_hi = persist_tile_units(a.phases[lane + 64], cu, ncu);
+    int total = units_lo + units_hi;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
+    total = rfl(total);
+    auto units_of = [&](int p) { return p < 64 ? __builtin_amdgcn_readlane(units_lo, p) : __builtin_amdgcn_readlane(units_hi, p - 64); };
     int issued = 0, consumed = 0, end = 0, slot = 0;
     const int lane16 = lane * 16;
     auto issue_one = [&]() {
@@ -106,7 +114,7 @@ __device__ void persist_loader(const PersistArgs& a, char* lds, int cu, int ncu,
     fill(RING_UNITS);
     volatile int* flag = reinterpret_cast<volatile int*>(lds + FLAG_OFF);
     for (int p = 0; p < a.n_phases; ++p) {
-            end += rfl(persist_tile_units(a.phases[p], cu, ncu));
+        end += units_of(p);
         while (issued < end) issue_one();                // (space is there: a tile never exceeds the ring, and everything before it is consumed)
         wait_vm_le(issued - end);                        // everything up to the end of phase p's tile has landed
         raw_bar();                                       // S1
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
 // host side
 // ---------------------------------------------------------------------------------------------
 bool persist_program_ok(const std::vector<PersistPhase>& phases, int D, int M, int n_heads, int ncu) {
-    if (ncu < 8 || ncu % 4 != 0 || ncu > 256 || D % 8 != 0 || (D / 8 + 2) / 3 > ncu / 4 || phases.empty() || M < 1 || M > 64) return false;
+    if (ncu < 8 || ncu % 4 != 0 || ncu > 256 || D % 8 != 0 || (D / 8 + 2) / 3 > ncu / 4 || phases.empty() || phases.size() > 128 || M < 1 || M > 64) return false;
     if (n_heads < 1 || D % n_heads != 0) return false;
     const int hs = D / n_heads;
     if (hs % 8 != 0 || hs > 512 || ((hs / 8) & (hs / 8 - 1)) != 0) return false;

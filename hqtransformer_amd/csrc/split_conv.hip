@@ -497,7 +497,11 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
     auto LDS = [&](int stage, int op) -> char* { return lds_raw + (size_t)(stage * 4 + op) * OPB; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bz = blockIdx.z;
+    // K slices (AF32 rows of the SPLIT AR loop whose 128 x 128 tiles would fill a quarter of the chip: fc2 / proj at 640 rows are 60 tiles):
+    // blockIdx.z is the slice, the partial goes to its fp32 slab as it is
+    const int S = (AF32 && !BF32 && g.k_slices > 1) ? g.k_slices : 1;
+    const int ks = S > 1 ? (int)blockIdx.z : 0, bz = S > 1 ? 0 : (int)blockIdx.z;
+    const int kbase = ks * (g.K / S);
     int tile_m, tile_n;
     xcd_tile(tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -517,10 +521,10 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         aoff[i] = (m0 + row < g.M) ? (long long)(m0 + row) * g.lda + ch : -1;
         boff[i] = (n0 + row < g.N) ? (long long)(n0 + row) * g.ldb + ch : -1;
     }
-    const int KT = g.K / BKG;
+    const int KT = g.K / S / BKG;
     u32x4 stg[2][2][4];                                 // [slot][piece][A hi | A lo | W hi | W lo]; AF32: [first | second four floats | W hi | W lo]
     auto fetch = [&](int kt, u32x4 (&sl)[2][4]) {
-        const int k0 = min(kt, KT - 1) * BKG;
+        const int k0 = kbase + min(kt, KT - 1) * BKG;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (AF32) {
@@ -648,16 +652,17 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
     // epilogue: a lane owns 4 consecutive columns of one row per register quad.  The bias of the tile's 128 columns goes through the
     // (now dead) LDS stages: as one scalar load in front of every store, each a dependent L2 round trip, the epilogue took 32 k cycles
     // of a workgroup's 80 k (tools/micro/bench_split_gemm, in-kernel stamps); 14-25 k since.
-    float* Cb = reinterpret_cast<float*>(g.C) + (long long)bz * g.c_batch_stride;
-    const float* Rb = g.resid ? reinterpret_cast<const float*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
+    float* Cb = S > 1 ? g.k_slabs + (size_t)ks * g.M * g.N : reinterpret_cast<float*>(g.C) + (long long)bz * g.c_batch_stride;
+    const float* Rb = (g.resid && S == 1) ? reinterpret_cast<const float*>(g.resid) + (long long)bz * g.c_batch_stride : nullptr;
+    const int ldc = S > 1 ? g.N : g.ldc, act = S > 1 ? ACT_NONE : g.act;       // (bias, activation and residual of a sliced launch: the combine)
     // STORE_QKV (SPLIT AR loop: the fused [query; key; value] GEMM of a block, stage2/layers.py:73-85): a wave's 64-column block lies in ONE
     // part (the launcher guarantees qkv_D % 64 == 0), so the destination -- q rows as they are, K / V rows through the cache's row remap --
     // is resolved once per wave, never per element (a per-element select between C / C2 / C3 was miscompiled by hipcc -O3, fast_kernels.hip)
     const bool qkv = g.store == STORE_QKV;
-    const bool plain = ((g.store == STORE_ROWS && g.rows_per_group == 0) || qkv) && (g.N & 3) == 0 && (g.ldc & 3) == 0;
+    const bool plain = ((g.store == STORE_ROWS && g.rows_per_group == 0) || qkv) && (g.N & 3) == 0 && (ldc & 3) == 0;
     const int qkv_row_dev = (qkv && g.row_offset_dev) ? *g.row_offset_dev : 0;
     float* lbias = reinterpret_cast<float*>(lds_raw);
-    if (tid < BN) lbias[tid] = (g.bias && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.0f;     // every wave passed the loop's last barrier: the stages are free
+    if (tid < BN) lbias[tid] = (g.bias && S == 1 && n0 + tid < g.N) ? g.bias[n0 + tid] : 0.0f;     // every wave passed the loop's last barrier: the stages are free
     __syncthreads();
     if (plain) {
         // Row-major stores straight from the accumulators leave as 32 rows x 32 B per instruction (a million 32-byte write requests per
@@ -685,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                     const f32x4 bq = *reinterpret_cast<const f32x4*>(lbias + wn * 64 + cl);
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act((accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV) * g.alpha + bq[e], g.act);
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act((accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV) * g.alpha + bq[e], act);
                     *reinterpret_cast<f32x4*>(stg + fr * PITCH + cl) = v;
                 }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the patch is exchanged between the lanes of this wave only
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     const int m = min(mrow0 + p * 4 + r0, g.M - 1);
-                    x0[p] = *reinterpret_cast<const f32x4*>(Rb + (long long)m * g.ldc + min(ncol0 + cg, g.N - 4));
+                    x0[p] = *reinterpret_cast<const f32x4*>(Rb + (long long)m * ldc + min(ncol0 + cg, g.N - 4));
                 }
             }
 #pragma unroll
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                 if (Rb) v += x0[p];
                 long long orow = m;
                 if (remap) orow = (long long)(m / g.rows_per_group) * g.group_stride + m % g.rows_per_group + g.row_offset + qkv_row_dev;
-                if (m < g.M && col_ok) *reinterpret_cast<f32x4*>(Cw + orow * g.ldc + ccol0 + cg) = v;
+                if (m < g.M && col_ok) *reinterpret_cast<f32x4*>(Cw + orow * ldc + ccol0 + cg) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();                           // the patch is rewritten by the next row block
@@ -739,8 +744,8 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (n4 + e < g.N) {
-                            const long long idx = (long long)m * g.ldc + n4 + e;
-                            float x = apply_act(s[e] * g.alpha + bq[e], g.act);
+                            const long long idx = (long long)m * ldc + n4 + e;
+                            float x = apply_act(s[e] * g.alpha + bq[e], act);
                             if (Rb) x += Rb[idx];
                             Cb[idx] = x;
                         }
@@ -755,6 +760,34 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         d[0] = st_[1] - st_[0]; d[1] = st_[2] - st_[1]; d[2] = st_[3] - st_[2]; d[3] = wall_clock64();
     }
 #endif
+}
+
+// finishes a K-sliced launch: C[m][n] = (sum over the slices in index order) + bias[n] (+ resid[m][n]); 4 columns per thread
+__global__ __launch_bounds__(256) void split_rows_combine_kernel(float* C, int ldc, const float* resid, const float* __restrict__ slabs,
+                                                                 const float* __restrict__ bias, int M, int N, int S, int act) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x, n4 = N >> 2;
+    if (i >= (long long)M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (size_t)m * N + n);
+    for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(slabs + ((size_t)z * M + m) * N + n);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+    if (act != ACT_NONE)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+    if (resid) v += *reinterpret_cast<const f32x4*>(resid + (long long)m * ldc + n);
+    *reinterpret_cast<f32x4*>(C + (long long)m * ldc + n) = v;
+}
+
+// K slices of a launch whose tiles alone would leave most of the chip idle (up to 4, while two workgroups per slice-tile still fit 256 CUs once)
+int split_gemm_slices(const GemmArgs& g) {
+    if (!g.a_f32 || g.b_f32 || g.store != STORE_ROWS || g.rows_per_group != 0 || g.batch > 1 || g.conv_taps) return 1;
+    if (g.N % 4 != 0 || g.ldc % 4 != 0 || g.alpha != 1.0f) return 1;
+    const int tiles = ((g.N + 127) / 128) * ((g.M + 127) / 128);
+    // measured on the AR loop's shapes (profiles/r05_split_kslices.txt): slices pay while the launch stays within one workgroup per CU, and
+    // -- fc2, K = 4 D -- up to two per CU as long as a slice keeps 1536 of K; beyond that the slab traffic and the shorter loops cost more
+    int S = 1;
+    while (S < 4 && g.K % (S * 2 * 64) == 0 && (tiles * S * 2 <= 256 || (tiles * S * 2 <= 512 && g.K / (S * 2) >= 1536))) S *= 2;
+    return S;
 }
 
 bool split_gemm_ok(const GemmArgs& g) {
@@ -774,10 +807,16 @@ hipError_t launch_split_gemm(const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     if (g.conv_taps == 1) { g.lda = g.a_f32 ? g.Cin : 2 * g.Cin; g.conv_taps = 0; }   // a 1x1 conv over [pixel][hi C | lo C] (or [pixel][C] fp32) is a plain GEMM
     const int a_lo_off = g.lda / 2;
-    const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, g.batch > 0 ? g.batch : 1);
+    if (g.k_slices > 1 && (!g.k_slabs || g.k_slices > split_gemm_slices(g))) g.k_slices = 1;
+    const int S = g.k_slices > 1 ? g.k_slices : 1;
+    const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, S > 1 ? S : (g.batch > 0 ? g.batch : 1));
     if (g.a_f32 && g.b_f32) split_gemm_kernel<true, true><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
     else if (g.a_f32) split_gemm_kernel<true, false><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
     else split_gemm_kernel<false, false><<<grid, 256, 2 * 4 * 128 * 64, st>>>(g, a_lo_off);
+    if (S > 1) {
+        const long long n = (long long)g.M * (g.N / 4);
+        split_rows_combine_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(reinterpret_cast<float*>(g.C), g.ldc, reinterpret_cast<const float*>(g.resid), g.k_slabs, g.bias, g.M, g.N, S, g.act);
+    }
     return hipGetLastError();
 }
 

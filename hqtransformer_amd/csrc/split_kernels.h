@@ -30,7 +30,8 @@ hipError_t launch_split_pack(const float* x, half_t* y, const float* stats, cons
 bool split_conv3_ok(const GemmArgs& g);           // 3x3 stride-1 'same' conv (halo-tile kernel)
 bool split_gemm_ok(const GemmArgs& g);            // 1x1 conv / plain GEMM (128 x 128 x 64 tiles)
 hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st);
-hipError_t launch_split_gemm(const GemmArgs& g, hipStream_t st);
+hipError_t launch_split_gemm(const GemmArgs& g, hipStream_t st);   // g.k_slices > 1 (at most split_gemm_slices(g), with g.k_slabs): K-sliced + the combine launch
+int split_gemm_slices(const GemmArgs& g);         // 1 .. 4: slices worth taking for this shape (fp32-A rows out, few tiles)
 int split_conv3_tiles_per_image(const GemmArgs& g);
 hipError_t split_kernels_configure();             // raise the dynamic-LDS limits once (outside stream capture)
 

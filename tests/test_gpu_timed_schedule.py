@@ -56,7 +56,10 @@ def test_merged_pass_kernels_vs_oracle_at_imagenet_width(B, n):
     st, sb, ls = eng.sample(B, tc, n, precision=PRECISION_SPLIT, noise=tn, return_logits=True, use_graph=False)
     vs = variants(eng)
     eng.timing(False)
-    assert sum(c for k, c in vs.items() if k.startswith('variant:split_gemm:')) == 14 * n, vs      # every nn.Linear of the pass on the fp16 hi / lo matrix path
+    assert sum(c for k, c in vs.items() if k.startswith('variant:split_gemm')) == 14 * n, vs      # every nn.Linear of the pass on the fp16 hi / lo matrix path
+    # proj / fc2 of the B-row launches are 12 x B / 128 tiles: up to 1024 rows they run K-sliced (split_gemm_slices), the slices summed in index order
+    sliced = sum(c for k, c in vs.items() if k.startswith('variant:split_gemm_kslices'))
+    assert sliced == (4 * n if B <= 1024 else 2 * n), vs     # (2048 rows: fc2 of the body and of depth sub-step 0 in two slices)
     assert np.abs(np_(ls) - want[2]).max() <= LOGIT_TOL
     assert (np_(st) == want[0]).all() and (np_(sb) == want[1]).all()
     st, sb, ls = eng.sample(B, tc, n, precision=PRECISION_SPLIT, noise=tn, return_logits=True, use_graph=True)
