@@ -2040,7 +2040,7 @@ extern "C" int hqt_range_check(hqt_handle* h, void* stream) {
     ON_DEVICE(h);
     int flag = 0;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    if (h->persist_used && h->persist_err) {     // a persistent AR launch that gave up on a barrier (2 s: the GPU was shared with something that kept its workgroups out)
+    if (h->persist_used && h->persist_err) {     // a persistent AR launch that gave up on a barrier (1 s: the GPU was shared with something that kept its workgroups out)
         unsigned pe = 0;
         HIPCHK(hipMemcpy(&pe, h->persist_err, sizeof pe, hipMemcpyDeviceToHost));
         h->persist_used = false;

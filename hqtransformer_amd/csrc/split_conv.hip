@@ -490,6 +490,9 @@ hipError_t launch_split_conv3(const GemmArgs& g, hipStream_t st) {
 // a memory round trip, and the 16 k-tiles of a 512-channel 1x1 conv each waited for theirs: 23 % of the matrix peak).  Loads are
 // unconditional (clamped k-tile) so that the loop body is one basic block and the compiler's counted waits stay exact.
 // ---------------------------------------------------------------------------------------------
+// (Round 5, measured and removed: four register slots -- twice the bytes in flight, one workgroup per CU, accumulators in AGPRs -- for the AR loop's launches of at most one
+// tile per CU: 480 vs 472 ms per 640-row pass, profiles/r05_split_kslices.txt.  A k-tile of such a launch is not waiting for bytes: with one workgroup on the CU nothing
+// overlaps its ds_read -> MFMA -> stash -> barrier chain.)
 template <bool AF32, bool BF32>
 __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo_off) {
     constexpr int BM = 128, BN = 128, BKG = 32, ROWB = 64, OPB = 128 * ROWB;        // 32-wide k-tiles: 64 KiB of LDS, two workgroups per CU

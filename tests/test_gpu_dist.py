@@ -47,10 +47,16 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run(tmp_path, mode):
     model = ImageGPT2(load_config(os.path.join(ROOT, 'configs', 'tiny-cls.yaml')), seed=5).to(dev)
     cond = torch.from_numpy(synth.class_ids(7, gb, model.stage2.spec.n_classes))
     fast = mode == 'fast'
-    ct, cb = sampling_ihqgpt(model.stage2, num_candidates=gb, cond=cond, top_k_top=50, top_p_top=0.9, top_k_bot=None, top_p_bot=None,
-                             softmax_temperature=[1.0, 0.9], use_fp16=fast, is_tqdm=False, max_seq_len=steps, seed=1234, sample_offset=0)
-    px = model.stage1.decode_sequences(ct, cb, precision='fast' if fast else 'exact')
-    torch.cuda.synchronize()
+    # FAST draws are reproducible per (seed, schedule): the ranks of this test share one GPU and therefore run the launch chain (HQT_PERSIST=0 in
+    # dist_gpu_worker.py) -- the unsharded run they are compared with bit for bit must take the same schedule, not the persistent chain
+    os.environ['HQT_PERSIST'] = '0'
+    try:
+        ct, cb = sampling_ihqgpt(model.stage2, num_candidates=gb, cond=cond, top_k_top=50, top_p_top=0.9, top_k_bot=None, top_p_bot=None,
+                                 softmax_temperature=[1.0, 0.9], use_fp16=fast, is_tqdm=False, max_seq_len=steps, seed=1234, sample_offset=0)
+        px = model.stage1.decode_sequences(ct, cb, precision='fast' if fast else 'exact')
+        torch.cuda.synchronize()
+    finally:
+        del os.environ['HQT_PERSIST']
     assert np.array_equal(got['codes_top'], ct.cpu().numpy()) and np.array_equal(got['codes_bot'], cb.cpu().numpy())
     if fast:       # bf16 GEMM tiles depend on the row count (3 / 2 / 5 rows pad differently): same codes, pixels to bf16 accuracy
         assert np.abs(got['pixels'] - px.cpu().numpy()).max() <= 0.05

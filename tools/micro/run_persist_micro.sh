@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/p17; mkdir -p $O
+O=${O:-gpurun_out/p17}; mkdir -p $O
 (
 timeout 120 tools/micro/bench_persist check 128 4 2 512 3 5 1
 timeout 120 tools/micro/bench_persist check 1536 24 2 0 64 31 1 | tail -4
