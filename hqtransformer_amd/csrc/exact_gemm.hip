@@ -45,7 +45,13 @@ __global__ __launch_bounds__(256) void exact_mfma_gemm_kernel(GemmArgs g, int TM
     // the four partial tiles meet in LDS and leave as (p0 + p1) + (p2 + p3) -- the summation order gemm_tile_kernel uses too (gemm_generic.h).
     // Chains are a quarter as long (fc2 at 64 rows: 1536 dependent matrix instructions per wave before), and four times the waves fill the chip.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tm = (int)(blockIdx.x % TM), tn = (int)(blockIdx.x / TM);
+    // Workgroup b runs on XCD b % 8 and every XCD has its own L2: the TM workgroups that read the same W tile (same tn) must sit on ONE XCD, or the tile crosses
+    // the fabric TM times (fc2 at 64 rows, TM = 4: 151 MB instead of 38).  AR loop of one batch-64 step in EXACT: 190.8 -> 183.7 ms (profiles/r05_exact_xcd_order.txt).  XCD x takes the contiguous id range
+    // [x total / 8, (x + 1) total / 8); ids of one tn are adjacent.
+    int id = (int)blockIdx.x;
+    const int total = (int)gridDim.x;
+    if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int tm = id % TM, tn = id / TM;
     const int r = lane & 15, q = lane >> 4;
     const int m0 = tm * 16 * MT, n0 = tn * 16;
     const int NST = g.K >> 5;
