@@ -165,6 +165,9 @@ hipError_t launch_exact_mfma_gemm(const GemmArgs& g, hipStream_t st) {
         const long long waves = 4LL * (t16 / mt) * TN, cost = ((waves + 4095) / 4096) * mt * (mt == 1 ? 5 : 4);
         if (best < 0 || cost <= best) { best = cost; MT = mt; }
     }
+    // 64 rows, measured per shape (tools/micro/bench_exact, cold weights; us for MT = 1 / 2 / 4): qkv 18.8 / 20.2 / 27.4, fc1 26.4 / 22.0 / 28.8, fc2 26.4 / 24.1 / 43.1,
+    // proj 9.2 / 9.8 / 16.9 -- the model above picks MT = 2 for qkv and MT = 1 for fc2: a long K (48 steps per wave at MT = 1) wants two chains per wave, 4608 waves still fit
+    if (t16 == 4) MT = (g.K >= 4096 || 4LL * t16 * TN > 5120) ? 2 : 1;
     const int TM = t16 / MT;
     const unsigned grid = (unsigned)((long long)TM * TN);
 #define HQT_EXACT_LAUNCH(TILED, MT_) exact_mfma_gemm_kernel<TILED, MT_><<<grid, 256, 0, st>>>(g, TM, TN)

@@ -585,6 +585,37 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
             }
         }
     };
+    // fp32 A rows (the SPLIT AR loop, the decoder's nin_shortcut / q / k / v / proj_out): the hi / lo split of the NEXT k-tile's rows is ~130 vector instructions per lane.
+    // convert() is pure register work and shares a scheduling region with compute(): hipcc issues it in the shadow of the matrix instructions, only the LDS writes stay
+    // behind them (2048-row AR GEMMs 2800 -> 2520 cycles per k-tile with two workgroups per CU, the decoder's fp32-A 1x1 convs 399 -> 376 us; a launch of ONE workgroup
+    // per CU stays at 2140 cycles per k-tile -- its four waves run in lockstep between barriers -- whatever the order of the tiles, the prefetch depth or the tile height:
+    // profiles/r05_micro_split_gemm_ar.txt).
+    u32x4 cva[2][2];                                    // [piece][hi | lo] of the slot on its way to LDS
+    auto convert = [&](const u32x4 (&sl)[2][4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float xs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned bits = sl[i][e >> 2][e & 3];
+                xs[e] = __builtin_bit_cast(float, bits);
+            }
+            unsigned hi[4], lo[4];
+            split8_checked(xs, hi, lo, bad);
+            cva[i][0] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            cva[i][1] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    };
+    auto write = [&](int buf, const u32x4 (&sl)[2][4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* at = lds_raw + (size_t)buf * 4 * OPB + (wave * 2 + i) * 16 * ROWB + lane * 16;
+            *reinterpret_cast<u32x4*>(at) = cva[i][0];
+            *reinterpret_cast<u32x4*>(at + OPB) = cva[i][1];
+            *reinterpret_cast<u32x4*>(at + 2 * OPB) = sl[i][2];
+            *reinterpret_cast<u32x4*>(at + 3 * OPB) = sl[i][3];
+        }
+    };
     f32x16 accm[2][2], accx[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -634,6 +665,24 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
 #ifdef HQT_SPLIT_GEMM_STAMPS
     st_[1] = clock64();
 #endif
+    if constexpr (AF32 && !BF32) {
+        for (int kt = 0; kt < KT; kt += 2) {
+            fetch(kt + 2, stg[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            convert(stg[1]);                            // k-tile kt + 1, in the shadow of the MFMAs of k-tile kt
+            __builtin_amdgcn_sched_barrier(0);
+            write(1, stg[1]);
+            __syncthreads();
+            fetch(kt + 3, stg[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            convert(stg[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            write(0, stg[0]);
+            __syncthreads();
+        }
+    } else
     for (int kt = 0; kt < KT; kt += 2) {                // KT is even (K % 64 == 0)
         fetch(kt + 2, stg[0]);                          // slot 0 went to LDS one k-tile ago; in flight under TWO k-tiles of MFMAs
         __builtin_amdgcn_sched_barrier(0);              // (without the fences hipcc sinks the loads below the LDS writes of the other slot)
@@ -759,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
 #ifdef HQT_SPLIT_GEMM_STAMPS
     if (g.am_best && tid == 0) {
         st_[3] = clock64();
-        long long* d = reinterpret_cast<long long*>(g.am_best) + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4;
+        long long* d = reinterpret_cast<long long*>(g.am_best) + (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4;
         d[0] = st_[1] - st_[0]; d[1] = st_[2] - st_[1]; d[2] = st_[3] - st_[2]; d[3] = wall_clock64();
     }
 #endif
