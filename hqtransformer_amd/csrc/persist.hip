@@ -113,6 +113,9 @@ __device__ void persist_loader(const PersistArgs& a, char* lds, int cu, int ncu,
     };
     fill(RING_UNITS);
     volatile int* flag = reinterpret_cast<volatile int*>(lds + FLAG_OFF);
+    // (Measured and removed, profiles/r05_micro_persist_kv_touch.txt: touching the cached K / V rows of a CU's attention unit a phase ahead -- one dword per row, by the
+    // consumer waves in front of the grid wait or by this wave behind S1 of the QKV phase.  The attention phase gains 3 us at 63 cached keys, but the 25 MB of misses
+    // sit in front of wave 0's poll (in-order returns) or compete with the operand loads of the QKV phase: the body costs 15-28 us MORE with either form.)
     for (int p = 0; p < a.n_phases; ++p) {
         end += units_of(p);
         while (issued < end) issue_one();                // (space is there: a tile never exceeds the ring, and everything before it is consumed)
@@ -244,25 +247,6 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
             const int t = tid;
             cb[t] = (ph.bias && t < nc) ? ph.bias[n0 + t] : 0.0f;
             cb[32 + t] = (ph.colsum && t < nc) ? ph.colsum[n0 + t] : 0.0f;
-        }
-        // The cached keys / values of this CU's first attention unit of THIS layer do not depend on this launch.  One dword per cached row
-        // (lane j touches row j: a row of one head is at most one 128-byte line per 64 head dimensions) pulls them into this XCD's L2; the
-        // real loads behind the attention phase's barrier then take an L2 round trip instead of an HBM one.  Issued at the head of the QKV
-        // phase -- a whole phase ahead: at the last positions the rows of all units are 25 MB, ~5 us of HBM time that a request made at
-        // the head of the attention phase itself did not have (attention 12.6 us at 63 cached keys against 6.7 at none).
-        unsigned touch_k = 0, touch_v = 1;               // (two registers, first USED behind the barriers: an add here would make wave 0 wait out the HBM round trip before it polls)
-        if (ph.type == PP_QKV && t_cur > 0 && cu < nunits) {
-            const int h = cu / nb8, b = min((cu - h * nb8) * 8 + wave, M - 1);
-            const auto rsK = rsrc_of(ph.kc), rsV = rsrc_of(ph.vc);
-            const long long row0 = ((long long)b * ph.cache_T) * D + h * hs;
-            const int j = min(lane, t_cur - 1);
-            touch_k = __builtin_amdgcn_raw_buffer_load_b32(rsK, (int)((row0 + (long long)j * D) * 2), 0, 0);
-            touch_v = __builtin_amdgcn_raw_buffer_load_b32(rsV, (int)((row0 + (long long)j * D) * 2), 0, 0);
-            if (t_cur > 64) {                            // text prompts: rows 64 .. 127
-                const int j2 = min(64 + lane, t_cur - 1);
-                touch_k ^= __builtin_amdgcn_raw_buffer_load_b32(rsK, (int)((row0 + (long long)j2 * D) * 2), 0, 0);
-                touch_v ^= __builtin_amdgcn_raw_buffer_load_b32(rsV, (int)((row0 + (long long)j2 * D) * 2), 0, 0);
-            }
         }
         if (p > 0 && wave == 0 && !grid_wait(a, p, cu, ncu, lane)) give_up(p);
         cbar();                                          // S1: the previous phase is complete on every CU; this phase's tile has landed
@@ -587,7 +571,6 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
                 }
             }
         }
-        if (a.stamps && (touch_k ^ touch_v) == 0x5a5a5a5au && touch_k == 0x13579bdfu) a.stamps[0] = touch_k;     // (keeps the touch loads alive; stamps are a tools-only buffer)
         stamp(p, 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
         stamp(p, 5);
