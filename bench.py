@@ -662,7 +662,7 @@ def main():
             for k, v in e.timing_report().items():
                 rep[k] = (rep.get(k, (0, 0.0))[0] + v[0], rep.get(k, (0, 0.0))[1] + v[1])
             e.timing(False)
-        gemm = {k: v for k, v in rep.items() if k.startswith('gemm_') or k.startswith('persist_')}     # persist_*: the persistent AR chain (one launch = the GEMMs, attention and epilogues of 12 body blocks / of depth sub-step 0 + head_top)
+        gemm = {k: v for k, v in rep.items() if k.startswith('gemm_') or k.startswith('persist_')}     # persist_*: the persistent AR chain (one launch = the GEMMs, attention and epilogues of a top position up to its top logits)
         conv = {k: v for k, v in rep.items() if k in ('conv3x3', 'conv1x1', 'conv_out', 'attn_gemm')}
         ar_classes = [k for k in rep if k.startswith('gemm_') or k.startswith('persist_') or k in ('layernorm', 'attention', 'sampler', 'embed')]
         ar_eager_ms = sum(rep[k][1] for k in ar_classes)
@@ -686,7 +686,7 @@ def main():
             # part 2500 TFLOP/s / 8 TB/s = 312 FLOP/B.  Below 256 rows the launches are weight streams (HBM); merged passes are matrix work.
             mfma_bound = Bm >= 256
             persist = any(k.startswith('persist_') for k in gemm)
-            rec = {'kernel': (('persist_kernel (the 12 body blocks of a top position as ONE launch, depth sub-step 0 + head_top as a second: GEMMs + attention + epilogues; '
+            rec = {'kernel': (('persist_kernel (body blocks, ln_f + sos_depth, depth sub-step 0 and head_top of a top position as ONE launch: GEMMs + attention + epilogues; '
                                f'csrc/persist.hip) + stream_gemm_kernel (depth sub-step 1 at {4 * Bm} rows, head_bot): AR weight-streaming family, {Bm}-row passes') if persist else
                               f'tile_gemm_kernel / stream_gemm_kernel: AR GEMM family (qkv / proj / fc1 / fc2 / heads + split-K combine; {Bm}-row passes, {4 * Bm} rows in depth sub-step 1)'),
                    'bound': 'mfma' if mfma_bound else 'hbm',

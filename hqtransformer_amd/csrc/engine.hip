@@ -171,7 +171,8 @@ struct hqt_handle {
     int n_clones = 0;
     int policy = 0;                           // HQT_POLICY_*: tile choice of the streaming GEMMs (part of the graph key)
     // ---- persistent AR chain (FAST precision, up to 64 rows, latency policy, root handle): body blocks / depth sub-step 0 + head_top
-    PersistProg pbody, pdepth0;
+    PersistProg pbody, pfull;                 // body only (three code levels) / the whole position up to the top logits (persist_build)
+    float* lnf_shift = nullptr;               // ln_f.bias + sos_depth (PP_LNF)
     int ncu = 0;
     unsigned* persist_counters = nullptr;     // workspace: barrier + quad counters (zeroed by every launch)
     unsigned* persist_err = nullptr;          // workspace: set by a launch that gave up on a barrier
@@ -514,7 +515,7 @@ extern "C" int hqt_clone(hqt_handle* src, hqt_handle** out) {
     for (int i = 0; i < hqt_handle::ROWS_RING; ++i) { h->rows_pinned[i] = nullptr; h->rows_ev[i] = nullptr; h->rows_busy[i] = false; }
     h->rows_next = 0;
     h->nparts = h->npartsd = 0;
-    h->pbody.d_phases = nullptr; h->pdepth0.d_phases = nullptr;      // phase tables hold workspace pointers: bound per handle (persist_bind)
+    h->pbody.d_phases = nullptr; h->pfull.d_phases = nullptr;      // phase tables hold workspace pointers: bound per handle (persist_bind)
     h->persist_used = false;
     h->policy = HQT_POLICY_LATENCY;              // a lane's tile choice never depends on what the root ran when it was cloned
     const int rc = alloc_workspace(h.get());
@@ -742,7 +743,7 @@ extern "C" int hqt_finalize_weights(hqt_handle* h) {
         for (size_t i = owned_before; i < h->owned.size(); ++i) hipFree(h->owned[i]);
         h->owned.resize(owned_before);
         h->body.clear(); h->depth.clear();
-        h->pbody = PersistProg(); h->pdepth0 = PersistProg();
+        h->pbody = PersistProg(); h->pfull = PersistProg();
         h->head_top = h->head_bot = h->head_l2 = h->post_quant = h->quant_conv = Lin();
         for (auto& l : h->dec) { l.conv1 = l.conv2 = l.nin = l.q = l.k = l.v = l.proj = Lin(); }
         for (auto& l : h->enc) { l.conv1 = l.conv2 = l.nin = l.q = l.k = l.v = l.proj = Lin(); }
@@ -1026,12 +1027,11 @@ static const float* W(hqt_handle* h, const char* name) { return h->w[key2(h, nam
 
 // ------------------------------------------------------------------------------------------ persistent AR chain (persist.h)
 // FAST precision, up to 64 rows, decode steps (one token per sample), root handle under the latency policy: the twelve body blocks of a top
-// position run as ONE launch, and depth sub-step 0 (single-key blocks) + head_top as a second one.  Everything else -- merged passes, lanes,
+// position, ln_f + sos_depth, depth sub-step 0 (single-key blocks) and head_top run as ONE launch (three code levels: the body).  Everything else -- merged passes, lanes,
 // EXACT / SPLIT, the text prefill, depth sub-step 1 (256 rows: MI355X_MICROARCH.md's verdict for 256-row blocks is "cut at every seam") --
 // keeps the launch chain.  HQT_PERSIST=0 switches it off (A/B).
 struct PackSrc { const float* w; const float* gamma; };
 static bool persist_env_on() { const char* e = getenv("HQT_PERSIST"); return !(e && atoi(e) == 0); }      // read per call: tests switch it between calls (part of the graph key)
-static bool persist_depth0_env_on() { const char* e = getenv("HQT_PERSIST_DEPTH0"); return !(e && atoi(e) == 0); }
 
 static void persist_block_shapes(hqt_handle* h, const BlockW& bw, bool single_key, int cache_T, int* k4, std::vector<PersistPhase>& out, std::vector<PackSrc>& src) {
     const int D = h->cfg.embed_dim;
@@ -1077,22 +1077,39 @@ static int persist_build_one(hqt_handle* h, PersistProg& pr, const std::vector<P
 // finalize (root): the weight streams of both programs
 static int persist_build(hqt_handle* h) {
     const hqt_config& c = h->cfg;
-    h->pbody = PersistProg(); h->pdepth0 = PersistProg();
+    h->pbody = PersistProg(); h->pfull = PersistProg();
     if (!c.has_stage2 || getenv("HQT_PERSIST_BUILD_OFF")) return HQT_OK;
     HIPCHK(hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device));
     for (auto& b : h->body) if (!b.qkv.bias_ln || !b.fc1.bias_ln) return HQT_OK;        // no deferred-LayerNorm layouts for these shapes: launch chain
     for (auto& b : h->depth) if (!b.qkv.bias_ln || !b.fc1.bias_ln) return HQT_OK;
     std::vector<PackSrc> src;
     int k4 = 0;
-    for (auto& b : h->body) persist_block_shapes(h, b, false, h->Tmax, &k4, h->pbody.phases, src);
-    CHK(persist_build_one(h, h->pbody, src));
     if (c.code_levels != 3 && h->head_top.bias_ln) {
-        src.clear(); k4 = 0;
-        for (auto& b : h->depth) persist_block_shapes(h, b, true, 5, &k4, h->pdepth0.phases, src);
+        // two levels: body -> ln_f + sos_depth (a phase on the residual stream itself) -> the four single-key blocks of depth sub-step 0 -> head_top
+        PersistProg& pr = h->pfull;
+        for (auto& b : h->body) persist_block_shapes(h, b, false, h->Tmax, &k4, pr.phases, src);
         PersistPhase ph{};
+        ph.type = PP_LNF; ph.N = c.embed_dim; ph.K = c.embed_dim; ph.map = PP_MAP_QUAD; ph.dln = 1;
+        pr.phases.push_back(ph); src.push_back({nullptr, nullptr});
+        for (auto& b : h->depth) persist_block_shapes(h, b, true, 5, &k4, pr.phases, src);
+        ph = PersistPhase{};
         ph.type = PP_ROWS; ph.N = c.vocab_top; ph.K = c.embed_dim; ph.dln = 1;
-        h->pdepth0.phases.push_back(ph); src.push_back({h->head_top.w32, h->w[key2(h, "ln_top.weight")].d});
-        CHK(persist_build_one(h, h->pdepth0, src));
+        pr.phases.push_back(ph); src.push_back({h->head_top.w32, h->w[key2(h, "ln_top.weight")].d});
+        CHK(persist_build_one(h, pr, src));
+        if (pr.ok) {
+            const int D = c.embed_dim;
+            std::vector<float> beta(D), sos(D);
+            HIPCHK(hipMemcpy(beta.data(), h->w[key2(h, "ln_f.bias")].d, (size_t)D * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(sos.data(), h->w[key2(h, "sos_depth")].d, (size_t)D * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < D; ++i) beta[i] += sos[i];
+            CHK(dev_alloc(h, (void**)&h->lnf_shift, (size_t)D * 4, false));
+            HIPCHK(hipMemcpy(h->lnf_shift, beta.data(), (size_t)D * 4, hipMemcpyHostToDevice));
+        }
+    }
+    if (!h->pfull.ok) {                          // three code levels (or no folded head): the body alone
+        src.clear(); k4 = 0;
+        for (auto& b : h->body) persist_block_shapes(h, b, false, h->Tmax, &k4, h->pbody.phases, src);
+        CHK(persist_build_one(h, h->pbody, src));
     }
     HIPCHK(persist_configure());
     return HQT_OK;
@@ -1107,14 +1124,14 @@ static int persist_bind(hqt_handle* h) {
         HIPCHK(hipMemcpy(pr.d_phases, pr.phases.data(), pr.phases.size() * sizeof(PersistPhase), hipMemcpyHostToDevice));
         return HQT_OK;
     };
-    if (h->pbody.ok && !h->pbody.d_phases) {
+    auto bind_body = [&](PersistProg& pr) -> size_t {
         const size_t kv_layer = (size_t)c.max_batch * h->Tmax * D;              // bf16 elements
         size_t p = 0;
         for (int l = 0; l < c.n_layers; ++l) {
             const BlockW& bw = h->body[l];
             bf16_t* kc = reinterpret_cast<bf16_t*>(h->kcache) + l * kv_layer;
             bf16_t* vc = reinterpret_cast<bf16_t*>(h->vcache) + l * kv_layer;
-            PersistPhase* ph = &h->pbody.phases[p];
+            PersistPhase* ph = &pr.phases[p];
             ph[0].A = h->xpk; ph[0].bias = bw.qkv.bias_ln; ph[0].colsum = bw.qkv.colsum; ph[0].out = h->qbuf; ph[0].kc = kc; ph[0].vc = vc;
             ph[1].A = reinterpret_cast<bf16_t*>(h->qbuf); ph[1].out = h->abuf; ph[1].kc = kc; ph[1].vc = vc;
             ph[2].A = reinterpret_cast<bf16_t*>(h->abuf); ph[2].bias = bw.proj.b32; ph[2].out = h->xpk;
@@ -1122,14 +1139,20 @@ static int persist_bind(hqt_handle* h) {
             ph[4].A = reinterpret_cast<bf16_t*>(h->mbuf); ph[4].bias = bw.fc2.b32; ph[4].out = h->xpk;
             p += 5;
         }
+        return p;
+    };
+    if (h->pbody.ok && !h->pbody.d_phases) {
+        bind_body(h->pbody);
         CHK(upload(h->pbody));
     }
-    if (h->pdepth0.ok && !h->pdepth0.d_phases) {
+    if (h->pfull.ok && !h->pfull.d_phases) {
+        size_t p = bind_body(h->pfull);
+        PersistPhase& lf = h->pfull.phases[p++];
+        lf.A = h->xpk; lf.bias = h->lnf_shift; lf.colsum = W(h, "ln_f.weight"); lf.out = h->xdpk;
         const size_t dkv_layer = (size_t)c.max_batch * 5 * D;
-        size_t p = 0;
         for (int l = 0; l < c.n_layers_depth; ++l) {
             const BlockW& bw = h->depth[l];
-            PersistPhase* ph = &h->pdepth0.phases[p];
+            PersistPhase* ph = &h->pfull.phases[p];
             ph[0].A = h->xdpk; ph[0].bias = bw.qkv.bias_ln + D; ph[0].colsum = bw.qkv.colsum + D;
             ph[0].kc = reinterpret_cast<bf16_t*>(h->dk) + l * dkv_layer; ph[0].vc = reinterpret_cast<bf16_t*>(h->dv) + l * dkv_layer;
             ph[0].vpk = reinterpret_cast<bf16_t*>(h->abuf);
@@ -1138,9 +1161,9 @@ static int persist_bind(hqt_handle* h) {
             ph[3].A = reinterpret_cast<bf16_t*>(h->mbuf); ph[3].bias = bw.fc2.b32; ph[3].out = h->xdpk;
             p += 4;
         }
-        PersistPhase& hd = h->pdepth0.phases[p];
+        PersistPhase& hd = h->pfull.phases[p];
         hd.A = h->xdpk; hd.bias = h->head_top.bias_ln; hd.colsum = h->head_top.colsum; hd.out = h->logits;
-        CHK(upload(h->pdepth0));
+        CHK(upload(h->pfull));
     }
     return HQT_OK;
 }
@@ -1277,18 +1300,22 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     // them (decode steps, Tq = 1); the text prefill's embed_text does not, so the prefill pass takes the classic path
     const bool dln_body = Tq_body == 1 && dln_ok(h, c, h->body[0], B * Tq_body);
     // the twelve body blocks as ONE persistent launch (persist.h): decode steps of up to 64 samples
-    const bool pbody = dln_body && body_tbase_from_state && body_t_base == 0 && persist_on(h, c, h->pbody);
+    const bool dln1 = dln_ok(h, c, h->depth[0], B) && h->head_top.wpk_ln;
+    const bool dln4 = dln_ok(h, c, h->depth[0], 4 * B) && h->head_bot.wpk_ln;
+    const bool body_persistable = dln_body && body_tbase_from_state && body_t_base == 0;
+    // ... up to the top logits: body, ln_f + sos_depth, depth sub-step 0, head_top as ONE persistent launch
+    const bool pfull = body_persistable && dln1 && !getenv("HQT_NO_SINGLE_KEY") && persist_on(h, c, h->pfull);
+    const bool pbody = !pfull && body_persistable && persist_on(h, c, h->pbody);
+    if (pfull) CHK(run_persist(h, c, h->pfull, h->x, 0, tb_dev, "persist_position"));
     if (pbody) CHK(run_persist(h, c, h->pbody, h->x, 1, tb_dev, "persist_body"));
-    for (int l = 0; l < (pbody ? 0 : cf.n_layers); ++l) {
+    for (int l = 0; l < (pbody || pfull ? 0 : cf.n_layers); ++l) {
         void* kc = (char*)h->kcache + l * kv_layer;
         void* vc = (char*)h->vcache + l * kv_layer;
         if (dln_body) CHK(run_block_dln(h, c, h->body[l], h->x, h->xpk, h->parts, &h->nparts, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
         else CHK(run_block(h, c, h->body[l], h->x, Tq_body, kc, vc, h->Tmax, body_t_base, tb_dev, 1));
     }
-    const bool dln1 = dln_ok(h, c, h->depth[0], B) && h->head_top.wpk_ln;
-    const bool dln4 = dln_ok(h, c, h->depth[0], 4 * B) && h->head_bot.wpk_ln;
     // ln_f on the last token of each sample, + sos_depth (hierarchical_ar.py:561,684-686) -> depth-head input
-    {
+    if (!pfull) {
         Timed t(h, "layernorm", c.st);
         LNArgs ln{h->x, W(h, "ln_f.weight"), W(h, "ln_f.bias"), W(h, "sos_depth"), h->xd, B, D, Tq_body, Tq_body - 1, 1e-5f, DT_F32, 0,
                   h->pend.slabs, h->pend.S, h->pend.rows, h->pend.bias, dln1 ? h->xdpk : nullptr, dln1 ? packed_mb(B) : 0, h->partsd};
@@ -1299,10 +1326,8 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     const size_t dkv_layer = (size_t)cf.max_batch * 5 * D * esz;
     const int pk1 = (c.md.fast && B <= PACKED_MAX_ROWS && h->head_top.wpk) ? packed_mb(B) : 0;
     const int pk4 = (c.md.fast && 4 * B <= PACKED_MAX_ROWS && h->head_bot.wpk) ? packed_mb(4 * B) : 0;
-    // ---- depth sub-step 0: top code.  Persistent form: the four single-key blocks + head_top as one launch
-    const bool pdepth0 = dln1 && !getenv("HQT_NO_SINGLE_KEY") && persist_depth0_env_on() && persist_on(h, c, h->pdepth0);
-    if (pdepth0) CHK(run_persist(h, c, h->pdepth0, h->xd, 0, nullptr, "persist_depth0"));
-    for (int l = 0; l < (pdepth0 ? 0 : cf.n_layers_depth); ++l) {
+    // ---- depth sub-step 0: top code
+    for (int l = 0; l < (pfull ? 0 : cf.n_layers_depth); ++l) {
         void* kc = (char*)h->dk + l * dkv_layer;
         void* vc = (char*)h->dv + l * dkv_layer;
         if (dln1) CHK(run_block_dln(h, c, h->depth[l], h->xd, h->xdpk, h->partsd, &h->npartsd, 1, kc, vc, 5, 0, nullptr, 0));
@@ -1316,7 +1341,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
         g.A = h->hbuf; g.a_packed_mb = pk1;
     }
     g.M = B; g.batch = 1; g.C = h->logits; g.ldc = V; g.store = STORE_ROWS;
-    if (!pdepth0) CHK(run_linear(h, c.md, g, h->head_top, adt, DT_F32, c.st, "gemm_head"));
+    if (!pfull) CHK(run_linear(h, c.md, g, h->head_top, adt, DT_F32, c.st, "gemm_head"));
     {
         Timed t(h, "sampler", c.st);
         SamplerArgs s{h->logits, B, V, 1, B, c.o.temperature_top, c.o.top_k_top, c.o.top_p_top, c.noise, 0,
@@ -1602,7 +1627,7 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
                                      (uint64_t)logits_out, (uint64_t)opts->precision,
                                      (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot,
                                      (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2], (uint64_t)h->policy,
-                                     (uint64_t)(persist_env_on() ? 1 + (persist_depth0_env_on() ? 1 : 0) + (getenv("HQT_NO_SINGLE_KEY") ? 4 : 0) : 0)};
+                                     (uint64_t)(persist_env_on() ? 1 + (getenv("HQT_NO_SINGLE_KEY") ? 4 : 0) : 0)};
         { uint32_t f3[2]; memcpy(f3, &c.top_p[2], 4); memcpy(f3 + 1, &c.temperature[2], 4); key.push_back(f3[0]); key.push_back(f3[1]); }
         uint32_t f[4];
         memcpy(f, &opts->top_p_top, 4); memcpy(f + 1, &opts->top_p_bot, 4);

@@ -18,7 +18,9 @@
 #include "common.h"
 #include <vector>
 
-enum { PP_QKV = 0, PP_KV1 = 1, PP_ATTN = 2, PP_RESID = 3, PP_GELU = 4, PP_ROWS = 5, PP_RESID_K4 = 6 };
+enum { PP_QKV = 0, PP_KV1 = 1, PP_ATTN = 2, PP_RESID = 3, PP_GELU = 4, PP_ROWS = 5, PP_RESID_K4 = 6,
+       PP_LNF = 7 };       // x <- LayerNorm(x) gamma + shift on the residual stream itself (ln_f + sos_depth between the body and the depth head, hierarchical_ar.py:561,684-686): N = K = D,
+                           // PP_MAP_QUAD, A = the packed bf16 copy of x (row statistics), colsum = gamma, bias = beta + shift, out = the packed bf16 copy of the new x; no weights
 enum { PP_MAP_EVEN = 0, PP_MAP_QUAD = 1, PP_MAP_K4 = 2 };
 
 struct PersistPhase {       // one phase; the table lives in device memory and is the same for every CU
@@ -98,7 +100,7 @@ __host__ __device__ inline void persist_cols(int N, int rot, int map, int cu, in
 }
 __host__ __device__ inline bool persist_is_gemm(int type) { return type != PP_ATTN; }
 __host__ __device__ inline int persist_tile_units(const PersistPhase& ph, int cu, int ncu) {    // KiB of CU cu's weight tile of this phase
-    if (!persist_is_gemm(ph.type)) return 0;
+    if (!persist_is_gemm(ph.type) || ph.type == PP_LNF) return 0;
     int g0, ng, kq;
     persist_cols(ph.N, ph.rot, ph.map, cu, ncu, &g0, &ng, &kq);
     return ng * ((ph.map == PP_MAP_K4 ? ph.K >> 2 : ph.K) >> 6);

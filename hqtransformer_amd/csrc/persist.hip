@@ -256,7 +256,8 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
             const bool k4 = ph.type == PP_RESID_K4;
             const bool active = ng > 0 && mh < MB;
             const bool dln = ph.dln != 0;
-            const bool ones_col = dln && nc < 32;        // the row sums ride in column 31 of the MFMA tile
+            const bool lnf = ph.type == PP_LNF;          // no product: row statistics of x, then x itself is normalised (its fp32 master is in this CU's LDS)
+            const bool ones_col = dln && nc < 32 && !lnf;        // the row sums ride in column 31 of the MFMA tile
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
                 // One round = NR k16-steps as straight-line code (a branch per step makes every step its own basic block: ds_read -> wait -> MFMA ->
                 // dot products in series, ~170 cycles per step instead of ~50).  All W fragments of the round are read first.  MODE: 0 no statistics,
                 // 1 sum of squares (the sum rides in the ones column), 2 both by dot products.  TAIL: steps beyond the k-group's range multiply by
-                // zero rows (their loads were clamped to a valid address).
+                // zero rows (their loads were clamped to a valid address).  MODE 3 (PP_LNF): statistics only, no weights, no matrix instructions.
                 auto compute = [&](u32x4(&b)[NR], int r, auto mode_tag, auto tail_tag) {
                     constexpr int MODE = decltype(mode_tag)::value;
                     constexpr bool TAIL = decltype(tail_tag)::value;
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
                         bf16x8 wf[WB];
 #pragma unroll
                         for (int u = 0; u < WB; ++u) {
+                            if (MODE == 3) continue;
                             int off = tb + (ksW + min(r * NR + h + u, KS4 - 1)) * wstep + lane_w;
                             if (off >= RING_BYTES) off -= RING_BYTES;
                             if (MODE == 1 && ones_lane) off = ONES_OFF;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
                         for (int u = 0; u < WB; ++u) {
                             u32x4 bu = b[h + u];
                             if (TAIL && r * NR + h + u >= KS4) bu = u32x4{0u, 0u, 0u, 0u};
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], __builtin_bit_cast(bf16x8, bu), acc, 0, 0, 0);
+                            if (MODE != 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u], __builtin_bit_cast(bf16x8, bu), acc, 0, 0, 0);
                             if (MODE != 0) {
                                 // (NOT __builtin_bit_cast(bf16x2, b[u][j]): clang reads an ext-vector ELEMENT lvalue under bit_cast at the vector's
                                 //  base -- all four became dword 0, and the load shrank to one dword)
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
                                 ssq = __builtin_amdgcn_fdot2_f32_bf16(v1, v1, ssq, false);
                                 ssq = __builtin_amdgcn_fdot2_f32_bf16(v2, v2, ssq, false);
                                 ssq = __builtin_amdgcn_fdot2_f32_bf16(v3, v3, ssq, false);
-                                if (MODE == 2) {
+                                if (MODE >= 2) {
                                     ssum = __builtin_amdgcn_fdot2_f32_bf16(v0, ones, ssum, false);
                                     ssum = __builtin_amdgcn_fdot2_f32_bf16(v1, ones, ssum, false);
                                     ssum = __builtin_amdgcn_fdot2_f32_bf16(v2, ones, ssum, false);
@@ -346,13 +348,15 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
                         }
                     }
                 };
-                const int mode = !dln ? 0 : (ones_col ? 1 : 2);
+                const int mode = lnf ? 3 : (!dln ? 0 : (ones_col ? 1 : 2));
                 if (KS4 % NR == 0) {
                     if (mode == 0) run(std::integral_constant<int, 0>{}, std::false_type{});
                     else if (mode == 1) run(std::integral_constant<int, 1>{}, std::false_type{});
-                    else run(std::integral_constant<int, 2>{}, std::false_type{});
+                    else if (mode == 2) run(std::integral_constant<int, 2>{}, std::false_type{});
+                    else run(std::integral_constant<int, 3>{}, std::false_type{});
                 } else {                                   // small or odd K (the benchmark shapes never come here): one generic body
                     if (mode == 1) run(std::integral_constant<int, 1>{}, std::true_type{});
+                    else if (mode == 3) run(std::integral_constant<int, 3>{}, std::true_type{});
                     else run(std::integral_constant<int, 2>{}, std::true_type{});
                 }
                 if (dln) {
@@ -416,7 +420,16 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
                     st16_sc1(rsrc_of(ph.out), packed_off(mm, (g0 + kq) * 8, MB) * 2, __builtin_bit_cast(u32x4, pack8(o)));
                 }
             } else {
-                if (mine) {
+                if (mine && lnf) {                       // the residual stream itself: x <- (x - mean) rstd gamma + (beta + shift), fp32 master in place
+                    float s = 0.0f, qq = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { s += stat[(k * 64 + m) * 2]; qq += stat[(k * 64 + m) * 2 + 1]; }
+                    const float mean = s / (float)ph.K;
+                    const float rstd = 1.0f / sqrtf(fmaxf(qq / (float)ph.K - mean * mean, 0.0f) + 1e-5f);
+                    float* xr = xs + m * 8 + h4 * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = (xr[e] - mean) * rstd * cb[32 + g * 8 + h4 * 4 + e] + cb[g * 8 + h4 * 4 + e]; xr[e] = v[e]; }
+                } else if (mine) {
                     if (dln) {
                         float s = 0.0f, qq = 0.0f;
 #pragma unroll
@@ -460,7 +473,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
                     }
                 }
             }
-            unit0 = (unit0 + ng * (Kp >> 6)) % RING_UNITS;
+            if (!lnf) unit0 = (unit0 + ng * (Kp >> 6)) % RING_UNITS;
         } else {
             // ---- PP_ATTN: one query per (sample, head) over the cached keys + this step's (layers.py:93-102: scale on K, fp32 softmax).
             // A unit = (head h, 8 consecutive samples): wave w serves sample 8 bb + w, so the unit's output is hs / 8 whole 128-byte
@@ -602,9 +615,10 @@ bool persist_program_ok(const std::vector<PersistPhase>& phases, int D, int M, i
             continue;
         }
         if (ph.N % 8 != 0 || ph.K % 64 != 0 || ph.N <= 0 || ph.K <= 0) return false;
-        if (ph.type == PP_RESID && (ph.N != D || ph.map != PP_MAP_QUAD)) return false;
+        if ((ph.type == PP_RESID || ph.type == PP_LNF) && (ph.N != D || ph.map != PP_MAP_QUAD)) return false;
+        if (ph.type == PP_LNF && (ph.K != D || !ph.dln)) return false;
         if (ph.type == PP_RESID_K4 && (ph.N != D || ph.map != PP_MAP_K4 || ph.K % 256 != 0 || ph.k4_epoch != ++k4)) return false;
-        if (ph.type != PP_RESID && ph.type != PP_RESID_K4 && ph.map != PP_MAP_EVEN) return false;
+        if (ph.type != PP_RESID && ph.type != PP_RESID_K4 && ph.type != PP_LNF && ph.map != PP_MAP_EVEN) return false;
         if ((ph.type == PP_QKV || ph.type == PP_KV1) && (ph.N % D != 0)) return false;
         for (int c = 0; c < ncu; ++c) {
             int g0, ng, kq;

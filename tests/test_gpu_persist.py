@@ -74,7 +74,8 @@ def test_tiny_model_persistent_vs_chain_and_exact(B):
 
 def test_persistent_launches_are_what_runs():
     """The timing report names the kernels of a pass: with the persistent chain on, a FAST batch-64 position of the ImageNet model is
-    persist_body + persist_depth0 and no body / depth-0 GEMM launch; with HQT_PERSIST=0 it is the launch chain."""
+    ONE persistent launch (persist_position: body, ln_f + sos_depth, depth sub-step 0, head_top) and no body / depth-0 GEMM or LayerNorm launch; with HQT_PERSIST=0
+    it is the launch chain."""
     s2 = imagenet_spec()
     eng = engine_s2(s2, synth.stage2_weights(s2, 0, 'bench'), 64, 8)
     B, n = 64, 2
@@ -83,7 +84,7 @@ def test_persistent_launches_are_what_runs():
     eng.sample(B, cond, n, precision=PRECISION_FAST, seed=3, use_graph=False)
     rep = eng.timing_report()
     eng.timing(False)
-    assert rep['persist_body'][0] == n and rep['persist_depth0'][0] == n, rep
+    assert rep['persist_position'][0] == n and 'persist_body' not in rep and rep.get('layernorm', (0,))[0] == 0, rep
     # what is left of the chain: depth sub-step 1 (4 blocks x 4 GEMMs) + head_bot per position
     assert rep['gemm_qkv'][0] == 4 * n and rep['gemm_head'][0] == n, {k: v[0] for k, v in rep.items()}
     with chain_only():
@@ -92,7 +93,7 @@ def test_persistent_launches_are_what_runs():
         eng.sample(B, cond, n, precision=PRECISION_FAST, seed=3, use_graph=False)
         rep = eng.timing_report()
         eng.timing(False)
-    assert 'persist_body' not in rep or rep['persist_body'][0] == 0
+    assert 'persist_position' not in rep or rep['persist_position'][0] == 0
     assert rep['gemm_qkv'][0] == (12 + 4 + 4) * n
 
 
