@@ -63,6 +63,10 @@ def sampling_ihqgpt(model,
     ``precision`` ('exact' | 'fast' | 'split') overrides ``use_fp16``: 'split' = the fp32 launch sequence with every nn.Linear on the
     matrix cores (fp16 hi / lo operands, three MFMAs per term, fp32 accumulation): code sequences bit-identical to 'exact' wherever the
     draw is well-conditioned, at several times its speed.
+
+    The call is asynchronous and does not read the device's flags: 'split' passes above 256 rows SATURATE activations outside the fp16 range and
+    only flag them, and a persistent FAST launch (up to 64 samples) that could not finish on a shared GPU only marks the handle -- call
+    ``model.range_check()`` (``hqt_range_check``: raises ``HqtError``) once the codes are needed, as ``InflightSampler.drain`` and ``bench.py`` do.
     """
     spec = model.spec
     if model.use_txt_cond:
