@@ -1,4 +1,5 @@
-// Persistent AR chain (FAST precision, up to 64 rows): the transformer blocks of one top position as ONE launch.
+// Persistent AR chain (FAST precision, up to 64 rows): one top position up to its top logits as ONE launch -- the body blocks, ln_f + sos_depth
+// (hierarchical_ar.py:561,684-686), the single-key blocks of depth sub-step 0 and head_top (three code levels: the body blocks).
 //
 // Replaces, for a batch of up to 64 samples, the launch chain of hierarchical_ar.py:554-563 / layers.py:324-328,61-195
 // (qkv -> attention -> proj -> fc1 -> fc2 per block; 5 dependent launches per block in run_block_dln) with one
