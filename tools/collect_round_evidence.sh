@@ -20,9 +20,9 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 --
 python tools/prof_summary.py $O/stats1 60 > $O/kernel_stats_one_lane_merge32.txt
 cp $(find $O/stats1 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_one_lane_merge32.csv
 rm -rf $O/stats1
-# ---- counters: separate passes over a bounded run (2 positions + the decode) of the kernels AT THE ROWS OF THE TIMED PASSES: 640 (driver) and 2048 (default)
+# ---- counters: separate passes over a bounded run (2 positions + the decode) of the kernels AT THE ROWS OF THE TIMED PASSES: 64 (one step at a time: the persistent chain), 640 (driver) and 2048 (default)
 rm -f $O/pmc_latest.json
-for rows in 640 2048; do
+for rows in 64 640 2048; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- $(pmcrun $rows) > /dev/null 2> $O/pmc_${c}_$rows.err
     python tools/pmc_summary.py $O/pmc_$c > $O/pmc_${c}_rows${rows}_positions2.txt

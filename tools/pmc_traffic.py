@@ -14,7 +14,7 @@ import os
 import re
 import sys
 
-FAMILIES = {'stream_gemm': ('stream_gemm_kernel', 'tile_gemm_kernel', 'resid_combine_kernel'),       # the AR GEMM family (bench.py reads this key)
+FAMILIES = {'stream_gemm': ('stream_gemm_kernel', 'tile_gemm_kernel', 'resid_combine_kernel', 'persist_kernel'),       # the AR GEMM family (bench.py reads this key; 64 rows: the persistent chain + the 256-row streaming GEMMs)
             'decoder_conv': ('conv3x3_split_ring16_kernel', 'conv2x2_split_up16_kernel', 'conv3x3_split_out16_kernel', 'conv3x3_split_kernel', 'split_gemm_kernel'),       # SPLIT (the default decode)
             'decoder_conv_fast': ('conv3x3_halo_kernel', 'conv_glds_kernel')}
 
