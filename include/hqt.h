@@ -241,7 +241,13 @@ int hqt_decode_seq(hqt_handle* h, int B, const int64_t* codes_top, const int64_t
  * cannot travel that way.  The operand pass saturates it and sets a flag on the handle instead of failing the (asynchronous) call.
  * hqt_range_check synchronises `stream` (the one the calls were enqueued on), returns HQT_ERR_RANGE if any SPLIT call since the last
  * check met such a value (and clears the flag), HQT_OK otherwise.  The Python surface calls it wherever it hands pixels or codes of a
- * SPLIT call to the host side (decode_code / encode of lane 0, InflightSampler.drain). */
+ * SPLIT call to the host side (decode_code / encode of lane 0, InflightSampler.drain).
+ * Since round 5 it also reports the one asynchronous failure of a FAST call: hqt_sample of up to 64 samples on a root handle runs a top
+ * position as ONE persistent launch that needs every compute unit of the device resident at once (hqtransformer_amd/csrc/persist.h); every
+ * spin in it is bounded (1 s), and a launch that could not finish -- the GPU is shared with something that keeps compute units busy --
+ * marks the handle instead of hanging: HQT_ERR_STATE here ("... gave up at the grid barrier in front of phase p"), the codes of that call
+ * are invalid, later launches return at once until this call has cleared the mark.  HQT_PERSIST=0 in the environment selects the
+ * launch chain instead. */
 int hqt_range_check(hqt_handle* h, void* stream);
 
 /* introspection */
