@@ -23,13 +23,13 @@ static float timed(const GemmArgs& g, hipStream_t st, int reps) {
 }
 
 // `bench_split_gemm ar [rows]`: the SPLIT AR loop's nn.Linear shapes (fp32 activation rows, split while staged) at one merged-pass row count, K-sliced as the engine would
-static int ar_mode(int rows) {
+static int ar_mode(int rows, bool packed = false) {      // packed: A as fp16 [row][hi K | lo K] planes (what a separate operand pass would leave) instead of fp32 rows
     hipStream_t st; CK(hipStreamCreate(&st));
     CK(split_kernels_configure());
     const int D = 1536;
     const Shape shapes[] = {{"qkv", rows, 3 * D, D}, {"fc1", rows, 4 * D, D}, {"fc2", rows, D, 4 * D}, {"proj", rows, D, D}};
     float *A, *C, *slabs, *bias; half_t *Wh, *Wl; void* zero;
-    CK(hipMalloc(&A, (size_t)rows * 4 * D * 4)); CK(hipMalloc(&C, (size_t)rows * 4 * D * 4)); CK(hipMalloc(&slabs, (size_t)4 * rows * D * 4));
+    CK(hipMalloc(&A, (size_t)rows * 4 * D * 4 * 2)); CK(hipMalloc(&C, (size_t)rows * 4 * D * 4)); CK(hipMalloc(&slabs, (size_t)4 * rows * D * 4));
     CK(hipMalloc(&Wh, (size_t)4 * D * D * 2)); CK(hipMalloc(&Wl, (size_t)4 * D * D * 2)); CK(hipMalloc(&bias, 4 * D * 4)); CK(hipMalloc(&zero, 256));
     {
         std::vector<float> h((size_t)rows * 4 * D);
@@ -44,7 +44,7 @@ static int ar_mode(int rows) {
     printf("SPLIT AR GEMMs at %d rows (fp32 A): us per launch (incl. the combine of a K-sliced launch), TFLOP/s algorithmic, of the 2.5 PFLOP/s peak issued (x3)\n", rows);
     for (const Shape& s : shapes) {
         GemmArgs g{};
-        g.A = A; g.a_f32 = 1; g.lda = s.K; g.Bw = Wh; g.Bw_lo = Wl; g.ldb = s.K; g.C = C; g.ldc = s.N; g.M = s.M; g.N = s.N; g.K = s.K; g.batch = 1;
+        g.A = A; g.a_f32 = packed ? 0 : 1; g.lda = packed ? 2 * s.K : s.K; g.Bw = Wh; g.Bw_lo = Wl; g.ldb = s.K; g.C = C; g.ldc = s.N; g.M = s.M; g.N = s.N; g.K = s.K; g.batch = 1;
         g.bias = bias; g.alpha = 1.f; g.store = STORE_ROWS; g.zero_page = zero;
         const int S = split_gemm_slices(g);
         if (S > 1) { g.k_slices = S; g.k_slabs = slabs; }
@@ -68,6 +68,7 @@ static int ar_mode(int rows) {
 
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "ar")) return ar_mode(argc > 2 ? atoi(argv[2]) : 640);
+    if (argc > 1 && !strcmp(argv[1], "arp")) return ar_mode(argc > 2 ? atoi(argv[2]) : 640, true);
     const int B = argc > 1 ? atoi(argv[1]) : 64;
     hipStream_t st; CK(hipStreamCreate(&st));
     CK(split_kernels_configure());
