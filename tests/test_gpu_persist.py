@@ -146,6 +146,36 @@ def test_full_sampling_run_persistent_vs_chain(B):
     eng.range_check()
 
 
+def test_three_level_model_runs_its_body_persistently():
+    """Three code levels (fixture G7's tiny HQTransformer): the body blocks are one persistent launch (`persist_body`; the depth head of 21 tokens
+    keeps its launch chain), teacher-forced logits within the FAST gate of EXACT and of the chain's, graph and eager."""
+    import json
+    from hqtransformer_amd.spec import Stage2Spec
+    fx = load('g7_l3_tiny_cls.npz')
+    spec = Stage2Spec(**json.loads(str(fx['spec'])))
+    weights = synth.stage2_weights(spec, int(fx['weight_seed']), 'fixture')
+    B, n = int(fx['B']), 16
+    noise = torch.from_numpy(np.maximum(np.random.default_rng([int(fx['noise_seed']), 0x9e3779b9]).standard_exponential((n, 21, B, spec.vocab_top), dtype=np.float32),
+                                        np.float32(1e-30)))
+    force = [torch.from_numpy(fx[f'codes{i}_0'].copy())[:, :n] for i in range(3)]
+    eng = engine_s2(spec, weights, 4)
+    cond = torch.full((B,), 7)
+    ex = eng.sample3(B, cond, n, precision=PRECISION_EXACT, noise=noise, force=force, return_logits=True, use_graph=False)
+    with chain_only():
+        ch = eng.sample3(B, cond, n, precision=PRECISION_FAST, noise=noise, force=force, return_logits=True, use_graph=False)
+    eng.timing(True)
+    eng.timing_reset()
+    pe = eng.sample3(B, cond, n, precision=PRECISION_FAST, noise=noise, force=force, return_logits=True, use_graph=False)
+    rep = eng.timing_report()
+    eng.timing(False)
+    assert rep['persist_body'][0] == n and 'persist_position' not in rep, {k: v[0] for k, v in rep.items()}
+    pg = eng.sample3(B, cond, n, precision=PRECISION_FAST, noise=noise, force=force, return_logits=True, use_graph=True)
+    assert torch.equal(pe[3], pg[3]), 'graph replay and eager launches of the persistent body differ'
+    gate('persist.l3_tiny.vs_exact_logits', (pe[3] - ex[3]).abs().max().item(), 0.15)
+    gate('persist.l3_tiny.vs_chain_logits', (pe[3] - ch[3]).abs().max().item(), 0.15)
+    eng.range_check()
+
+
 def test_a_launch_that_cannot_finish_gives_up_and_says_so():
     """Every spin of the persistent kernel is bounded (1 s).  HQT_PERSIST_FAULT=1 makes CU 0 withhold its first grid-barrier signal: the
     other CUs must give up instead of hanging the GPU, every later launch of the call must return at once (the mark of the first one is
