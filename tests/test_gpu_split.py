@@ -380,3 +380,29 @@ def test_split_sampler_tiny_fixture_bit_exact():
     assert any(k.startswith(('variant:split_gemm:', 'variant:exact_mfma:')) for k in v), v
     assert not any(k.startswith('variant:gemm_generic_f32:') for k in v), f'fp32 vector-ALU GEMMs ran inside a SPLIT call: {v}'
     e.range_check()
+
+
+def test_split_sampler_k_sliced_gemms_on_the_tiny_model():
+    """SPLIT AR above 256 rows on fixture G4's tiny model (D = 128: K = 128 -> two K slices, K = 512 -> four): the K-sliced GEMMs + their combine launch
+    (split_rows_combine_kernel: slices summed in index order, bias, GELU, residual) against EXACT on the same noise -- identical codes, logits <= 2e-4 -- graph replay == eager, bitwise; the variant counters prove both slice counts ran."""
+    from tests.helpers import stage2_from_fixture
+    fx = load('g4_tiny_cls.npz')
+    spec, weights = stage2_from_fixture(fx)
+    B, n = 320, 3
+    e = Engine(spec, None, dev(), B, 8)
+    e.load(stage2=weights)
+    e.finalize()
+    noise = torch.from_numpy(synth.exp_noise(21, n, B, spec.vocab_top))
+    cond = torch.from_numpy((np.arange(B) * 3) % spec.n_classes)
+    ct, cb, lg = e.sample(B, cond, n, precision=0, noise=noise, return_logits=True, use_graph=False)
+    e.timing(True)
+    e.timing_reset()
+    st, sb, ls = e.sample(B, cond, n, precision=PRECISION_SPLIT, noise=noise, return_logits=True, use_graph=False)
+    v = {k: c[0] for k, c in e.timing_report().items() if k.startswith('variant:')}
+    e.timing(False)
+    assert any(k.startswith('variant:split_gemm_kslices2:') for k in v) and any(k.startswith('variant:split_gemm_kslices4:') for k in v), v
+    assert (ls - lg).abs().max().item() <= 2e-4
+    assert torch.equal(st, ct) and torch.equal(sb, cb)
+    sg, sbg, lsg = e.sample(B, cond, n, precision=PRECISION_SPLIT, noise=noise, return_logits=True, use_graph=True)
+    assert torch.equal(lsg, ls) and torch.equal(sg, st) and torch.equal(sbg, sb)
+    e.range_check()
