@@ -14,11 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libhqt.so')
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['engine.hip', 'kernels.hip', 'fast_kernels.hip', 'persist.hip', 'tile_gemm.hip', 'exact_gemm.hip', 'mfma_gemm.hip', 'split_conv.hip', 'split_stream_conv.hip']
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT = 0, 1, 2
 PRECISIONS = {'exact': PRECISION_EXACT, 'fast': PRECISION_FAST, 'split': PRECISION_SPLIT}
 POLICY_LATENCY, POLICY_THROUGHPUT = 0, 1
+SWITCH_PERSIST, SWITCH_SINGLE_KEY, SWITCH_PERSIST_FAULT = 0, 1, 2
+LAYOUT_FAST, LAYOUT_EXACT, LAYOUT_SPLIT, LAYOUT_ALL = 1, 2, 4, 7
 
 
 class HqtLibraryError(RuntimeError):
@@ -49,6 +51,7 @@ class hqt_config(C.Structure):
         ('max_batch', C.c_int32), ('max_steps', C.c_int32),
         ('code_levels', C.c_int32),
         ('depth_decoding', C.c_int32),
+        ('ar_layouts', C.c_int32),
     ]
 
 
@@ -91,6 +94,7 @@ SYMBOLS = {
     'hqt_finalize_weights': (C.c_int, [_VP]),
     'hqt_clone': (C.c_int, [_VP, C.POINTER(_VP)]),
     'hqt_set_policy': (C.c_int, [_VP, C.c_int]),
+    'hqt_set_switch': (C.c_int, [_VP, C.c_int, C.c_int]),
     'hqt_sample': (C.c_int, [_VP, C.c_int, _I64P, C.POINTER(hqt_sample_opts), _F32P, _I64P, _I64P, _F32P, _I64P, _I64P, _VP]),
     'hqt_decode': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),
     'hqt_decode_seq': (C.c_int, [_VP, C.c_int, _I64P, _I64P, _F32P, C.c_int, C.c_int, _VP]),

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -178,6 +179,12 @@ struct hqt_handle {
     unsigned* persist_err = nullptr;          // workspace: set by a launch that gave up on a barrier
     float* persist_slabs = nullptr;           // workspace: K-split partials
     bool persist_used = false;                // a persistent launch was queued since the last check of persist_err
+    bool persist_enabled = true;              // HQT_SWITCH_PERSIST (default: on unless HQT_PERSIST=0 was in the environment at hqt_create)
+    bool persist_tripped = false;             // a persistent launch of this handle gave up (hqt_range_check): the launch chain until HQT_SWITCH_PERSIST re-arms it
+    bool single_key = true;                   // HQT_SWITCH_SINGLE_KEY (default: on unless HQT_NO_SINGLE_KEY was in the environment at hqt_create)
+    bool capture_persist = false;             // run_persist ran since sample_run cleared it (is a persistent launch inside the graph being captured?)
+    bool graph_has_persist = false;           // the cached graph holds persistent launches: every replay marks persist_used
+    int layouts = 0;                          // HQT_LAYOUT_* bits hqt_finalize_weights builds for the AR loop's nn.Linear weights
     // ---- timing
     bool timing = false;
     std::vector<TimingSlot> slots;
@@ -354,8 +361,12 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
     DeviceGuard dg(device);
     if (!dg.ok) return fail(HQT_ERR_HIP, "hipSetDevice(%d) failed", device);
     std::unique_ptr<hqt_handle> h(new hqt_handle());
+    // every environment switch of the per-call path is read HERE, once per handle (hqt_set_switch changes two of them afterwards)
     h->tile_gemm = getenv("HQT_NO_TILE_GEMM") == nullptr;
+    { const char* e = getenv("HQT_PERSIST"); h->persist_enabled = !(e && atoi(e) == 0); }
+    h->single_key = getenv("HQT_NO_SINGLE_KEY") == nullptr;
     h->cfg = *cfg;
+    h->layouts = (cfg->ar_layouts & HQT_LAYOUT_ALL) ? (cfg->ar_layouts & HQT_LAYOUT_ALL) : HQT_LAYOUT_ALL;
     h->device = device;
     const hqt_config& c = h->cfg;
     if (c.has_stage2) {
@@ -443,10 +454,14 @@ static int alloc_workspace(hqt_handle* hp) {
         CHK(dev_alloc(h.get(), (void**)&h->xdpk, rows_pk * D * 2, true));
         CHK(dev_alloc(h.get(), (void**)&h->parts, (D / 32 + 1) * rows_pk * 2 * 4, true));
         CHK(dev_alloc(h.get(), (void**)&h->partsd, (D / 32 + 1) * rows_pk * 2 * 4, true));
-        CHK(dev_alloc(h.get(), (void**)&h->persist_counters, PERSIST_COUNTER_BYTES, true));
-        CHK(dev_alloc(h.get(), (void**)&h->persist_err, 256, true));
-        HIPCHK(hipMemset(h->persist_err, 0, 256));
-        CHK(dev_alloc(h.get(), (void**)&h->persist_slabs, persist_slab_floats(256) * 4, true));
+        if (!h->parent) {                        // the persistent chain runs on root handles only (persist_on)
+            CHK(dev_alloc(h.get(), (void**)&h->persist_counters, PERSIST_COUNTER_BYTES, true));
+            CHK(dev_alloc(h.get(), (void**)&h->persist_err, 256, true));
+            HIPCHK(hipMemset(h->persist_err, 0, 256));
+            CHK(dev_alloc(h.get(), (void**)&h->persist_slabs, persist_slab_floats(256) * 4, true));
+        } else {
+            h->persist_counters = nullptr; h->persist_err = nullptr; h->persist_slabs = nullptr;
+        }
     }
     if (c.has_stage1) {
         std::vector<DecLayer> both(h->dec);                 // decoder and encoder share the activation / attention / statistics buffers
@@ -516,7 +531,7 @@ extern "C" int hqt_clone(hqt_handle* src, hqt_handle** out) {
     h->rows_next = 0;
     h->nparts = h->npartsd = 0;
     h->pbody.d_phases = nullptr; h->pfull.d_phases = nullptr;      // phase tables hold workspace pointers: bound per handle (persist_bind)
-    h->persist_used = false;
+    h->persist_used = false; h->persist_tripped = false; h->capture_persist = false; h->graph_has_persist = false;
     h->policy = HQT_POLICY_LATENCY;              // a lane's tile choice never depends on what the root ran when it was cloned
     const int rc = alloc_workspace(h.get());
     if (rc != HQT_OK) { for (void* p : h->owned) hipFree(p); return rc; }
@@ -580,18 +595,22 @@ static int get_w(hqt_handle* h, const std::string& name, std::vector<int64_t> sh
 
 static int make_lin(hqt_handle* h, Lin& l, const float* w32, const float* b32, int N, int K, bool stream_pack, bool split_planes = false) {
     l.w32 = w32; l.b32 = b32; l.N = N; l.K = K;
-    CHK(dev_alloc(h, (void**)&l.w16, (size_t)N * K * 2, false));
-    HIPCHK(launch_f32_to_bf16(w32, l.w16, (size_t)N * K, 0));
-    if (split_planes) {
+    if (!stream_pack || (h->layouts & HQT_LAYOUT_FAST)) {
+        CHK(dev_alloc(h, (void**)&l.w16, (size_t)N * K * 2, false));
+        HIPCHK(launch_f32_to_bf16(w32, l.w16, (size_t)N * K, 0));
+    }
+    // the AR loop's nn.Linear weights (stream_pack) build only the layouts the handle was created for (hqt_config.ar_layouts)
+    const bool ar = stream_pack;
+    if (split_planes && (!ar || (h->layouts & HQT_LAYOUT_SPLIT))) {
         CHK(dev_alloc(h, (void**)&l.w16h, (size_t)N * K * 2, false));
         CHK(dev_alloc(h, (void**)&l.w16l, (size_t)N * K * 2, false));
         HIPCHK(launch_split_f32(w32, l.w16h, l.w16l, (size_t)N * K, 0));
     }
-    if (stream_pack && N % 16 == 0 && K % 32 == 0) {          // the AR loop's linears: tile-contiguous fp32 for the EXACT small-row GEMM
+    if (stream_pack && (h->layouts & HQT_LAYOUT_EXACT) && N % 16 == 0 && K % 32 == 0) {          // the AR loop's linears: tile-contiguous fp32 for the EXACT small-row GEMM
         CHK(dev_alloc(h, (void**)&l.w32t, (size_t)N * K * 4, false));
         HIPCHK(launch_pack_exact_tiles(w32, l.w32t, N, K, 0));
     }
-    if (stream_pack && stream_gemm_supported(N, K)) {
+    if (stream_pack && (h->layouts & HQT_LAYOUT_FAST) && stream_gemm_supported(N, K)) {
         CHK(dev_alloc(h, (void**)&l.wpk, (size_t)N * K * 2, false));
         HIPCHK(launch_pack_stream_weights(w32, l.wpk, N, K, 0));
     }
@@ -1031,7 +1050,6 @@ static const float* W(hqt_handle* h, const char* name) { return h->w[key2(h, nam
 // EXACT / SPLIT, the text prefill, depth sub-step 1 (256 rows: MI355X_MICROARCH.md's verdict for 256-row blocks is "cut at every seam") --
 // keeps the launch chain.  HQT_PERSIST=0 switches it off (A/B).
 struct PackSrc { const float* w; const float* gamma; };
-static bool persist_env_on() { const char* e = getenv("HQT_PERSIST"); return !(e && atoi(e) == 0); }      // read per call: tests switch it between calls (part of the graph key)
 
 static void persist_block_shapes(hqt_handle* h, const BlockW& bw, bool single_key, int cache_T, int* k4, std::vector<PersistPhase>& out, std::vector<PackSrc>& src) {
     const int D = h->cfg.embed_dim;
@@ -1078,8 +1096,11 @@ static int persist_build_one(hqt_handle* h, PersistProg& pr, const std::vector<P
 static int persist_build(hqt_handle* h) {
     const hqt_config& c = h->cfg;
     h->pbody = PersistProg(); h->pfull = PersistProg();
-    if (!c.has_stage2 || getenv("HQT_PERSIST_BUILD_OFF")) return HQT_OK;
+    if (!c.has_stage2 || !(h->layouts & HQT_LAYOUT_FAST) || getenv("HQT_PERSIST_BUILD_OFF")) return HQT_OK;
     HIPCHK(hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device));
+    // one 576-thread workgroup with its whole LDS ring must fit a compute unit, or the grid barrier can never complete: no program then (launch chain)
+    HIPCHK(persist_configure());
+    if (persist_blocks_per_cu() < 1) return HQT_OK;
     for (auto& b : h->body) if (!b.qkv.bias_ln || !b.fc1.bias_ln) return HQT_OK;        // no deferred-LayerNorm layouts for these shapes: launch chain
     for (auto& b : h->depth) if (!b.qkv.bias_ln || !b.fc1.bias_ln) return HQT_OK;
     std::vector<PackSrc> src;
@@ -1118,6 +1139,7 @@ static int persist_build(hqt_handle* h) {
 // per handle (a clone binds its own workspace): the phase tables with this handle's buffers.  Outside stream capture.
 static int persist_bind(hqt_handle* h) {
     const hqt_config& c = h->cfg;
+    if (h->parent) return HQT_OK;                // lanes never launch it (persist_on): no phase tables, no uploads
     const size_t D = c.embed_dim;
     auto upload = [&](PersistProg& pr) -> int {
         CHK(dev_alloc(h, (void**)&pr.d_phases, pr.phases.size() * sizeof(PersistPhase), true));
@@ -1169,7 +1191,7 @@ static int persist_bind(hqt_handle* h) {
 }
 
 static bool persist_on(hqt_handle* h, const SampleCtx& c, const PersistProg& pr) {
-    return persist_env_on() && pr.ok && pr.d_phases && c.md.fast && c.B <= 64 && h->policy == HQT_POLICY_LATENCY && !h->parent;
+    return h->persist_enabled && !h->persist_tripped && pr.ok && pr.d_phases && c.md.fast && c.B <= 64 && h->policy == HQT_POLICY_LATENCY && !h->parent;
 }
 
 static int run_persist(hqt_handle* h, const SampleCtx& c, const PersistProg& pr, float* x32, int write_back, const int* t_dev, const char* slot) {
@@ -1182,9 +1204,9 @@ static int run_persist(hqt_handle* h, const SampleCtx& c, const PersistProg& pr,
     static const bool nt = !(getenv("HQT_PERSIST_NT") && atoi(getenv("HQT_PERSIST_NT")) == 0);
     a.nt_weights = nt ? 1 : 0;
     persist_default_fill(a);
-    if (const char* f = getenv("HQT_PERSIST_FAULT")) a.fault = atoi(f);        // test hook: tests/test_gpu_persist.py::test_a_launch_that_cannot_finish_gives_up_and_says_so
     HIPCHK(launch_persist(a, h->ncu, c.st));
     h->persist_used = true;
+    h->capture_persist = true;
     count_variant(h, "variant:%s", slot);
     return HQT_OK;
 }
@@ -1235,7 +1257,6 @@ static int run_block(hqt_handle* h, const SampleCtx& c, const BlockW& bw, float*
 // a bf16 packed copy with partial row statistics; qkv / fc1 consume the copy with gamma-folded weights and normalise in
 // their epilogue, proj / fc2 update all three in theirs.  (Round 4's ninth "prefetch" wave, which touched the NEXT launch's weights
 // from inside this one, bought nothing -- profiles/r04_micro_weight_prefetch.txt -- and left with its switch in round 5.)
-static bool single_key_on() { static const bool on = !getenv("HQT_NO_SINGLE_KEY"); return on; }
 static bool dln_ok(hqt_handle* h, const SampleCtx& c, const BlockW& bw, int M) {
     static const bool off = getenv("HQT_NO_DLN") != nullptr;      // debugging / A-B switch: classic LayerNorm kernels
     if (off) return false;
@@ -1253,7 +1274,7 @@ static int run_block_dln(hqt_handle* h, const SampleCtx& c, const BlockW& bw, fl
     // score is exactly 1, so the attention output is the value row itself.  The GEMM then skips the query third of
     // the fused weight (rows [D, 3D) only), appends K/V to the cache for sub-step 1 and writes V straight into the
     // projection's operand; no attention launch.
-    const bool single_key = Tq == 1 && t_base == 0 && !t_base_dev && !getenv("HQT_NO_SINGLE_KEY");
+    const bool single_key = Tq == 1 && t_base == 0 && !t_base_dev && h->single_key;
     if (single_key) {
         g.qkv_first = 1; g.qkv_v_pk = reinterpret_cast<bf16_t*>(h->abuf); g.c_packed_mb = pk;
         Lin kv = bw.qkv;
@@ -1304,7 +1325,7 @@ static int run_position(hqt_handle* h, const SampleCtx& c, int Tq_body, int body
     const bool dln4 = dln_ok(h, c, h->depth[0], 4 * B) && h->head_bot.wpk_ln;
     const bool body_persistable = dln_body && body_tbase_from_state && body_t_base == 0;
     // ... up to the top logits: body, ln_f + sos_depth, depth sub-step 0, head_top as ONE persistent launch
-    const bool pfull = body_persistable && dln1 && !getenv("HQT_NO_SINGLE_KEY") && persist_on(h, c, h->pfull);
+    const bool pfull = body_persistable && dln1 && h->single_key && persist_on(h, c, h->pfull);
     const bool pbody = !pfull && body_persistable && persist_on(h, c, h->pbody);
     if (pfull) CHK(run_persist(h, c, h->pfull, h->x, 0, tb_dev, "persist_position"));
     if (pbody) CHK(run_persist(h, c, h->pbody, h->x, 1, tb_dev, "persist_body"));
@@ -1484,6 +1505,13 @@ static int run_position_l3(hqt_handle* h, const SampleCtx& c, int Tq_body, int b
     return HQT_OK;
 }
 
+// hqt_config.ar_layouts: a precision whose weight layout the handle was created without fails here, loudly (never a silent slower path)
+static int layout_check(const hqt_handle* h, const Mode& md) {
+    if (md.fast && !(h->layouts & HQT_LAYOUT_FAST)) return fail(HQT_ERR_STATE, "HQT_PRECISION_FAST on a handle created without HQT_LAYOUT_FAST (hqt_config.ar_layouts = %d)", h->cfg.ar_layouts);
+    if (md.split_ar && !(h->layouts & HQT_LAYOUT_SPLIT)) return fail(HQT_ERR_STATE, "HQT_PRECISION_SPLIT on a handle created without HQT_LAYOUT_SPLIT (hqt_config.ar_layouts = %d)", h->cfg.ar_layouts);
+    return HQT_OK;
+}
+
 static int run_decode_step(hqt_handle* h, const SampleCtx& c) {      // one KV-cached position, Tq = 1
     const hqt_config& cf = h->cfg;
     {
@@ -1530,6 +1558,7 @@ extern "C" int hqt_sample(hqt_handle* h, int B, const int64_t* cond, const hqt_s
     c.logits_out = logits_out; c.out_top = h->codes_top; c.out_bot = h->codes_bot;
     c.st = (hipStream_t)stream;
     CHK(mode_of(opts->precision, false, &c.md));
+    CHK(layout_check(h, c.md));
     if (cond) HIPCHK(hipMemcpyAsync(h->cond_buf, cond, (size_t)B * (cf.cond_type == HQT_COND_TEXT ? cf.ctx_len_txt : 1) * 8, hipMemcpyDefault, c.st));
     const int rc_run = sample_run(h, c);
     if (rc_run != HQT_OK) return rc_run;
@@ -1570,6 +1599,7 @@ extern "C" int hqt_sample_l3(hqt_handle* h, int B, const int64_t* cond, const hq
     c.logits_out = logits_out; c.out_top = h->codes_top; c.out_bot = h->codes_bot; c.out_l2 = h->codes_l2;
     c.st = (hipStream_t)stream;
     CHK(mode_of(opts->precision, false, &c.md));
+    CHK(layout_check(h, c.md));
     if (cond) HIPCHK(hipMemcpyAsync(h->cond_buf, cond, (size_t)B * (cf.cond_type == HQT_COND_TEXT ? cf.ctx_len_txt : 1) * 8, hipMemcpyDefault, c.st));
     const int rc_run = sample_run(h, c);
     if (rc_run != HQT_OK) return rc_run;
@@ -1578,6 +1608,33 @@ extern "C" int hqt_sample_l3(hqt_handle* h, int B, const int64_t* cond, const hq
     HIPCHK(hipMemcpyAsync(out2, h->codes_l2, (size_t)B * opts->n_steps * 16 * 8, hipMemcpyDeviceToDevice, c.st));
     return HQT_OK;
 }
+
+// Persistent launches need every compute unit of the device: two of them in flight at once (two root handles sampling on two streams)
+// would each hold part of the chip and spin until their time limit.  All persistent work of a process on one device is therefore
+// ordered by an event chain: the stream about to receive persistent launches first waits for the event behind the previous such
+// enqueue (of ANY handle), and records the next one behind its own.  The mutex is held across the enqueue (wait .. record): two host
+// threads cannot both wait for the same predecessor.  Kernels of other streams that are not persistent (a decode on another lane)
+// only delay a persistent launch -- they end by themselves.
+struct PersistOrder {
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static hipEvent_t& ev(int device) { static std::map<int, hipEvent_t> evs; return evs[device]; }
+    std::unique_lock<std::mutex> lock;
+    hipStream_t st;
+    int device;
+    bool active;
+    PersistOrder(int device_, hipStream_t st_, bool active_) : st(st_), device(device_), active(active_) {
+        if (!active) return;
+        lock = std::unique_lock<std::mutex>(mu());
+        hipEvent_t& e = ev(device);
+        if (!e) { if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; return; } }
+        else hipStreamWaitEvent(st, e, 0);
+    }
+    ~PersistOrder() {
+        if (!active) return;
+        hipEvent_t e = ev(device);
+        if (e) hipEventRecord(e, st);
+    }
+};
 
 static int sample_run(hqt_handle* h, const SampleCtx& c) {
     const hqt_config& cf = h->cfg;
@@ -1627,7 +1684,7 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
                                      (uint64_t)logits_out, (uint64_t)opts->precision,
                                      (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot,
                                      (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2], (uint64_t)h->policy,
-                                     (uint64_t)(persist_env_on() ? 1 + (getenv("HQT_NO_SINGLE_KEY") ? 4 : 0) : 0)};
+                                     (uint64_t)((h->persist_enabled && !h->persist_tripped ? 1 : 0) + (h->single_key ? 0 : 4))};
         { uint32_t f3[2]; memcpy(f3, &c.top_p[2], 4); memcpy(f3 + 1, &c.temperature[2], 4); key.push_back(f3[0]); key.push_back(f3[1]); }
         uint32_t f[4];
         memcpy(f, &opts->top_p_top, 4); memcpy(f + 1, &opts->top_p_bot, 4);
@@ -1643,6 +1700,7 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
             HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             SampleCtx cc = c;
             cc.st = cs;
+            h->capture_persist = false;
             HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
             int rc = HQT_OK;
             for (int gi = 0; gi < G && rc == HQT_OK; ++gi) rc = run_decode_step(h, cc);
@@ -1654,10 +1712,16 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
             HIPCHK(hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0));
             hipGraphDestroy(graph);
             h->graph_key = key;
+            h->graph_has_persist = h->capture_persist;
+            h->persist_used = false;                     // capturing queued nothing
         }
+        PersistOrder order(h->device, c.st, h->graph_has_persist);
+        if (h->graph_has_persist) h->persist_used = true;   // every replay queues the persistent launches the graph holds (hqt_range_check reads their mark)
         for (int s = 0; s < remaining / G; ++s) HIPCHK(hipGraphLaunch(h->graph_exec, c.st));
         return HQT_OK;
     }
+    const bool may_persist = c.md.fast && c.B <= 64 && (persist_on(h, c, h->pfull) || persist_on(h, c, h->pbody));
+    PersistOrder order(h->device, c.st, may_persist);
     for (int s = 0; s < remaining; ++s) CHK(run_decode_step(h, c));
     return HQT_OK;
 }
@@ -2059,6 +2123,21 @@ extern "C" int hqt_set_policy(hqt_handle* h, int policy) {
     return HQT_OK;
 }
 
+extern "C" int hqt_set_switch(hqt_handle* h, int which, int on) {
+    if (!h) return fail(HQT_ERR_INVALID, "null handle");
+    if (which == HQT_SWITCH_PERSIST) { h->persist_enabled = on != 0; if (on) h->persist_tripped = false; }
+    else if (which == HQT_SWITCH_SINGLE_KEY) h->single_key = on != 0;
+    else if (which == HQT_SWITCH_PERSIST_FAULT) {        // test hook: a device word next to the give-up mark (persist.h: err[1]); NOT part of the graph key -- a cached graph replays it
+        if (!h->persist_err) return fail(HQT_ERR_STATE, "no persistent chain on this handle (a lane, or a handle without stage 2)");
+        ON_DEVICE(h);
+        const unsigned v = (unsigned)on;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(h->persist_err + 1, &v, sizeof v, hipMemcpyHostToDevice));
+    }
+    else return fail(HQT_ERR_INVALID, "unknown switch %d", which);
+    return HQT_OK;
+}
+
 // ------------------------------------------------------------------------------------------ range check of SPLIT calls
 extern "C" int hqt_range_check(hqt_handle* h, void* stream) {
     if (!h) return fail(HQT_ERR_INVALID, "null");
@@ -2071,8 +2150,9 @@ extern "C" int hqt_range_check(hqt_handle* h, void* stream) {
         h->persist_used = false;
         if (pe) {
             HIPCHK(hipMemset(h->persist_err, 0, sizeof pe));
-            return fail(HQT_ERR_STATE, "a persistent AR launch on this handle gave up at the grid barrier in front of phase %u (its workgroups were not all resident within 1 s: the GPU is shared with a process or stream that keeps compute units busy): "
-                                       "the codes of that call are invalid; repeat it, or set HQT_PERSIST=0", pe - 1);
+            h->persist_tripped = true;           // part of the graph key: the next call captures the launch chain
+            return fail(HQT_ERR_STATE, "a persistent AR launch on this handle gave up at the grid barrier in front of phase %u (its workgroups were not all resident within 1 s: the GPU is shared with a process that keeps compute units busy): "
+                                       "the codes of that call are invalid; repeat it -- this handle now takes the launch chain (hqt_set_switch(h, HQT_SWITCH_PERSIST, 1) re-arms the persistent launch)", pe - 1);
         }
     }
     HIPCHK(hipMemcpy(&flag, h->range_flag, sizeof flag, hipMemcpyDeviceToHost));

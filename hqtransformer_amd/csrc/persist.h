@@ -49,7 +49,8 @@ struct PersistArgs {
     const char* wstream;                    // the program's weight streams, one contiguous run per CU
     const unsigned long long* cu_off;       // [ncu] byte offset of CU c's run
     unsigned* counters;                     // [64] barrier counters + [64] quad counters, one 128-byte line each (zeroed before every launch)
-    unsigned* err;                          // != 0 after a launch that gave up on a barrier (results are garbage)
+    unsigned* err;                          // err[0] != 0 after a launch that gave up on a barrier (results are garbage); err[1]: test hook, c + 1 = CU c never signals
+                                            // its first phase, so every other CU runs into the time limit (hqt_set_switch(HQT_SWITCH_PERSIST_FAULT); 0 in production)
     float* x32;                             // fp32 master of the residual stream [M][D]: read at start, written back at the end
     float* slabs;                           // PP_RESID_K4 partials: [quad][3 groups][4 quarters][64 rows][8] fp32
     int D, M, MB, n_heads, head_dim;
@@ -58,7 +59,6 @@ struct PersistArgs {
     int write_back;
     int nt_weights;                         // non-temporal weight DMA
     int fill_s1, fill_s3;                   // loader budgets (1-KiB pieces) behind the barriers S1 / S3 of a phase (persist_default_fill)
-    int fault;                              // test hook (HQT_PERSIST_FAULT=c+1): CU c never signals its first phase, so every other CU runs into the time limit
     long long* stamps;                      // tools/micro only: [ncu][n_phases][8] wall-clock stamps of wave 0 (NULL in the product)
 };
 
@@ -117,5 +117,7 @@ size_t persist_layout(const std::vector<PersistPhase>& phases, int ncu, std::vec
 hipError_t launch_persist_pack(const float* w, const float* gamma, const PersistPhase& ph, int ncu, char* stream, const unsigned long long* d_tile_off, hipStream_t st);
 inline void persist_default_fill(PersistArgs& a) { a.fill_s1 = 0; a.fill_s3 = 48; }
 hipError_t persist_configure();
+// persistent workgroups (576 threads, the whole LDS ring) one compute unit admits by the occupancy query: the grid barrier needs >= 1
+int persist_blocks_per_cu();
 // memset of the counters + the launch (both stream-ordered, capturable)
 hipError_t launch_persist(const PersistArgs& a, int ncu, hipStream_t st);

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
     // a launch that gave up leaves its mark until the host has read it (hqt_range_check): every later launch returns at once instead of
     // waiting out its own time limit (a GPU shared with another process that keeps some CUs busy would otherwise cost a second per launch)
     if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const unsigned fault = a.err[1];                     // test hook (hqt_set_switch(HQT_SWITCH_PERSIST_FAULT, c + 1)): a device word, so a cached graph replays it
     if (wave == 8) {
         persist_loader(a, lds, cu, ncu, lane);
         return;
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(576, 1) void persist_kernel(PersistArgs a) {
         stamp(p, 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
         stamp(p, 5);
-        if (last_wave(drained, 8u * (unsigned)(p + 1)) && p + 1 < a.n_phases && lane < 8 && !(a.fault == cu + 1 && p == 0))   // ... and the last one to have done so signals
+        if (last_wave(drained, 8u * (unsigned)(p + 1)) && p + 1 < a.n_phases && lane < 8 && !(fault == (unsigned)cu + 1u && p == 0))   // ... and the last one to have done so signals
             __hip_atomic_fetch_add(a.counters + ((cu & 7) * 8 + lane) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stamp(p, 6);
     }
@@ -689,6 +690,11 @@ hipError_t launch_persist_pack(const float* w, const float* gamma, const Persist
 
 hipError_t persist_configure() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+}
+int persist_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(persist_kernel), 576, LDS_BYTES) != hipSuccess) return 0;
+    return n;
 }
 hipError_t launch_persist(const PersistArgs& a, int ncu, hipStream_t st) {
     hipError_t e = hipMemsetAsync(a.counters, 0, PERSIST_COUNTER_BYTES, st);

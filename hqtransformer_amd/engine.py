@@ -20,11 +20,12 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def make_config(s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], max_batch: int, max_steps: int) -> hqt_config:
+def make_config(s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], max_batch: int, max_steps: int, ar_layouts: int = 0) -> hqt_config:
     c = hqt_config()
     c.abi_version = _lib.ABI_VERSION
     c.max_batch = int(max_batch)
     c.max_steps = int(max_steps)
+    c.ar_layouts = int(ar_layouts)
     if s2 is not None:
         c.has_stage2 = 1
         c.embed_dim, c.n_layers, c.n_heads, c.n_layers_depth = s2.embed_dim, s2.n_layers, s2.n_heads, s2.n_layers_depth
@@ -59,7 +60,10 @@ class Engine:
     """One libhqt handle on one GPU.  Not thread-safe; asynchronous on torch's current stream."""
 
     def __init__(self, s2: Optional[Stage2Spec], s1: Optional[Stage1Spec], device: torch.device, max_batch: int,
-                 max_steps: Optional[int] = None):
+                 max_steps: Optional[int] = None, ar_layouts: int = 0):
+        """``ar_layouts``: bit mask of ``_lib.LAYOUT_*`` -- which derived layouts of the AR loop's weights ``finalize`` builds
+        (``hqt_config.ar_layouts``; 0 = all).  A FAST-only replica passes ``_lib.LAYOUT_FAST`` and holds 5.2 instead of 9.1 GB for the
+        ImageNet-12L model; a call in a precision the engine was built without raises HqtError (HQT_ERR_STATE)."""
         self.lib = _lib.load()                      # raises HqtLibraryError when the HIP library is absent
         self.s2, self.s1 = s2, s1
         self.device = torch.device(device)
@@ -67,7 +71,7 @@ class Engine:
             raise _lib.HqtLibraryError(f'libhqt runs on an MI355X only; got device {self.device} (no CPU fallback)')
         self.max_batch = int(max_batch)
         self.max_steps = int(max_steps if max_steps is not None else (s2.ctx_len_img if s2 else 1))
-        self.cfg = make_config(s2, s1, self.max_batch, self.max_steps)
+        self.cfg = make_config(s2, s1, self.max_batch, self.max_steps, ar_layouts)
         h = C.c_void_p()
         _lib.check(self.lib.hqt_create(C.byref(self.cfg), self.device.index or 0, C.byref(h)))
         self.h = h
@@ -96,6 +100,21 @@ class Engine:
         lanes in flight).  Part of the graph key: the next sample() re-captures if it changed."""
         _lib.check(self.lib.hqt_set_policy(self.h, int(policy)))
         self.policy = int(policy)
+
+    def set_persist(self, on: bool) -> None:
+        """``hqt_set_switch(HQT_SWITCH_PERSIST)``: False = the launch chain instead of the persistent AR launch (FAST sampling of up to 64
+        rows); True also re-arms a handle that fell back to the chain after a launch gave up.  Part of the graph key."""
+        _lib.check(self.lib.hqt_set_switch(self.h, _lib.SWITCH_PERSIST, int(bool(on))))
+
+    def set_persist_fault(self, cu_plus_one: int) -> None:
+        """Test hook ``hqt_set_switch(HQT_SWITCH_PERSIST_FAULT)``: compute unit ``cu_plus_one - 1`` withholds its first grid-barrier signal in
+        every later persistent launch (0 = none), cached graphs included."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.hqt_set_switch(self.h, _lib.SWITCH_PERSIST_FAULT, int(cu_plus_one)))
+
+    def set_single_key(self, on: bool) -> None:
+        """``hqt_set_switch(HQT_SWITCH_SINGLE_KEY)``: False = depth sub-step 0 the long way round (A/B runs and tests; bit-identical results)."""
+        _lib.check(self.lib.hqt_set_switch(self.h, _lib.SWITCH_SINGLE_KEY, int(bool(on))))
 
     def _note_split(self, precision: int, stream: int, ar_rows: int = 0) -> None:
         # calls whose validity the device reports after the fact: SPLIT (an activation outside the fp16 range) and FAST sampling of up to
@@ -307,7 +326,7 @@ class Engine:
         with torch.cuda.device(dev):
             _lib.check(self.lib.hqt_sample_l3(self.h, B, _ptr(cond), C.byref(o), _ptr(noise), _ptr(f[0]), _ptr(f[1]), _ptr(f[2]),
                                               _ptr(logits), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), C.c_void_p(stream)))
-            self._note_split(precision, stream)
+            self._note_split(precision, stream, ar_rows=B)        # the three-level body runs persistently too (run_position_l3)
         self._keep = (cond, noise, f, rows)
         self._trust(*outs, bound=max(self.s2.vocab_top, self.s2.vocab_bot))
         return (outs[0], outs[1], outs[2], logits) if return_logits else tuple(outs)

@@ -128,6 +128,7 @@ def main(args) -> dict:
         torch.cuda.synchronize(device)
         wall_s = time.time() - t_begin
         model_ar.stage1.range_check()
+        model_ar.stage2.range_check()          # FAST AR sampling of up to 64 rows: raises if a persistent launch gave up (hqt_range_check)
         if pipe is not None and merge > 1:
             log, pipe.phase_log = pipe.phase_log, []
             phase_s = [sum(ev[a].elapsed_time(ev[a + 1]) for ev, _ in log) / 1000 for a in (0, 1)]

@@ -87,6 +87,7 @@ def main(argv=None):
                                            is_tqdm=False, max_seq_len=args.top_resolution * args.top_resolution, model_stage1=model.stage1)
         pixels = model.stage1.decode_sequences(codes_t, codes_b, precision=args.decode_precision, clamp01=True)
         model.stage1.range_check()                                  # SPLIT decode: raises if an activation left the fp16 range
+        model.stage2.range_check()          # FAST AR sampling of up to 64 rows: raises if a persistent launch gave up (hqt_range_check)
         save_pickle(os.path.join(args.result_path, f'samples_({batch_idx + 1}_{n}).pkl'), pixels.cpu().numpy().astype(np.float32))
 
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HQT_ABI_VERSION 6
+#define HQT_ABI_VERSION 7
 
 typedef enum {
     HQT_OK = 0,
@@ -92,7 +92,17 @@ typedef struct {
      * the sub-step inputs come from tok_emb_levels).  The other values of the reference ('tree', 'old-parallel',
      * 'parallel-add-reduce') cannot sample three levels there either. */
     int32_t depth_decoding;
+    /* Which derived layouts of the AR loop's nn.Linear weights hqt_finalize_weights builds (bit mask of HQT_LAYOUT_*; 0 = all of them,
+     * what ABI <= 6 always did: 9.1 GB for the 2.1 GB ImageNet-12L model).  The fp32 tensors as received are always kept: they are
+     * what EXACT computes from.  A replica that only ever samples in FAST precision passes HQT_LAYOUT_FAST (5.2 GB); a hqt_sample /
+     * hqt_sample_l3 call in a precision whose layout the handle was built without fails with HQT_ERR_STATE (EXACT without
+     * HQT_LAYOUT_EXACT still runs, on the row-major fp32 weights: same results, slower below 257 rows).  Stage 1 is not affected. */
+    int32_t ar_layouts;
 } hqt_config;
+#define HQT_LAYOUT_FAST 1   /* bf16 MFMA-fragment packing (+ the LayerNorm-folded copies, the persistent chain's per-CU stream) */
+#define HQT_LAYOUT_EXACT 2  /* fragment-ordered fp32 copy (v_mfma_f32_16x16x4_f32 kernel of passes up to 256 rows) */
+#define HQT_LAYOUT_SPLIT 4  /* fp16 hi / lo planes (SPLIT precision on the stage-2 entry points) */
+#define HQT_LAYOUT_ALL 7
 #define HQT_DEPTH_PARALLEL_ADD 0
 #define HQT_DEPTH_PARALLEL 1
 #define HQT_DEPTH_PARALLEL_REDUCE 2
@@ -149,6 +159,20 @@ int hqt_clone(hqt_handle* src, hqt_handle** out);
  * to fp32 summation order in FAST arithmetic (EXACT arithmetic does not use these kernels). */
 enum { HQT_POLICY_LATENCY = 0, HQT_POLICY_THROUGHPUT = 1 };
 int hqt_set_policy(hqt_handle* h, int policy);
+
+/* hqt_set_switch -- two choices of launch sequence that do not change what is computed beyond fp32 summation order (no reference
+ * counterpart; A/B runs and tests).  Both are part of the graph key: the next hqt_sample re-captures if one changed.
+ *   HQT_SWITCH_PERSIST     1 (default): FAST hqt_sample of up to 64 rows on a root handle runs a top position as ONE persistent launch
+ *                          (csrc/persist.h); 0: the launch chain.  The default is 0 when HQT_PERSIST=0 was in the environment at hqt_create
+ *                          -- the environment is read there, once, never per call.  A handle whose persistent launch gave up
+ *                          (hqt_range_check) switches itself to 0; setting 1 re-arms it.
+ *   HQT_SWITCH_SINGLE_KEY  1 (default): depth sub-step 0 (one query over one key) skips the query third of the fused GEMM and the
+ *                          attention launch, bit-identically; 0: the long way round (default 0 when HQT_NO_SINGLE_KEY was set at hqt_create). */
+/*   HQT_SWITCH_PERSIST_FAULT  test hook (0 = none, the default): on = c + 1 makes compute unit c withhold its first grid-barrier signal in every
+ *                          later persistent launch, so the launch gives up after its time limit (tests/test_gpu_persist.py).  A device word, not
+ *                          part of the graph key: a cached graph replays it.  Synchronises the device. */
+enum { HQT_SWITCH_PERSIST = 0, HQT_SWITCH_SINGLE_KEY = 1, HQT_SWITCH_PERSIST_FAULT = 2 };
+int hqt_set_switch(hqt_handle* h, int which, int on);
 
 /* hqt_sample -- replaces sampling_ihqgpt + iHQGPT.sampling_step (hqvae/utils/sampling.py:164-237,
  * hierarchical_ar.py:428-480, 482-563, 667-789) for a batch of B independent images.
@@ -246,8 +270,10 @@ int hqt_decode_seq(hqt_handle* h, int B, const int64_t* codes_top, const int64_t
  * position as ONE persistent launch that needs every compute unit of the device resident at once (hqtransformer_amd/csrc/persist.h); every
  * spin in it is bounded (1 s), and a launch that could not finish -- the GPU is shared with something that keeps compute units busy --
  * marks the handle instead of hanging: HQT_ERR_STATE here ("... gave up at the grid barrier in front of phase p"), the codes of that call
- * are invalid, later launches return at once until this call has cleared the mark.  HQT_PERSIST=0 in the environment selects the
- * launch chain instead. */
+ * are invalid, later launches return at once until this call has cleared the mark -- and the handle then takes the launch chain
+ * (hqt_set_switch(h, HQT_SWITCH_PERSIST, 1) re-arms the persistent launch).  Persistent launches of ALL handles of a process on one
+ * device are ordered behind each other (an event chain inside the library), so two root handles sampling on two streams both finish.
+ * hqt_set_switch(h, HQT_SWITCH_PERSIST, 0), or HQT_PERSIST=0 in the environment at hqt_create, selects the launch chain from the start. */
 int hqt_range_check(hqt_handle* h, void* stream);
 
 /* introspection */

@@ -38,7 +38,7 @@ def test_struct_layout_matches_header():
     import ctypes as C
     import subprocess
     import tempfile
-    checks = {'hqt_config': ['abi_version', 'has_stage1', 's1_ch_mult', 's1_attn_res', 'max_batch', 'code_levels'],
+    checks = {'hqt_config': ['abi_version', 'has_stage1', 's1_ch_mult', 's1_attn_res', 'max_batch', 'code_levels', 'depth_decoding', 'ar_layouts'],
               'hqt_sample_opts': ['precision', 'top_p_top', 'seed', 'sample_offset', 'use_graph', 'row_seeds', 'row_offsets'],
               'hqt_sample_opts_l3': ['top_k', 'top_p', 'temperature', 'seed', 'use_graph', 'row_seeds', 'row_offsets'],
               'hqt_encode_out': ['codes', 'quant', 'resid', 'recon', 'diff']}

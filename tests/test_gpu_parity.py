@@ -242,21 +242,21 @@ def test_fast_wide_passes_up_to_4096_rows(tiny_cls):
 def test_fast_single_key_shortcut_is_bit_identical(tiny_cls):
     """Depth sub-step 0 attends to exactly one key, so its attention output is the value row: the FAST path skips the
     query third of the fused GEMM and the attention launch.  softmax of one score is exactly 1.0, hence logits and
-    codes must be BIT-identical to the long way round (HQT_NO_SINGLE_KEY=1)."""
+    codes must be BIT-identical to the long way round (hqt_set_switch(HQT_SWITCH_SINGLE_KEY, 0))."""
     import os
     fx, spec, weights, eng = tiny_cls
     B, n = int(fx['B']), 8
     noise = torch.from_numpy(synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:n])
-    os.environ['HQT_PERSIST'] = '0'              # the launch chain's claim (the persistent chain of round 5 has no long way round: tests/test_gpu_persist.py)
+    eng.set_persist(False)                       # the launch chain's claim (the persistent chain of round 5 has no long way round: tests/test_gpu_persist.py)
     try:
         a = eng.sample(B, torch.full((B,), 3), n, precision=PRECISION_FAST, noise=noise, return_logits=True, use_graph=False)
-        os.environ['HQT_NO_SINGLE_KEY'] = '1'
+        eng.set_single_key(False)
         try:
             b = eng.sample(B, torch.full((B,), 3), n, precision=PRECISION_FAST, noise=noise, return_logits=True, use_graph=False)
         finally:
-            del os.environ['HQT_NO_SINGLE_KEY']
+            eng.set_single_key(True)
     finally:
-        del os.environ['HQT_PERSIST']
+        eng.set_persist(True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.equal(a[2], b[2])
 

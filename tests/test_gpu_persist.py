@@ -4,7 +4,7 @@ FAST precision, up to 64 samples, decode steps, root engine under the latency po
 launch, depth sub-step 0 + head_top as a second one (stage2/layers.py:324-328,61-195; hierarchical_ar.py:554-563,684-702).  Both
 forms compute the same bf16 arithmetic with different summation orders (the persistent kernel splits K over four waves and, for
 mlp.2, over four CUs), so they are compared teacher-forced within a few bf16 ulps of the logits, and each is held to the FAST gate
-against the fp32 oracle.  HQT_PERSIST=0 selects the launch chain (read per call; part of the graph key).
+against the fp32 oracle.  Engine.set_persist(False) (hqt_set_switch) selects the launch chain (part of the graph key; the environment variable HQT_PERSIST is read once, at hqt_create).
 """
 import os
 
@@ -34,12 +34,15 @@ def engine_s2(spec, weights, max_batch, max_steps=None):
 
 
 class chain_only:
-    """Context: HQT_PERSIST=0 (the launch chain)."""
+    """Context: the launch chain on this engine (hqt_set_switch(HQT_SWITCH_PERSIST, 0)), persistent launches again afterwards."""
+    def __init__(self, eng):
+        self.eng = eng
+
     def __enter__(self):
-        os.environ['HQT_PERSIST'] = '0'
+        self.eng.set_persist(False)
 
     def __exit__(self, *a):
-        del os.environ['HQT_PERSIST']
+        self.eng.set_persist(True)
 
 
 def imagenet_spec():
@@ -61,7 +64,7 @@ def test_tiny_model_persistent_vs_chain_and_exact(B):
     noise = torch.from_numpy(synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:n])
     cond = torch.full((B,), 7)
     ct, cb, lg_e = eng.sample(B, cond, n, precision=PRECISION_EXACT, noise=noise, return_logits=True, use_graph=False)
-    with chain_only():
+    with chain_only(eng):
         _, _, lg_c = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, force_top=ct, force_bot=cb, return_logits=True, use_graph=False)
     for graph in (False, True):
         pt, pb, lg_p = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, force_top=ct, force_bot=cb, return_logits=True, use_graph=graph)
@@ -87,7 +90,7 @@ def test_persistent_launches_are_what_runs():
     assert rep['persist_position'][0] == n and 'persist_body' not in rep and rep.get('layernorm', (0,))[0] == 0, rep
     # what is left of the chain: depth sub-step 1 (4 blocks x 4 GEMMs) + head_bot per position
     assert rep['gemm_qkv'][0] == 4 * n and rep['gemm_head'][0] == n, {k: v[0] for k, v in rep.items()}
-    with chain_only():
+    with chain_only(eng):
         eng.timing_reset()
         eng.timing(True)
         eng.sample(B, cond, n, precision=PRECISION_FAST, seed=3, use_graph=False)
@@ -110,7 +113,7 @@ def test_full_benchmark_model_persistent_vs_chain_and_oracle():
     eng = engine_s2(s2, weights, B, 8)
     kw = dict(precision=PRECISION_FAST, noise=torch.from_numpy(noise), force_top=torch.from_numpy(want[0]), force_bot=torch.from_numpy(want[1]),
               return_logits=True)
-    with chain_only():
+    with chain_only(eng):
         _, _, lc = eng.sample(B, torch.from_numpy(cond), n, use_graph=True, **kw)
     _, _, lp = eng.sample(B, torch.from_numpy(cond), n, use_graph=True, **kw)
     _, _, lp2 = eng.sample(B, torch.from_numpy(cond), n, use_graph=False, **kw)
@@ -138,7 +141,7 @@ def test_full_sampling_run_persistent_vs_chain(B):
     a = eng.sample(B, cond, n, precision=PRECISION_FAST, seed=21, use_graph=True)
     b = eng.sample(B, cond, n, precision=PRECISION_FAST, seed=21, use_graph=True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), 'two persistent runs with one seed differ'
-    with chain_only():
+    with chain_only(eng):
         c = eng.sample(B, cond, n, precision=PRECISION_FAST, seed=21, use_graph=True)
     assert int(a[0].min()) >= 0 and int(a[0].max()) < s2.vocab_top and int(a[1].min()) >= 0 and int(a[1].max()) < s2.vocab_bot
     first = (a[0][:, 0] == c[0][:, 0]).float().mean().item()       # position 0 sees identical inputs in both forms
@@ -161,7 +164,7 @@ def test_three_level_model_runs_its_body_persistently():
     eng = engine_s2(spec, weights, 4)
     cond = torch.full((B,), 7)
     ex = eng.sample3(B, cond, n, precision=PRECISION_EXACT, noise=noise, force=force, return_logits=True, use_graph=False)
-    with chain_only():
+    with chain_only(eng):
         ch = eng.sample3(B, cond, n, precision=PRECISION_FAST, noise=noise, force=force, return_logits=True, use_graph=False)
     eng.timing(True)
     eng.timing_reset()
@@ -176,31 +179,119 @@ def test_three_level_model_runs_its_body_persistently():
     eng.range_check()
 
 
-def test_a_launch_that_cannot_finish_gives_up_and_says_so():
-    """Every spin of the persistent kernel is bounded (1 s).  HQT_PERSIST_FAULT=1 makes CU 0 withhold its first grid-barrier signal: the
-    other CUs must give up instead of hanging the GPU, every later launch of the call must return at once (the mark of the first one is
-    still set: no second per launch), range_check must report it -- and after that the same engine samples correctly again."""
+@pytest.mark.parametrize('graph', [False, True])
+def test_a_launch_that_cannot_finish_gives_up_and_says_so(graph):
+    """Every spin of the persistent kernel is bounded (1 s).  The fault hook (hqt_set_switch(HQT_SWITCH_PERSIST_FAULT, 1): a device word) makes
+    CU 0 withhold its first grid-barrier signal: the other CUs must give up instead of hanging the GPU, every later launch of the call must
+    return at once (the mark of the first one is still set: no second per launch), range_check must report it -- eager AND on a cache-hit
+    REPLAY of a hipGraph after a clean check (round 5 marked the handle only while capturing: a replay that gave up went unreported and
+    returned garbage codes with HQT_OK) -- and after that the handle takes the launch chain by itself: the same engine samples correctly
+    again, bit-identical to the launch chain."""
     import time
     from hqtransformer_amd import _lib
     fx = load('g4_tiny_cls.npz')
     spec, weights = stage2_from_fixture(fx)
-    eng = engine_s2(spec, weights, 8)
     B, n = 4, 16
     noise = torch.from_numpy(synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:n])
     cond = torch.full((B,), 7)
-    good = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=False)
-    eng.range_check()
-    os.environ['HQT_PERSIST_FAULT'] = '1'
-    try:
-        t0 = time.perf_counter()
-        eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=False)
-        torch.cuda.synchronize()
-        took = time.perf_counter() - t0
-    finally:
-        del os.environ['HQT_PERSIST_FAULT']
+    eng = engine_s2(spec, weights, 8)
+    with chain_only(eng):
+        chain = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=graph)
+    good = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=graph)       # (graph: captures the persistent graph and replays it)
+    eng.range_check()                                                                           # clean: resets the handle's "persistent work pending" mark
+    eng.set_persist_fault(1)
+    t0 = time.perf_counter()
+    eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=graph)              # graph: a pure replay of the cached graph
+    torch.cuda.synchronize()
+    took = time.perf_counter() - t0
     assert 0.5 < took < 10.0, f'{took:.2f} s: one bounded wait (1 s), not one per launch ({2 * n} launches) and not a hang'
     with pytest.raises(_lib.HqtError, match='gave up at the grid barrier'):
         eng.range_check()
-    again = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=False)
+    # the handle fell back to the launch chain by itself: correct codes, no second time-out, although the fault is still armed
+    t0 = time.perf_counter()
+    again = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=graph)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5
     eng.range_check()
-    assert torch.equal(again[0], good[0]) and torch.equal(again[1], good[1])
+    assert torch.equal(again[0], chain[0]) and torch.equal(again[1], chain[1])
+    # re-armed and healthy again: the persistent launch runs and draws what it drew before
+    eng.set_persist_fault(0)
+    eng.set_persist(True)
+    back = eng.sample(B, cond, n, precision=PRECISION_FAST, noise=noise, use_graph=graph)
+    eng.range_check()
+    assert torch.equal(back[0], good[0]) and torch.equal(back[1], good[1])
+
+
+def test_two_root_handles_sampling_concurrently_both_finish():
+    """Two ImageGPT2-sized root engines on two streams, batch 64 each, FAST: each persistent launch needs all 256 compute units, so two in
+    flight at once would keep each other out until both time out (round 5: HQT_ERR_STATE on both).  The library orders persistent work of
+    all handles of a process on a device behind each other (engine.hip: PersistOrder): both calls finish, neither reports a give-up, and
+    each draws what it draws alone."""
+    s2 = imagenet_spec()
+    w = synth.stage2_weights(s2, 0, 'bench')
+    a, b = engine_s2(s2, w, 64, 8), engine_s2(s2, w, 64, 8)
+    B, n = 64, 8
+    cond = torch.from_numpy(synth.class_ids(5, B, s2.n_classes))
+    alone_a = a.sample(B, cond, n, precision=PRECISION_FAST, seed=3)
+    torch.cuda.synchronize()
+    alone_b = b.sample(B, cond, n, precision=PRECISION_FAST, seed=4)
+    torch.cuda.synchronize()
+    a.range_check(); b.range_check()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        with torch.cuda.stream(sa):
+            ra = a.sample(B, cond, n, precision=PRECISION_FAST, seed=3)
+        with torch.cuda.stream(sb):
+            rb = b.sample(B, cond, n, precision=PRECISION_FAST, seed=4)
+        outs.append((ra, rb))
+    torch.cuda.synchronize()
+    a.range_check(); b.range_check()                     # raises if a launch gave up
+    for ra, rb in outs:
+        assert torch.equal(ra[0], alone_a[0]) and torch.equal(ra[1], alone_a[1])
+        assert torch.equal(rb[0], alone_b[0]) and torch.equal(rb[1], alone_b[1])
+    rep = None
+    a.timing(True)
+    a.sample(B, cond, 2, precision=PRECISION_FAST, seed=3, use_graph=False)
+    rep = a.timing_report()
+    a.timing(False)
+    assert rep['persist_position'][0] == 2, 'the persistent launch is what ran'
+
+
+def test_fast_only_replica_holds_fewer_layouts_and_refuses_the_others():
+    """hqt_config.ar_layouts = HQT_LAYOUT_FAST: FAST sampling is bit-identical to a full engine's, EXACT still runs (from the fp32 tensors as
+    received), SPLIT fails loudly with HQT_ERR_STATE; the device memory the replica takes is visibly smaller."""
+    from hqtransformer_amd import _lib
+    fx = load('g4_tiny_cls.npz')
+    spec, weights = stage2_from_fixture(fx)
+    B, n = 4, 8
+    noise = torch.from_numpy(synth.exp_noise(int(fx['noise_seed']), 64, B, spec.vocab_top)[:n])
+    cond = torch.full((B,), 7)
+    full = engine_s2(spec, weights, 8)
+    lean = Engine(spec, None, dev(), 8, spec.ctx_len_img, ar_layouts=_lib.LAYOUT_FAST)
+    lean.load(stage2=weights)
+    lean.finalize()
+    for prec in (PRECISION_FAST, PRECISION_EXACT):
+        x = full.sample(B, cond, n, precision=prec, noise=noise, return_logits=True)
+        y = lean.sample(B, cond, n, precision=prec, noise=noise, return_logits=True)
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2])
+    with pytest.raises(_lib.HqtError, match='HQT_LAYOUT_SPLIT'):
+        lean.sample(B, cond, n, precision=_lib.PRECISION_SPLIT, noise=noise)
+    full.range_check(); lean.range_check()
+    # the ImageNet-12L model: free memory before / after each build
+    s2 = imagenet_spec()
+    w = synth.stage2_weights(s2, 0, 'bench')
+    del full, lean
+    torch.cuda.synchronize()
+    sizes = {}
+    for name, mask in (('fast_only', _lib.LAYOUT_FAST), ('all', 0)):
+        torch.cuda.empty_cache()
+        free0 = torch.cuda.mem_get_info()[0]
+        e = Engine(s2, None, dev(), 64, 8, ar_layouts=mask)
+        e.load(stage2=w)
+        e.finalize()
+        torch.cuda.synchronize()
+        sizes[name] = (free0 - torch.cuda.mem_get_info()[0]) / 2 ** 30
+        e.close()
+    print('device memory of one ImageNet-12L stage-2 replica (GiB):', {k: round(v, 2) for k, v in sizes.items()})
+    assert sizes['fast_only'] < 0.7 * sizes['all'], sizes
