@@ -472,10 +472,13 @@ def main():
     pipe.drain()
     barrier()
     elapsed_lanes = time.perf_counter() - t0
+    elapsed_ranks = [elapsed_lanes]                # per-rank wall time of the timed region (skew visibility: one slow box vs the gather)
     if dist is not None:
         t = torch.tensor([elapsed_lanes], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_lanes = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        elapsed_ranks = [float(x.item()) for x in allt]
+        elapsed_lanes = max(elapsed_ranks)         # the contract's MAX over ranks
     # what the host itself spends per step: one more pass submitted into EMPTY queues (untimed), so that nothing throttles the submitting thread
     # (at most 8 steps: a pass of 32 steps is > 4000 launches, more than the HIP queues take without blocking the submitter -- measured 26 ms
     # "per step" that way, all of it waiting; the first, untimed round captures the graph of that row count)
@@ -546,7 +549,8 @@ def main():
     exact_mode = None
     if fast and not args.no_exact_mode and not args.positions:
         xprec = dec_prec if dec_prec != 'fast' else 'split'
-        what = {'exact': 'EXACT: fp32 weights / activations / accumulation on the vector ALUs -- codes bit-identical to the oracle (tests/test_gpu_timed_schedule.py)',
+        what = {'exact': 'EXACT: fp32 weights / activations / accumulation -- every nn.Linear of up to 256 rows on the fp32 MATRIX instructions (exact_mfma_gemm_kernel: v_mfma_f32_16x16x4_f32, '
+                         'bitwise an fmaf chain), larger ones on the vector ALUs (gemm_tile_kernel) -- codes bit-identical to the oracle (tests/test_gpu_timed_schedule.py)',
                 'split': 'SPLIT API: the EXACT launch sequence with every nn.Linear on the matrix cores -- up to 256 rows per GEMM the fp32 matrix instructions (exact_mfma_gemm_kernel: the SAME '
                          'kernels as `exact`, so a one-step-at-a-time record of `split` times what `exact` times), above 256 rows fp16 hi / lo operands with 3 MFMAs per term '
                          '(split_gemm_kernel); fp32 accumulation, LayerNorm, attention, softmax and sampler -- codes bit-identical to the oracle wherever the draw is well-conditioned '
@@ -558,6 +562,8 @@ def main():
             ex['ar_gemm_kernels'] = ('exact_mfma_gemm_kernel (fp32 matrix instructions): every AR GEMM of a batch-%d step has <= 256 rows' % B) if 4 * B <= 256 else (
                 'split_gemm_kernel above 256 rows, exact_mfma_gemm_kernel up to 256' if arp == 'split' else 'gemm_tile_kernel above 256 rows, exact_mfma_gemm_kernel up to 256')
             ex['note'] = '3 batch-%d steps one at a time on one lane' % B
+            if 4 * B <= 256:
+                ex['same_kernels_as'] = 'split.like_for_like and exact.like_for_like launch the SAME kernels at this batch (every GEMM <= 256 rows): two timings of one thing'
             rec = {'like_for_like': ex}
             if merge > 1:
                 m_ex = merge if arp == 'split' else min(merge, 16)
@@ -577,7 +583,7 @@ def main():
                 del xp
             exact_mode[arp] = rec
         exact_mode['note'] = ('the arithmetic whose code sequences are bit-identical to the reference CPU path (north_star): `split` = fp32-accurate on the matrix cores, '
-                              '`exact` = fp32 FMA chains on the vector ALUs; same workload, same decode; the headline `value` runs the tolerance-gated bf16 AR loop')
+                              '`exact` = fp32 arithmetic throughout (fp32 matrix instructions up to 256 rows, vector ALUs above); same workload, same decode; the headline `value` runs the tolerance-gated bf16 AR loop')
     elapsed = elapsed_lanes
 
     out = None
@@ -617,6 +623,8 @@ def main():
             # bit-exactness against the reference's CPU path holds for the fp32 AR loop (--precision exact, the `exact_mode` record) only; the timed arithmetic is tolerance-gated
             'bit_exact_codes': (not fast),
             'gather_ok': (None if dist is None else (args.gather == gather_requested)),
+            # per rank: wall time of the timed region between the two barriers and the images/s of that rank alone; `value` is world * B * K / max(elapsed_s_ranks)
+            'elapsed_s_ranks': [round(v, 4) for v in elapsed_ranks], 'value_ranks': [round(B * args.steps / v, 2) for v in elapsed_ranks],
             'host_ms_per_step': max(host_ms_ranks), 'host_ms_per_step_ranks': host_ms_ranks,
             'host_ms_per_step_unthrottled': round(1000 * host_free_s, 3),
             'host_ms_note': 'host_ms_per_step = wall time until the last step of the timed region was handed to HIP / steps -- the runtime blocks (spins) the submitting thread '

@@ -34,24 +34,29 @@ enum { TS_QKV = 0, TS_PACKED = 1, TS_RESID = 2, TS_ROWS = 3, TS_SLAB = 4 };
 #define HQT_TILE_STAGGER 1
 #endif
 
-template <int WGM_, int WGN_, int MBW_, int NT_, int KU_, int NSTAGE_>
+// NLOAD_ > 0 (round 6): NLOAD_ further waves do nothing but the LDS-DMA of the ring (loader waves), the WGM x WGN waves only read fragments and
+// multiply: a `buffer_load ... lds` piece costs its wave 60 .. 180 ISSUE cycles (the texture path takes 64 B/clk), and a wave issues in order -- in the
+// all-consumer form every stage opens with CPW such pieces in front of the matrix instructions of the wave that issues them.
+template <int WGM_, int WGN_, int MBW_, int NT_, int KU_, int NSTAGE_, int NLOAD_ = 0>
 struct TileGeom {
-    static constexpr int WGM = WGM_, WGN = WGN_, MBW = MBW_, NT = NT_, KU = KU_, NSTAGE = NSTAGE_;
-    static constexpr int NW = WGM * WGN;                       // waves per workgroup
+    static constexpr int WGM = WGM_, WGN = WGN_, MBW = MBW_, NT = NT_, KU = KU_, NSTAGE = NSTAGE_, NLOAD = NLOAD_;
+    static constexpr int NC = WGM * WGN;                       // consumer waves (wave tile (32 MBW) x (32 NT))
+    static constexpr int NW = NC + NLOAD;                      // waves per workgroup
+    static constexpr int NDMA = NLOAD ? NLOAD : NC;            // waves that issue the ring's DMA
     static constexpr int BM = 32 * MBW * WGM, BN = 32 * NT * WGN;
     static constexpr int ACH = BM / 32, WCH = BN / 32;         // 1-KiB fragments per k-step
     static constexpr int CPS = ACH + WCH;
     static constexpr int CH_STAGE = KU * CPS;
-    static constexpr int CPW = CH_STAGE / NW;                  // LDS-DMA instructions per wave per stage
+    static constexpr int CPW = CH_STAGE / NDMA;                // LDS-DMA instructions per issuing wave per stage
     static constexpr int STAGE_BYTES = CH_STAGE * 1024;
     static constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
-    static constexpr int GR = NW * 64 / BM;                    // threads per row in the statistics prologue
+    static constexpr int GR = NC * 64 / BM;                    // threads per row in the statistics prologue (consumer waves)
     // after the ring: (mean, rstd) per row, (bias, colsum) per column, prologue scratch
     static constexpr int AUX_BYTES = BM * 8 + BN * 8 + GR * BM * 8;
     static constexpr int LDS_BYTES = RING_BYTES + AUX_BYTES;
     static constexpr int WG_PER_CU = NW == 4 ? (160 * 1024 / LDS_BYTES < 4 ? 160 * 1024 / LDS_BYTES : 4) : (LDS_BYTES <= 80 * 1024 ? 2 : 1);   // by LDS; 4-wave workgroups up to 4 per CU
-    static_assert(CH_STAGE % NW == 0, "every wave issues the same number of DMA pieces per stage");
-    static_assert(NW * 64 % BM == 0 && GR >= 1, "statistics prologue: whole thread groups per row");
+    static_assert(CH_STAGE % NDMA == 0, "every issuing wave issues the same number of DMA pieces per stage");
+    static_assert(NC * 64 % BM == 0 && GR >= 1, "statistics prologue: whole thread groups per row");
     static_assert(WGN * BM * 8 <= RING_BYTES, "residual epilogue: per-wave partial statistics fit the dead ring");
 };
 
@@ -111,7 +116,7 @@ template <class G, int STORE, bool DLN, typename TC>
 __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_gemm_kernel(GemmArgs g, const char* __restrict__ wpk,
                                                                                               float* __restrict__ slabs, int TM, int TN) {
 #if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins have no host-side declaration: the host pass sees an empty body)
-    constexpr int WGM = G::WGM, MBW = G::MBW, NT = G::NT, KU = G::KU, NSTAGE = G::NSTAGE, NW = G::NW;
+    constexpr int WGM = G::WGM, MBW = G::MBW, NT = G::NT, KU = G::KU, NSTAGE = G::NSTAGE, NW = G::NW, NC = G::NC, NLOAD = G::NLOAD, NDMA = G::NDMA;
     constexpr int BM = G::BM, BN = G::BN, ACH = G::ACH, CPS = G::CPS, CPW = G::CPW, STAGE = G::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     float* const meanrstd = reinterpret_cast<float*>(lds + G::RING_BYTES);        // [BM][2]
@@ -123,6 +128,8 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wm = wave % WGM, wn = wave / WGM;
+    const bool loader = NLOAD > 0 && wave >= NC;                                  // wave-uniform
+    const int dw = NLOAD > 0 ? max(wave - NC, 0) : wave;                          // index among the DMA-issuing waves
     const int total = TM * TN;
     const int S = gridDim.x / total;
     int z, tile_m, tile_n;                                                        // z: split-K slice (TS_SLAB)
@@ -140,12 +147,12 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, 0xFFFFFFFF, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wpk), 0, 0xFFFFFFFF, 0x00020000);
     constexpr int NA = KU * ACH;                                  // A fragments per stage
-    static_assert(NA % NW == 0, "pieces 0 .. NA / NW - 1 of every wave are A fragments, the rest W fragments");
+    static_assert(NA % NDMA == 0, "pieces 0 .. NA / NDMA - 1 of every issuing wave are A fragments, the rest W fragments");
     unsigned off[CPW], dstoff[CPW];
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
-        const int f = i * NW + wave;
-        if (i < NA / NW) {
+        const int f = i * NDMA + dw;
+        if (i < NA / NDMA) {
             const int ku = f / ACH, r = f - ku * ACH;
             off[i] = (unsigned)(((size_t)(ks_lo + ku) * MB + min(tile_m * ACH + r, MB - 1)) * 1024);
             dstoff[i] = (ku * CPS + r) * 1024;
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             char* dst = lds + slot * STAGE + dstoff[i];                              // wave-uniform; the hardware adds 16 * lane
-            if (i < NA / NW) {
+            if (i < NA / NDMA) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, lane16, off[i], 0, 0);
                 off[i] += stepA;
             } else {
@@ -194,14 +201,16 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     constexpr int NPL = 6;                                        // one round covers 12 partials (a 128-column-tile producer at D = 1536)
     float2 pv[NPL];
     const int pr = threadIdx.x % BM, pgi = threadIdx.x / BM;
-    if (DLN) {
+    if (DLN && !loader) {
         const float2* base = reinterpret_cast<const float2*>(g.ln_parts) + min(m0 + pr, MB * 32 - 1);
 #pragma unroll
         for (int i = 0; i < NPL; ++i) pv[i] = base[(size_t)min(pgi + i * G::GR, g.ln_nparts - 1) * (MB * 32)];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (NLOAD == 0 || loader) {                                  // (wave-uniform; with loader waves the consumers issue no DMA at all)
 #pragma unroll
-    for (int s = 0; s < NSTAGE; ++s) issue(s);                   // unconditional (the launcher guarantees KT >= NSTAGE): behind a branch hipcc
+        for (int s = 0; s < NSTAGE; ++s) issue(s);               // unconditional (the launcher guarantees KT >= NSTAGE): behind a branch hipcc
+    }
     __builtin_amdgcn_sched_barrier(0);                           // would count none of them as younger than the small loads and drain the ring
     if (STORE != TS_SLAB && (int)threadIdx.x < BN) {
         colb[pc] = g.bias ? bias_r : 0.0f;
@@ -216,8 +225,10 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
             const float2* base = reinterpret_cast<const float2*>(g.ln_parts) + min(m0 + pr, MB * 32 - 1);
             for (int p0 = pgi + NPL * G::GR; p0 < g.ln_nparts; p0 += G::GR) { const float2 v = base[(size_t)p0 * (MB * 32)]; sm += v.x; sq += v.y; }
         }
-        scratch[2 * threadIdx.x] = sm;
-        scratch[2 * threadIdx.x + 1] = sq;
+        if (!loader) {
+            scratch[2 * threadIdx.x] = sm;
+            scratch[2 * threadIdx.x + 1] = sq;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // raw: __syncthreads() would drain the DMA in flight
         __builtin_amdgcn_sched_barrier(0);
@@ -264,7 +275,21 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
         else wait_vmcnt<0>();
     };
     const bool early = NW < 8 || wave < NW / 2 || HQT_TILE_STAGGER == 0;
-    wait_stage(NSTAGE - 1);
+    if (NLOAD > 0 && loader) {
+        // ---- loader waves: one barrier per stage, in step with the consumers' -- in front of barrier kt this wave's pieces of stage kt + 1 have
+        // landed (counted vmcnt: the NSTAGE - 2 younger stages stay in flight), behind it the consumers are done with stage kt: its slot is refilled
+        wait_stage(NSTAGE - 1);
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int kt = 0; kt < KT - 1; ++kt) {
+            wait_stage(min(NSTAGE - 2, KT - 2 - kt));
+            __builtin_amdgcn_s_barrier();
+            if (kt + NSTAGE < KT) issue(slot);
+            slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        }
+        return;                                                   // (a terminated wave no longer counts for the workgroup's barriers: the epilogue's are the consumers')
+    }
+    if (NLOAD == 0) wait_stage(NSTAGE - 1);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // no scalar load may be pending when the loop is entered: lgkmcnt also counts them, they return out of order, and with one
@@ -291,14 +316,14 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
             } else {
                 const int nxt = rd + 1 == NSTAGE ? 0 : rd + 1;
                 if (!LAST) {
-                    wait_stage(min(NSTAGE - 2, KT - 2 - kt));
+                    if (NLOAD == 0) wait_stage(min(NSTAGE - 2, KT - 2 - kt));
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of stage kt are in registers
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     // An LDS-DMA piece costs its wave 60 .. 180 issue cycles.  Waves w and w + 4 share a SIMD: the lower half refills
                     // the slot right behind the barrier, the upper half after this k-step's MFMAs, so that one of the two always
                     // has matrix work in the pipe (all eight issuing together left it idle ~400 cycles per stage).
-                    if (early && kt + NSTAGE < KT) issue(rd);
+                    if (NLOAD == 0 && early && kt + NSTAGE < KT) issue(rd);
                     if (cur1) read_frags(std::integral_constant<int, 0>{}, nxt, 0);
                     else read_frags(std::integral_constant<int, 1>{}, nxt, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -306,7 +331,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
                 if (cur1) multiply(std::integral_constant<int, 1>{});
                 else multiply(std::integral_constant<int, 0>{});
                 __builtin_amdgcn_sched_barrier(0);
-                if (!LAST && !early && kt + NSTAGE < KT) issue(rd);
+                if (NLOAD == 0 && !LAST && !early && kt + NSTAGE < KT) issue(rd);
                 __builtin_amdgcn_sched_barrier(0);
                 rd = nxt;
             }
@@ -342,7 +367,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     const int Mc = g.c_packed_mb * 32;
     constexpr int WCOLS = 32 * NT, PITCH = WCOLS + 4;                  // floats; +4: the 8 lanes of a ds_write_b128 group land on 8 distinct 4-bank sets
     float* const stg = reinterpret_cast<float*>(lds) + wave * (32 * PITCH);
-    static_assert(NW * 32 * PITCH * 4 <= G::RING_BYTES, "staging patches fit the ring");
+    static_assert(NC * 32 * PITCH * 4 <= G::RING_BYTES, "staging patches fit the ring");
     float mean[MBW], rstd[MBW];
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
@@ -477,8 +502,8 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     if (STORE == TS_RESID) {
         // row statistics of this tile's BN columns: lanes l and l ^ 32 hold the two halves of a row's columns within a wave,
         // the WGN waves of a row block meet in LDS (behind the staging patches); fixed order -> deterministic
-        float* red = reinterpret_cast<float*>(lds) + NW * 32 * PITCH;  // [WGN][BM][2]
-        static_assert((NW * 32 * PITCH + G::WGN * BM * 2) * 4 <= G::RING_BYTES, "statistics scratch fits behind the staging patches");
+        float* red = reinterpret_cast<float*>(lds) + NC * 32 * PITCH;  // [WGN][BM][2]
+        static_assert((NC * 32 * PITCH + G::WGN * BM * 2) * 4 <= G::RING_BYTES, "statistics scratch fits behind the staging patches");
 #pragma unroll
         for (int i = 0; i < MBW; ++i) {
             const float a = rs[i] + __shfl_xor(rs[i], 32, 64), b = rq[i] + __shfl_xor(rq[i], 32, 64);
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
             }
         }
         __syncthreads();
-        for (int r = threadIdx.x; r < BM; r += NW * 64) {
+        for (int r = threadIdx.x; r < BM; r += NC * 64) {
             float a = 0.0f, b = 0.0f;
 #pragma unroll
             for (int w = 0; w < G::WGN; ++w) { a += red[2 * (w * BM + r)]; b += red[2 * (w * BM + r) + 1]; }
@@ -567,6 +592,8 @@ typedef TileGeom<2, 2, 1, 2, 2, 3> Tile64;
 // the ring depth (6 stages in flight instead of 2 measured within 1 %: profiles/r04_tile_variants.txt) -- what paces it is the ISSUE of its
 // LDS-DMA pieces, ~150 cycles per 1-KiB piece and wave; eight waves issue the same pieces twice as fast.
 typedef TileGeom<2, 4, 1, 1, 4, 3> Tile64W8;
+// 128 x 128 with FOUR loader waves beside the four multiplying waves (round 6): 4 stages of 32 k (64 KiB ring, two workgroups per CU)
+typedef TileGeom<2, 2, 2, 2, 2, 4, 4> Tile128PC;
 typedef TileGeom<2, 2, 1, 1, 4, 3> Tile64x64;     // 64 x 64, 4 waves of 32 x 32, stages of 64 k: 48 KiB ring, three workgroups per CU (proj at 640 rows: tile_gemm_plan)
 
 template <class G, int STORE, bool DLN, typename TC>
@@ -645,6 +672,7 @@ hipError_t launch_tile_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int 
     if (p.geom == 1) return launch_tile_g<Tile64>(gg, wpk, c_dt, p.S, slabs, st);
     if (p.geom == 2) return launch_tile_g<Tile64W8>(gg, wpk, c_dt, p.S, slabs, st);
     if (p.geom == 3) return launch_tile_g<Tile64x64>(gg, wpk, c_dt, p.S, slabs, st);
+    if (p.geom == 4) return launch_tile_g<Tile128PC>(gg, wpk, c_dt, p.S, slabs, st);
     return hipErrorInvalidValue;
 }
 
@@ -683,5 +711,6 @@ hipError_t tile_gemm_configure() {
     if (e == hipSuccess) e = configure_g<Tile64>();
     if (e == hipSuccess) e = configure_g<Tile64W8>();
     if (e == hipSuccess) e = configure_g<Tile64x64>();
+    if (e == hipSuccess) e = configure_g<Tile128PC>();
     return e;
 }

@@ -127,6 +127,9 @@ def test_bench_eight_ranks_control_flow_on_one_gpu():
     assert d['n_gpus'] == 8 and d['config']['global_batch'] == 8 * d['config']['per_gpu_batch'] and d['scaling'] == 'weak'
     assert d['config']['gather'].startswith(('pixels', 'none (requested gather failed')), d['config']['gather']
     assert len(d['host_ms_per_step_ranks']) == 8 and all(v > 0 for v in d['host_ms_per_step_ranks']) and d['value'] > 0
+    # skew visibility: every rank's own wall time and images/s travel with the max-over-ranks line
+    assert len(d['elapsed_s_ranks']) == 8 and len(d['value_ranks']) == 8 and all(v > 0 for v in d['value_ranks'])
+    assert abs(d['value'] - 8 * d['config']['per_gpu_batch'] * d['steps'] / max(d['elapsed_s_ranks'])) <= 0.02 * d['value']
     print('8 ranks on one GPU: host ms per step per rank', d['host_ms_per_step_ranks'], 'unthrottled', d.get('host_ms_per_step_unthrottled'))
 
 

@@ -125,7 +125,7 @@ int main(int argc, char** argv) {
                 };
                 GemmArgs g = make_args(M, sh);
 #define RUN(G, what) { CK(hipMemsetAsync(b.y, 0xff, (size_t)M * sh.N * 4, st)); launch_raw<G, TS_ROWS, false, float>(g, wpk, 1, nullptr, st); cmp(what); }
-                RUN(Tile256, "256x256 k64 x2") RUN(Tile256k3, "256x256 k64 x2") RUN(Tile128, "128x128 k32 x3") RUN(Tile128k4, "128x128 k64 x2") RUN(Tile256x128, "256x128 k64 x3") RUN(Tile256x128k4, "256x128 k64 x3")
+                RUN(Tile128PC, "128x128 k32 x4 + 4 loaders") RUN(Tile256, "256x256 k64 x2") RUN(Tile256k3, "256x256 k64 x2") RUN(Tile128, "128x128 k32 x3") RUN(Tile128k4, "128x128 k64 x2") RUN(Tile256x128, "256x128 k64 x3") RUN(Tile256x128k4, "256x128 k64 x3")
 #undef RUN
                 // split-K slabs + combine against ref + x32 (+ bias)
                 if (sh.N == 1536) {
@@ -198,7 +198,7 @@ int main(int argc, char** argv) {
         std::vector<bf16_t*> w(nbuf);
         fill_kernel<<<1024, 256, 0, st>>>(w32, (size_t)sh.N * sh.K, 99u, 0.05f);
         for (auto& p : w) { CK(hipMalloc(&p, bytes)); CK(launch_pack_stream_weights(w32, p, sh.N, sh.K, st)); }
-        for (int M : {512, 640, 1280, 5120}) {
+        for (int M : {640, 1280, 2560}) {
             const int MB = packed_mb(M);
             pack_rows_kernel<<<1024, 256, 0, st>>>(b.x_rows, b.xpk, M, sh.K, MB);
             const double gf = 2.0 * M * sh.N * sh.K * 1e-9;
@@ -207,9 +207,10 @@ int main(int argc, char** argv) {
             auto report = [&](const char* what, float t) { printf("   %-44s %8.2f us  %6.0f TFLOP/s\n", what, t, gf / t * 1e3); };
 #define T(G, what) report(what, time_us(st, nbuf, [&](int i) { launch_raw<G, TS_ROWS, false, float>(g, w[i], 1, nullptr, st); }));
             T(Tile256, "256x256 k64 x2, fp32 rows") T(Tile256k3, "256x256 k32 x4 , fp32 rows") T(Tile128, "128x128 k32 x3 (3/CU), fp32 rows") T(Tile128k4, "128x128 k64 x2, fp32 rows")
+            T(Tile128PC, "128x128 k32 x4 + 4 loader waves, fp32 rows")
             T(Tile256x128, "256x128 k64 x3, fp32 rows") T(Tile256x128k4, "256x128 k32 x4 , fp32 rows") T(Tile128s3, "128x128 k32 x3 (k32 x4: 2/CU), fp32 rows")
 #undef T
-            if (M == 640 || M == 1280 || M == 5120) {
+            if (M == 640 || M == 1280 || M == 2560) {
                 // in-kernel stamps of one launch: cycles to the first landed stage, main loop, epilogue; wall span of the grid
                 auto stamps = [&](const char* what, int wgs, const std::function<void(GemmArgs&)>& run) {
                     GemmArgs gs = g;
@@ -238,6 +239,8 @@ int main(int argc, char** argv) {
                 stamps("128x128 k32 x3 rows", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 k32 x3 rows (k32 x4: 2/CU)", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128s3, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 k32 x3 packed bf16", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
+                stamps("128x128 PC rows", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128PC, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
+                stamps("128x128 PC packed bf16", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128PC, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 k32 x3 packed bf16 (k32 x4: 2/CU)", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128s3, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
             }
             // the store modes the AR loop uses, default geometries
@@ -247,6 +250,8 @@ int main(int argc, char** argv) {
                 GemmArgs gp = gd; gp.C = b.cpk; gp.store = STORE_PACKED; gp.c_packed_mb = MB; gp.act = ACT_GELU_ERF;
                 report("256x256 DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile256, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
                 report("128x128 DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile128, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
+                report("128x128 PC DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile128PC, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
+                report("64x128 W8 DLN + GELU + packed bf16 (product@640)", time_us(st, nbuf, [&](int i) { launch_raw<Tile64W8, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
                 gp.ln_nparts = 1;
                 report("256x256 DLN(1 part) + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile256, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
             } else {
