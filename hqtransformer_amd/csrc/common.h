@@ -155,6 +155,7 @@ struct GemmArgs {
     //      through C3 in the same kernel.)
     bf16_t* resid_pk;
     float* resid_parts;
+    unsigned* tile_ctr;      // split-K residual producers finished inside the launch (tile_gemm.hip: TS_FUSED): one arrival counter per output tile, zero between launches
     // ---- STORE_ARGMIN (nearest-code search, quantizer.py:99-103): d = (am_rownorm[m] + am_colnorm[n]) - 2 acc; the winner per row is
     //      kept as atomicMin over (float_order_key(d) << 32 | n) in am_best[m] (ties -> lowest n, as torch.argmin on equal values)
     const float* am_rownorm;

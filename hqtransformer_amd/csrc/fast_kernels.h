@@ -25,6 +25,7 @@ hipError_t launch_stream_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, in
 // S > 1 (STORE_RESID only): fp32 partial slabs [S][32 * a_packed_mb][N], finished by launch_resid_combine (x += bias + sum of
 // slabs, bf16 packed copy, whole-row statistics as ONE part).
 struct TilePlan { int geom; int bm, bn; int S; };    // geom < 0: not taken; S: split-K factor
+constexpr int TILE_CTR_MAX = 4096;          // output tiles of one TS_FUSED launch (GemmArgs.tile_ctr; tools/micro/bench_tile only: measured and lost, tile_gemm.hip)
 bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt);
 TilePlan tile_gemm_plan(const GemmArgs& g);
 hipError_t launch_tile_gemm(const GemmArgs& g, const bf16_t* wpk, int a_dt, int c_dt, const TilePlan& p, float* slabs, hipStream_t st);

@@ -29,7 +29,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum { TS_QKV = 0, TS_PACKED = 1, TS_RESID = 2, TS_ROWS = 3, TS_SLAB = 4 };
+enum { TS_QKV = 0, TS_PACKED = 1, TS_RESID = 2, TS_ROWS = 3, TS_SLAB = 4,
+       TS_FUSED = 5 };    // split-K residual producer finished INSIDE the launch (round 6): every slice stores its fp32 partial tile write-through, takes a ticket on the
+                          // tile's counter, and the workgroup that draws the last one sums the S partials in slice order and runs the TS_RESID epilogue on the sum --
+                          // no resid_combine_kernel launch, no second pass over the slabs from a cold start; nobody waits (MI355X_MICROARCH.md: valid forms, counter row)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #ifndef HQT_TILE_STAGGER
 #define HQT_TILE_STAGGER 1
 #endif
@@ -70,9 +74,12 @@ __device__ __forceinline__ float gelu_erf_fast(float v) {
     const float e = 1.0f - poly * __expf(-x * x);                 // erf(|v| / sqrt 2)
     return 0.5f * v + 0.5f * fabsf(v) * e;
 }
-__device__ __forceinline__ float tile_act(float v, int act) {
-    if (act == ACT_GELU_ERF) return gelu_erf_fast(v);
-    if (act == ACT_GELU_SIGMOID) return v / (1.0f + __expf(-1.702f * v));
+// The activation is a TEMPLATE parameter of the kernel (round 6): as a run-time field of GemmArgs hipcc kept three scalar branches PER ELEMENT in the
+// epilogue (293 branches in the 128 x 128 kernel; in-kernel stamps: 17 k of a workgroup's 50 k cycles went into "issuing" 64 values per lane, with or without an
+// activation selected -- taken branches and the instruction fetches behind them, not arithmetic).
+template <int ACT> __device__ __forceinline__ float tile_act(float v) {
+    if (ACT == ACT_GELU_ERF) return gelu_erf_fast(v);
+    if (ACT == ACT_GELU_SIGMOID) return v / (1.0f + __expf(-1.702f * v));
     return v;
 }
 
@@ -112,7 +119,7 @@ __device__ __forceinline__ void tile_of(int b, int total, int S, int TM, int TN,
     tm = first + in_group - tn * rows;
 }
 
-template <class G, int STORE, bool DLN, typename TC>
+template <class G, int STORE, bool DLN, typename TC, int ACT = ACT_NONE>
 __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_gemm_kernel(GemmArgs g, const char* __restrict__ wpk,
                                                                                               float* __restrict__ slabs, int TM, int TN) {
 #if defined(__HIP_DEVICE_COMPILE__)     // (the buffer-resource builtins have no host-side declaration: the host pass sees an empty body)
@@ -123,7 +130,8 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     float* const colb = meanrstd + 2 * BM;                                        // [BN] bias, [BN] column sums
     float* const scratch = colb + 2 * BN;                                         // [GR][BM][2]
 #ifdef HQT_TILE_STAMPS
-    long long stamp[5];
+    long long stamp[8];
+    stamp[5] = stamp[6] = stamp[7] = 0;
     stamp[0] = wall_clock64(); stamp[1] = clock64();
 #endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -381,11 +389,22 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     bf16_t* const qkv_base = reinterpret_cast<bf16_t*>(qkv_part == 0 ? g.C : (qkv_part == 1 ? g.C2 : g.C3));
     bf16_t* const qkv_vcopy = (STORE == TS_QKV && qkv_part == 2) ? g.qkv_v_pk : nullptr;
     float* const slab_out = STORE == TS_SLAB ? slabs + (size_t)z * (MB * 32) * g.N : nullptr;
+    const auto rs_slab = __builtin_amdgcn_make_buffer_rsrc(STORE == TS_FUSED ? slabs : nullptr, 0, 0xFFFFFFFF, 0x00020000);
+    const unsigned slab_stride = (unsigned)((size_t)(MB * 32) * g.N * 4);          // bytes between two slices' slabs (the launcher keeps S slabs under 4 GiB)
     float rs[MBW], rq[MBW];
 #pragma unroll
     for (int i = 0; i < MBW; ++i) rs[i] = rq[i] = 0.0f;
     const int wcol0 = n0 + wn * WCOLS;                                 // first column of this wave (the launcher guarantees N % BN == 0)
     if (STORE != TS_PACKED) __syncthreads();                           // every wave is past its last fragment read: the ring is dead
+    static_assert(STORE != TS_FUSED || (!DLN && G::NLOAD >= 0), "TS_FUSED: plain residual producers");
+#ifdef HQT_TILE_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    stamp[5] = clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    auto run_epilogue = [&](auto mode_c, auto from_slabs_c) {
+    constexpr int MODE = decltype(mode_c)::value;                  // the store mode of this pass over the tile (TS_FUSED: TS_SLAB, then TS_RESID in the last arriver)
+    constexpr bool FROM_SLABS = decltype(from_slabs_c)::value;
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
         const int mrow0 = m0 + (wm * MBW + i) * 32;
@@ -394,9 +413,10 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
+                if (FROM_SLABS) continue;                              // (second phase of TS_FUSED: the values are the sum of the slabs, fetched on the row-major side)
                 const int cl = j * 32 + 8 * q4 + 4 * h;                // column inside the wave's WCOLS
                 float v[4];
-                if (STORE == TS_SLAB) {
+                if (MODE == TS_SLAB) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * q4 + e];
                 } else {
@@ -409,45 +429,78 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
                         v[e] = t * g.alpha + b4[e];
                     }
                 }
-                if (STORE == TS_PACKED) {
+                if (MODE == TS_PACKED) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = tile_act(v[e], g.act);
+                    for (int e = 0; e < 4; ++e) v[e] = tile_act<ACT>(v[e]);
                     if (mrow0 + c < g.M) st4<bf16_t>(reinterpret_cast<bf16_t*>(g.C) + packed_off(mrow0 + c, wcol0 + cl, g.c_packed_mb), v);
                     continue;
                 }
-                if (STORE == TS_ROWS) {
+                if (MODE == TS_ROWS) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = tile_act(v[e], g.act);
+                    for (int e = 0; e < 4; ++e) v[e] = tile_act<ACT>(v[e]);
                 }
                 if (qkv_vcopy && mrow0 + c < g.M) st4<bf16_t>(qkv_vcopy + packed_off(mrow0 + c, wcol0 + cl - qkv_part_local * g.qkv_D, g.c_packed_mb), v);
                 *reinterpret_cast<f32x4*>(stg + c * PITCH + cl) = f32x4{v[0], v[1], v[2], v[3]};
             }
-        if (STORE == TS_PACKED) continue;
+        if (MODE == TS_PACKED) continue;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // the patch is exchanged between the lanes of this wave only: LDS
         __builtin_amdgcn_wave_barrier();                               // operations of a wave execute in order, the compiler must keep that order
         // ---- row-major side: a lane holds 16 bytes of one output row
-        if (STORE == TS_SLAB || STORE == TS_RESID || (STORE == TS_ROWS && sizeof(TC) == 4)) {
+        if (MODE == TS_SLAB || MODE == TS_RESID || (MODE == TS_ROWS && sizeof(TC) == 4)) {
             constexpr int LPR = WCOLS / 4, RPP = 64 / LPR, NP = 32 / RPP;         // lanes per row, rows per pass, passes
             const int cg = (lane % LPR) * 4, r0 = lane / LPR;
-            float* const out = STORE == TS_SLAB ? slab_out : reinterpret_cast<float*>(g.C);
-            const int ldo = STORE == TS_SLAB ? g.N : g.ldc;
+            float* const out = MODE == TS_SLAB ? slab_out : reinterpret_cast<float*>(g.C);
+            const int ldo = MODE == TS_SLAB ? g.N : g.ldc;
             f32x4 x0[NP];
-            if (STORE == TS_RESID) {                                   // the residual rows, all passes in flight together
+            if (MODE == TS_RESID) {                                   // the residual rows, all passes in flight together
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const int m = min(mrow0 + p * RPP + r0, g.M - 1);
                     x0[p] = *reinterpret_cast<const f32x4*>(out + (size_t)m * ldo + wcol0 + cg);
                 }
             }
+            if (FROM_SLABS) {
+                // TS_FUSED, last arriver: value = bias + sum over the S slices' partial tiles in slice order (what resid_combine_kernel computed: x += sum + bias).
+                // Write-through stores on the producers' side, sc1 loads here (every load of the handed-off bytes), behind the ticket: no fence.
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(colb + wn * WCOLS + cg);
+                constexpr int HP = NP / 2;                             // two rounds of NP / 2 passes: S x NP / 2 16-byte loads in flight per lane
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) {
+                    u32x4 pz[8][HP];
+#pragma unroll
+                    for (int p = 0; p < HP; ++p) {
+                        const int m = min(mrow0 + (hp * HP + p) * RPP + r0, g.M - 1);
+                        const unsigned boff = (unsigned)(((size_t)m * g.N + wcol0 + cg) * 4);
+#pragma unroll
+                        for (int zz = 0; zz < 8; ++zz)
+                            if (zz < S) pz[zz][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, boff + (unsigned)zz * slab_stride, 0, 16);
+                    }
+#pragma unroll
+                    for (int p = 0; p < HP; ++p) {
+                        const int r = (hp * HP + p) * RPP + r0, m = mrow0 + r;
+                        f32x4 sum = __builtin_bit_cast(f32x4, pz[0][p]);
+#pragma unroll
+                        for (int zz = 1; zz < 8; ++zz)
+                            if (zz < S) sum += __builtin_bit_cast(f32x4, pz[zz][p]);     // fixed slice order
+                        f32x4 v = x0[hp * HP + p];
+                        v += sum + b4;
+                        *reinterpret_cast<f32x4*>(stg + r * PITCH + cg) = v;
+                        if (m < g.M) *reinterpret_cast<f32x4*>(out + (size_t)m * ldo + wcol0 + cg) = v;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int r = p * RPP + r0, m = mrow0 + r;
                 f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * PITCH + cg);
-                if (STORE == TS_RESID) {
+                if (MODE == TS_RESID) {
                     v += x0[p];
                     *reinterpret_cast<f32x4*>(stg + r * PITCH + cg) = v;            // the new residual row goes back for the packed copy below
                 }
-                if (m < g.M) *reinterpret_cast<f32x4*>(out + (size_t)m * ldo + wcol0 + cg) = v;
+                if (MODE == TS_SLAB && STORE == TS_FUSED) {            // write-through: the last arriver of this tile reads these bytes inside this launch
+                    if (m < g.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_slab, (unsigned)(((size_t)m * g.N + wcol0 + cg) * 4) + (unsigned)z * slab_stride, 0, 16);
+                } else if (m < g.M) *reinterpret_cast<f32x4*>(out + (size_t)m * ldo + wcol0 + cg) = v;
+            }
             }
         } else {                                                       // bf16 rows: fused [query; key; value] or plain
             constexpr int LPR = WCOLS / 8, RPP = 64 / LPR, NP = 32 / RPP;
@@ -462,7 +515,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
                 pk.z = (unsigned)f32_to_bf16(b[0]) | ((unsigned)f32_to_bf16(b[1]) << 16);
                 pk.w = (unsigned)f32_to_bf16(b[2]) | ((unsigned)f32_to_bf16(b[3]) << 16);
                 if (m >= g.M) continue;
-                if (STORE == TS_QKV) {
+                if (MODE == TS_QKV) {
                     long long row = m;
                     if (qkv_part > 0) row = (long long)(m / g.rows_per_group) * g.group_stride + m % g.rows_per_group + g.row_offset + qkv_row_dev;
                     *reinterpret_cast<uint4*>(qkv_base + row * g.ldc + (wcol0 + cg - qkv_part_local * g.qkv_D)) = pk;
@@ -473,7 +526,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (STORE == TS_RESID) {
+        if (MODE == TS_RESID) {
             // back on the accumulator side: bf16 packed copy of the new residual rows for the next GEMM + their partial statistics
 #pragma unroll
             for (int j = 0; j < NT; ++j)
@@ -499,7 +552,31 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (STORE == TS_RESID) {
+    };
+    if (STORE != TS_FUSED) run_epilogue(std::integral_constant<int, STORE>{}, std::false_type{});
+    else {
+        run_epilogue(std::integral_constant<int, TS_SLAB>{}, std::false_type{});
+        // ---- ticket: every storing wave drains its write-through stores, then ONE lane adds to the tile's counter; the value the add returns tells who was last
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* const ctr = g.tile_ctr + (tile_m * TN + tile_n);
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1u == (unsigned)S) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // all S have arrived: clean for the next launch
+            reinterpret_cast<volatile unsigned*>(scratch)[0] = t;
+        }
+        __syncthreads();
+        const unsigned ticket = reinterpret_cast<volatile unsigned*>(scratch)[0];
+        if (ticket + 1u != (unsigned)S) return;
+        __syncthreads();                                               // (the patches are rewritten below)
+        run_epilogue(std::integral_constant<int, TS_RESID>{}, std::true_type{});
+    }
+#ifdef HQT_TILE_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    stamp[6] = clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if (STORE == TS_RESID || STORE == TS_FUSED) {
         // row statistics of this tile's BN columns: lanes l and l ^ 32 hold the two halves of a row's columns within a wave,
         // the WGN waves of a row block meet in LDS (behind the staging patches); fixed order -> deterministic
         float* red = reinterpret_cast<float*>(lds) + NC * 32 * PITCH;  // [WGN][BM][2]
@@ -528,6 +605,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         long long* dbg = reinterpret_cast<long long*>(g.am_best) + (size_t)blockIdx.x * 8;
         dbg[0] = stamp[0]; dbg[1] = stamp[2] - stamp[1]; dbg[2] = stamp[3] - stamp[1]; dbg[3] = clock64() - stamp[1]; dbg[4] = wall_clock64();
+        dbg[5] = stamp[5] - stamp[1]; dbg[6] = stamp[6] - stamp[1];
     }
 #endif
 #endif
@@ -596,11 +674,21 @@ typedef TileGeom<2, 4, 1, 1, 4, 3> Tile64W8;
 typedef TileGeom<2, 2, 2, 2, 2, 4, 4> Tile128PC;
 typedef TileGeom<2, 2, 1, 1, 4, 3> Tile64x64;     // 64 x 64, 4 waves of 32 x 32, stages of 64 k: 48 KiB ring, three workgroups per CU (proj at 640 rows: tile_gemm_plan)
 
-template <class G, int STORE, bool DLN, typename TC>
+template <class G, int STORE, bool DLN, typename TC, int ACT = ACT_NONE>
 static hipError_t launch_tile_t(const GemmArgs& g, const bf16_t* wpk, int S, float* slabs, hipStream_t st) {
     const int TM = (g.M + G::BM - 1) / G::BM, TN = (g.N + G::BN - 1) / G::BN;
-    tile_gemm_kernel<G, STORE, DLN, TC><<<TM * TN * S, G::NW * 64, G::LDS_BYTES, st>>>(g, reinterpret_cast<const char*>(wpk), slabs, TM, TN);
+    tile_gemm_kernel<G, STORE, DLN, TC, ACT><<<TM * TN * S, G::NW * 64, G::LDS_BYTES, st>>>(g, reinterpret_cast<const char*>(wpk), slabs, TM, TN);
     return hipGetLastError();
+}
+// STORE_PACKED (the only store mode the AR loop pairs with an activation: mlp.0 + GELU): one instantiation per activation
+template <class G, bool DLN>
+static hipError_t launch_tile_packed(const GemmArgs& g, const bf16_t* wpk, hipStream_t st) {
+    switch (g.act) {
+    case ACT_NONE: return launch_tile_t<G, TS_PACKED, DLN, bf16_t, ACT_NONE>(g, wpk, 1, nullptr, st);
+    case ACT_GELU_ERF: return launch_tile_t<G, TS_PACKED, DLN, bf16_t, ACT_GELU_ERF>(g, wpk, 1, nullptr, st);
+    case ACT_GELU_SIGMOID: return launch_tile_t<G, TS_PACKED, DLN, bf16_t, ACT_GELU_SIGMOID>(g, wpk, 1, nullptr, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <class G>
@@ -609,7 +697,7 @@ static hipError_t launch_tile_g(const GemmArgs& g, const bf16_t* wpk, int c_dt, 
     if (S > 1) return launch_tile_t<G, TS_SLAB, false, float>(g, wpk, S, slabs, st);
     switch (g.store) {
     case STORE_QKV: return dln ? launch_tile_t<G, TS_QKV, true, bf16_t>(g, wpk, 1, nullptr, st) : launch_tile_t<G, TS_QKV, false, bf16_t>(g, wpk, 1, nullptr, st);
-    case STORE_PACKED: return dln ? launch_tile_t<G, TS_PACKED, true, bf16_t>(g, wpk, 1, nullptr, st) : launch_tile_t<G, TS_PACKED, false, bf16_t>(g, wpk, 1, nullptr, st);
+    case STORE_PACKED: return dln ? launch_tile_packed<G, true>(g, wpk, st) : launch_tile_packed<G, false>(g, wpk, st);
     case STORE_RESID: return launch_tile_t<G, TS_RESID, false, float>(g, wpk, 1, nullptr, st);
     case STORE_ROWS:
         if (c_dt == DT_F32) return dln ? launch_tile_t<G, TS_ROWS, true, float>(g, wpk, 1, nullptr, st) : launch_tile_t<G, TS_ROWS, false, float>(g, wpk, 1, nullptr, st);
@@ -623,12 +711,13 @@ static hipError_t launch_tile_g(const GemmArgs& g, const bf16_t* wpk, int c_dt, 
 bool tile_gemm_ok(const GemmArgs& g, int a_dt, int c_dt) {
     if (!(g.a_packed_mb >= 16 && a_dt == DT_BF16 && !g.conv_taps && g.batch <= 1 && g.M >= 512)) return false;
     if (g.N % 128 != 0 || g.K % 32 != 0 || g.K < 256 || g.ldc % 8 != 0 || g.resid) return false;
+    if (g.act != ACT_NONE && g.store != STORE_PACKED) return false;
     if (g.store == STORE_QKV) return c_dt == DT_BF16 && g.qkv_D % 128 == 0 && g.rows_per_group > 0;
     if (g.store == STORE_PACKED) return c_dt == DT_BF16 && g.c_packed_mb > 0;
     // (proj, K = D: one short K loop over 48 column-tile rows.  Below 640 rows the streaming kernel's 64-row tiles win (23.5 vs 25.2 us at 512 rows); from 640
     //  rows the 8-wave 64 x 128 tiles do (27.8 -> 24.9 us at 640, 30.0 -> 26.8 at 768, 37.5 -> 29.3 at 1024))
     if (g.store == STORE_RESID) return c_dt == DT_F32 && g.c_packed_mb > 0 && !g.ln_parts && g.resid_pk && g.resid_parts && g.N == g.ldc && (g.K >= 3072 || g.M >= 640);
-    if (g.store == STORE_ROWS) return g.rows_per_group == 0;
+    if (g.store == STORE_ROWS) return g.rows_per_group == 0 && g.act == ACT_NONE;      // (the activation is a template parameter, instantiated for STORE_PACKED only)
     return false;
 }
 
@@ -642,6 +731,11 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
     // every CU gets one, half the matrix work per workgroup: 18.9 -> 16.5 ms per pass (1024 rows: 384 such tiles lose to 192 of 64 x 128, 21.4 vs 19.4)
     if (g.store == STORE_RESID && g.K < 3072 && ((g.M + 63) / 64) * (g.N / 64) <= 256 && KS % Tile64x64::KU == 0 && KS / Tile64x64::KU >= 2 * Tile64x64::NSTAGE)
         return TilePlan{3, 64, 64, 1};
+    // one round of 128 x 128 tiles that fills most of the chip (640 rows: qkv 180, fc1 240 tiles): the loader-wave geometry -- in-kernel stamps at 640 rows
+    // (profiles/r06_micro_tile_gemm.txt): main loop 18.4 k cycles against 28.9 k for the all-consumer 128 x 128 tile, workgroup life 13.5-14 us against the
+    // 8-wave 64 x 128 tiles' grid span of 16.5-17 us (360 / 480 workgroups: two rounds on part of the chip)
+    if (g.store != STORE_RESID && tiles >= 160 && tiles <= 256 && KS % Tile128PC::KU == 0 && KS / Tile128PC::KU >= 2 * Tile128PC::NSTAGE)
+        return TilePlan{4, Tile128PC::BM, Tile128PC::BN, 1};
     if (g.store != STORE_RESID && tiles < 256 && KS / Tile64::KU >= Tile64::NSTAGE) {
         const int t64 = ((g.M + Tile64::BM - 1) / Tile64::BM) * (g.N / Tile64::BN);
         if (t64 <= 512 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE) return TilePlan{2, Tile64::BM, Tile64::BN, 1};
@@ -658,7 +752,15 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
         const int t64 = ((g.M + Tile64::BM - 1) / Tile64::BM) * (g.N / Tile64::BN);
         if (((t64 >= 176 && t64 <= 208) || (t64 >= 448 && t64 <= 512)) && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
             return TilePlan{2, Tile64::BM, Tile64::BN, 1};
-        if ((tiles * 4 <= 256 || tiles % 64 == 0) && KS % (Tile128::KU * 4) == 0 && KS / 4 / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = 4; return p; }
+        if ((tiles * 4 <= 256 || tiles % 64 == 0) && KS % (Tile128::KU * 4) == 0 && KS / 4 / Tile128::KU >= 2 * Tile128::NSTAGE) {
+            p.S = 4;
+            // one round (640 rows: 60 tiles x 4 slices = 240 workgroups): the loader-wave geometry (fc2 at 640 rows, GEMM + combine: 29.2 -> 26.6 us).
+            // Finishing the slices INSIDE the launch (TS_FUSED: write-through slabs, the tile's last arriver sums them) was built and measured in round 6 and LOSES:
+            // 47.1 us (59.1 on this geometry) against 26.6 -- 256 KB of dependent sc1 reads by one workgroup per tile behind 64 KB of write-through stores per workgroup
+            // (profiles/r06_micro_tile_fused.txt); the product never selects it, tools/micro/bench_tile still times and checks it.
+            if (tiles * 4 <= 256 && KS / 4 / Tile128PC::KU >= 2 * Tile128PC::NSTAGE) p.geom = 4;
+            return p;
+        }
         for (int S : {8, 6, 4, 3, 2})
             if (S <= max_s && tiles * S <= 576 && KS % (Tile128::KU * S) == 0 && KS / S / Tile128::KU >= 2 * Tile128::NSTAGE) { p.S = S; break; }
     }
@@ -689,9 +791,9 @@ hipError_t launch_resid_combine(const GemmArgs& g, const float* slabs, int S, hi
 }
 
 // every instantiation raises its dynamic-LDS limit once, outside stream capture
-template <class G, int STORE, bool DLN, typename TC>
+template <class G, int STORE, bool DLN, typename TC, int ACT = ACT_NONE>
 static hipError_t configure_one() {
-    void (*kernel)(GemmArgs, const char*, float*, int, int) = tile_gemm_kernel<G, STORE, DLN, TC>;
+    void (*kernel)(GemmArgs, const char*, float*, int, int) = tile_gemm_kernel<G, STORE, DLN, TC, ACT>;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
 }
 template <class G>
@@ -704,6 +806,9 @@ static hipError_t configure_g() {
     CFG(TS_RESID, false, float) CFG(TS_ROWS, true, float) CFG(TS_ROWS, false, float) CFG(TS_ROWS, true, bf16_t) CFG(TS_ROWS, false, bf16_t)
     CFG(TS_SLAB, false, float)
 #undef CFG
+    for (hipError_t e2 : {configure_one<G, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(), configure_one<G, TS_PACKED, false, bf16_t, ACT_GELU_ERF>(),
+                          configure_one<G, TS_PACKED, true, bf16_t, ACT_GELU_SIGMOID>(), configure_one<G, TS_PACKED, false, bf16_t, ACT_GELU_SIGMOID>()})
+        if (e2 != hipSuccess) return e2;
     return hipSuccess;
 }
 hipError_t tile_gemm_configure() {

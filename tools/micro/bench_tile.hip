@@ -70,10 +70,10 @@ struct Bufs {
     float *y, *ref, *x32, *parts, *parts_out, *colsum, *bias, *slabs;
 };
 
-template <class G, int STORE, bool DLN, typename TC>
+template <class G, int STORE, bool DLN, typename TC, int ACT = ACT_NONE>
 static void launch_raw(GemmArgs g, const bf16_t* w, int S, float* slabs, hipStream_t st) {
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_gemm_kernel<G, STORE, DLN, TC>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-    CK((launch_tile_t<G, STORE, DLN, TC>(g, w, S, slabs, st)));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(tile_gemm_kernel<G, STORE, DLN, TC, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    CK((launch_tile_t<G, STORE, DLN, TC, ACT>(g, w, S, slabs, st)));
 }
 
 int main(int argc, char** argv) {
@@ -95,6 +95,7 @@ int main(int argc, char** argv) {
     const Shape shapes[] = {{"qkv", 4608, 1536}, {"proj", 1536, 1536}, {"fc1", 6144, 1536}, {"fc2", 1536, 6144}, {"head", 8192, 1536}};
     float* w32; CK(hipMalloc(&w32, (size_t)NMAX * KMAX * 4));
     long long* dbg; CK(hipMalloc(&dbg, (size_t)8192 * 64));
+    unsigned* tile_ctr; CK(hipMalloc(&tile_ctr, TILE_CTR_MAX * 4)); CK(hipMemset(tile_ctr, 0, TILE_CTR_MAX * 4));
 
     auto make_args = [&](int M, const Shape& sh) {
         GemmArgs g{};
@@ -153,6 +154,44 @@ int main(int argc, char** argv) {
                             worst_s = std::max(worst_s, std::fabs(rs - hp[2 * m]));
                         }
                         printf("check %-5s M=%4d split-K %d + combine           max|err| %.3e, row-sum err %.3e %s\n", sh.name, M, S, worst, worst_s, worst <= 0.05 && worst_s < 0.05 ? "ok" : "FAIL");
+                    }
+                    // split-K finished inside the launch (TS_FUSED): against ref + x32 + bias, row sums over the 12 column-tile parts, packed copy; twice (the counters clean themselves)
+                    for (int rep = 0; rep < 4; ++rep) {
+                        const int S = 4;
+                        if ((sh.K / 16) % (2 * S * 4)) continue;
+                        GemmArgs gr = g;
+                        gr.C = b.y; gr.store = STORE_RESID; gr.resid_pk = b.respk; gr.resid_parts = b.parts_out; gr.c_packed_mb = MB; gr.bias = b.bias; gr.tile_ctr = tile_ctr;
+                        CK(hipMemcpyAsync(b.y, b.x32, (size_t)M * sh.N * 4, hipMemcpyDeviceToDevice, st));
+                        CK(hipMemsetAsync(b.slabs, 0xff, (size_t)S * MB * 32 * sh.N * 4, st));
+                        if (rep & 1) launch_raw<Tile128, TS_FUSED, false, float>(gr, wpk, S, b.slabs, st);
+                        else launch_raw<Tile128PC, TS_FUSED, false, float>(gr, wpk, S, b.slabs, st);
+                        const int np = sh.N / 128;
+                        std::vector<float> hx((size_t)M * sh.N), hb(sh.N), hp((size_t)np * MB * 32 * 2);
+                        CK(hipMemcpyAsync(hx.data(), b.x32, hx.size() * 4, hipMemcpyDeviceToHost, st));
+                        CK(hipMemcpyAsync(hb.data(), b.bias, hb.size() * 4, hipMemcpyDeviceToHost, st));
+                        CK(hipMemcpyAsync(hy.data(), b.y, hy.size() * 4, hipMemcpyDeviceToHost, st));
+                        CK(hipMemcpyAsync(hp.data(), b.parts_out, hp.size() * 4, hipMemcpyDeviceToHost, st));
+                        std::vector<bf16_t> hpk((size_t)MB * 32 * sh.N);
+                        CK(hipMemcpyAsync(hpk.data(), b.respk, hpk.size() * 2, hipMemcpyDeviceToHost, st));
+                        std::vector<unsigned> hc(TILE_CTR_MAX);
+                        CK(hipMemcpyAsync(hc.data(), tile_ctr, hc.size() * 4, hipMemcpyDeviceToHost, st));
+                        CK(hipStreamSynchronize(st));
+                        double worst = 0, worst_s = 0, worst_pk = 0;
+                        unsigned dirty = 0;
+                        for (unsigned v : hc) dirty |= v;
+                        for (int m = 0; m < M; ++m) {
+                            double rs = 0, ps = 0;
+                            for (int n = 0; n < sh.N; ++n) {
+                                const size_t i = (size_t)m * sh.N + n;
+                                worst = std::max(worst, (double)std::fabs(hy[i] - (hx[i] + hr[i] + hb[n])));
+                                rs += bf16_to_f32(f32_to_bf16(hy[i]));
+                                worst_pk = std::max(worst_pk, (double)std::fabs(bf16_to_f32(hpk[packed_off(m, n, MB)]) - bf16_to_f32(f32_to_bf16(hy[i]))));
+                            }
+                            for (int p = 0; p < np; ++p) ps += hp[((size_t)p * MB * 32 + m) * 2];
+                            worst_s = std::max(worst_s, std::fabs(rs - ps));
+                        }
+                        printf("check %-5s M=%4d split-K 4 FUSED %-10s          max|err| %.3e, row-sum err %.3e, packed copy err %.3e, counters %s %s\n", sh.name, M, (rep & 1) ? "128x128" : "128x128 PC", worst, worst_s, worst_pk,
+                               dirty ? "DIRTY" : "clean", worst <= 0.05 && worst_s < 0.05 && worst_pk == 0 && !dirty ? "ok" : "FAIL");
                     }
                     // in-kernel residual epilogue
                     for (int geo = 0; geo < 2; ++geo) {
@@ -220,16 +259,18 @@ int main(int argc, char** argv) {
                     std::vector<long long> h((size_t)wgs * 8);
                     CK(hipMemcpyAsync(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost, st));
                     CK(hipStreamSynchronize(st));
-                    std::vector<long long> pro, loop, epi, life;
+                    std::vector<long long> pro, loop, epi, life, e1, e2, e3;
                     long long t0 = LLONG_MAX, t1 = 0;
                     for (int i = 0; i < wgs; ++i) {
                         pro.push_back(h[i * 8 + 1]); loop.push_back(h[i * 8 + 2] - h[i * 8 + 1]); epi.push_back(h[i * 8 + 3] - h[i * 8 + 2]);
                         life.push_back(h[i * 8 + 4] - h[i * 8]);
+                        e1.push_back(h[i * 8 + 5] - h[i * 8 + 2]); e2.push_back(h[i * 8 + 6] - h[i * 8 + 5]); e3.push_back(h[i * 8 + 3] - h[i * 8 + 6]);
                         t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 4]);
                     }
                     auto med = [](std::vector<long long>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
                     printf("   stamps %-30s %4d wgs: prologue %6lld  loop %7lld  epilogue %6lld cycles (median); workgroup life %.2f us, grid span %.2f us\n",
                            what, wgs, med(pro), med(loop), med(epi), med(life) / 100.0, (t1 - t0) / 100.0);
+                    printf("          epilogue split: sync %lld, values + stores issued %lld, store drain %lld\n", med(e1), med(e2), med(e3));
                 };
                 // the product's 8-wave 64 x 128 geometry (two workgroups per CU): what a 640-row pass runs
                 stamps("64x128 8 waves k64 x3 rows", ((M + 63) / 64) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile64W8, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
@@ -248,12 +289,12 @@ int main(int argc, char** argv) {
             gd.ln_parts = b.parts; gd.ln_nparts = 6; gd.ln_colsum = b.colsum; gd.ln_eps = 1e-5f; gd.bias = b.bias;
             if (sh.N != 1536) {
                 GemmArgs gp = gd; gp.C = b.cpk; gp.store = STORE_PACKED; gp.c_packed_mb = MB; gp.act = ACT_GELU_ERF;
-                report("256x256 DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile256, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
-                report("128x128 DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile128, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
-                report("128x128 PC DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile128PC, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
-                report("64x128 W8 DLN + GELU + packed bf16 (product@640)", time_us(st, nbuf, [&](int i) { launch_raw<Tile64W8, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
+                report("256x256 DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile256, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
+                report("128x128 DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile128, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
+                report("128x128 PC DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile128PC, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
+                report("64x128 W8 DLN + GELU + packed bf16 (product@640)", time_us(st, nbuf, [&](int i) { launch_raw<Tile64W8, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
                 gp.ln_nparts = 1;
-                report("256x256 DLN(1 part) + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile256, TS_PACKED, true, bf16_t>(gp, w[i], 1, nullptr, st); }));
+                report("256x256 DLN(1 part) + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile256, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
             } else {
                 GemmArgs gr = g;
                 gr.C = b.x32; gr.store = STORE_RESID; gr.resid_pk = b.respk; gr.resid_parts = b.parts_out; gr.c_packed_mb = MB; gr.bias = b.bias;
@@ -266,6 +307,13 @@ int main(int argc, char** argv) {
                     report(name, time_us(st, nbuf, [&](int i) { launch_raw<Tile256, TS_SLAB, false, float>(gr, w[i], S, b.slabs, st); CK(launch_resid_combine(gr, b.slabs, S, st)); }));
                     snprintf(name, sizeof name, "128x128 split-K %d slabs + combine", S);
                     report(name, time_us(st, nbuf, [&](int i) { launch_raw<Tile128, TS_SLAB, false, float>(gr, w[i], S, b.slabs, st); CK(launch_resid_combine(gr, b.slabs, S, st)); }));
+                }
+                if ((sh.K / 16) % 32 == 0) {
+                    GemmArgs gf = gr; gf.tile_ctr = tile_ctr;
+                    report("128x128 split-K 4 FUSED (last arriver)", time_us(st, nbuf, [&](int i) { launch_raw<Tile128, TS_FUSED, false, float>(gf, w[i], 4, b.slabs, st); }));
+                    report("128x128 PC split-K 4 FUSED (last arriver)", time_us(st, nbuf, [&](int i) { launch_raw<Tile128PC, TS_FUSED, false, float>(gf, w[i], 4, b.slabs, st); }));
+                    report("128x128 PC split-K 4 slabs + combine", time_us(st, nbuf, [&](int i) { launch_raw<Tile128PC, TS_SLAB, false, float>(gr, w[i], 4, b.slabs, st); CK(launch_resid_combine(gr, b.slabs, 4, st)); }));
+                    report("64x64 residual epilogue (proj@640 today)", time_us(st, nbuf, [&](int i) { launch_raw<Tile64x64, TS_RESID, false, float>(gr, w[i], 1, nullptr, st); }));
                 }
                 report("combine alone (S = 4)", time_us(st, nbuf, [&](int i) { CK(launch_resid_combine(gr, b.slabs, 4, st)); }));
             }
