@@ -29,6 +29,21 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_GELU_SIGMOID) return v / (1.0f + __expf(-1.702f * v));
     return v;
 }
+// The same with the activation as a compile-time constant, and the dispatcher that turns the run-time field into one: hipcc keeps
+// `apply_act(v, g.act)` as two or three scalar branches PER ELEMENT of an unrolled epilogue (64 values per lane on a 128 x 128 tile:
+// in-kernel stamps put 14-19 k of a workgroup's cycles there, with or without an activation selected -- round 6, tile_gemm.hip).
+// dispatch_act runs `f(integral_constant<int, ACT>)`: ONE wave-uniform branch in front of the whole epilogue, three copies of its code.
+template <int ACT> __device__ __forceinline__ float apply_act_c(float v) {
+    if (ACT == ACT_GELU_ERF) return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    if (ACT == ACT_GELU_SIGMOID) return v / (1.0f + __expf(-1.702f * v));
+    return v;
+}
+template <int V> struct ActC { static constexpr int value = V; };
+template <class F> __device__ __forceinline__ void dispatch_act(int act, F&& f) {
+    if (act == ACT_GELU_ERF) f(ActC<ACT_GELU_ERF>{});
+    else if (act == ACT_GELU_SIGMOID) f(ActC<ACT_GELU_SIGMOID>{});
+    else f(ActC<ACT_NONE>{});
+}
 
 // Loads 4 consecutive k of A row `m` (already decoded) starting at k.
 template <typename TA>

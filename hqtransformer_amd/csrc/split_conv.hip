@@ -731,6 +731,8 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
         float* const Cw = qkv ? reinterpret_cast<float*>(part == 0 ? g.C : (part == 1 ? g.C2 : g.C3)) : Cb;
         const int ccol0 = ncol0 - part_local * (qkv ? g.qkv_D : 0);          // column inside the destination
         const bool remap = qkv && part > 0;
+        dispatch_act(act, [&](auto act_c) {                           // (the activation as a constant: gemm_generic.h)
+        constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int mrow0 = m0 + wm * 64 + i * 32;
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
                     const f32x4 bq = *reinterpret_cast<const f32x4*>(lbias + wn * 64 + cl);
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act((accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV) * g.alpha + bq[e], act);
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>((accm[i][j][4 * q4 + e] + accx[i][j][4 * q4 + e] * SPLIT_INV) * g.alpha + bq[e]);
                     *reinterpret_cast<f32x4*>(stg + fr * PITCH + cl) = v;
                 }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the patch is exchanged between the lanes of this wave only
@@ -768,6 +770,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(GemmArgs g, int a_lo
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();                           // the patch is rewritten by the next row block
         }
+        });
     } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

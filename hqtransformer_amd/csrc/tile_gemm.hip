@@ -743,6 +743,10 @@ TilePlan tile_gemm_plan(const GemmArgs& g) {
     }
     if (g.store == STORE_RESID && g.K < 3072 && tiles < 256 && KS % Tile64W8::KU == 0 && KS / Tile64W8::KU >= 2 * Tile64W8::NSTAGE)
         return TilePlan{2, Tile64::BM, Tile64::BN, 1};
+    // the wide-K residual producer when its 128 x 128 tiles are ONE round over most of the chip (fc2 at 2560 rows: 240 tiles): the loader-wave geometry without split-K --
+    // grid span 46 us against 60-69 for 480 tiles of 64 x 128 (profiles/r06_micro_tile_gemm.txt: main loop 73 k cycles against 115 k for the all-consumer 128 x 128 tile)
+    if (g.store == STORE_RESID && g.K >= 3072 && tiles >= 160 && tiles <= 256 && KS % Tile128PC::KU == 0 && KS / Tile128PC::KU >= 2 * Tile128PC::NSTAGE)
+        return TilePlan{4, Tile128PC::BM, Tile128PC::BN, 1};
     if (g.store == STORE_RESID && g.K >= 3072 && tiles < 256) {
         // The wide-K residual producer (fc2).  Measured per (geometry, S) at the row counts the schedules produce (profiles/r04_fc2_plans.txt; GEMM + combine,
         // ms per pass): what counts is whole ROUNDS of workgroups (128 x 128: one per CU, 8-wave 64 x 128: two) and the slab traffic of the combine.
