@@ -696,8 +696,16 @@ int persist_blocks_per_cu() {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(persist_kernel), 576, LDS_BYTES) != hipSuccess) return 0;
     return n;
 }
+// zeroes the barrier / quad counters in front of every launch.  A KERNEL, not hipMemsetAsync: inside a captured graph replayed on a stream other than the
+// null stream the memset node did not order the way a kernel node does (round 6, tools/diag_two_handles.py: a 16-position graph of the persistent position
+// replayed on a side stream drew different codes than on the null stream -- 19 % of them -- with nothing else running; one position per graph, eager launches
+// and the launch chain were fine).
+__global__ __launch_bounds__(256) void persist_zero_kernel(unsigned* counters) {
+    for (int i = threadIdx.x; i < PERSIST_COUNTER_BYTES / 4; i += 256) counters[i] = 0u;
+}
 hipError_t launch_persist(const PersistArgs& a, int ncu, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(a.counters, 0, PERSIST_COUNTER_BYTES, st);
+    persist_zero_kernel<<<1, 256, 0, st>>>(a.counters);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     persist_kernel<<<ncu, 576, LDS_BYTES, st>>>(a);
     return hipGetLastError();

@@ -231,6 +231,28 @@ def test_a_launch_that_cannot_finish_gives_up_and_says_so(graph):
     assert torch.equal(back[0], good[0]) and torch.equal(back[1], good[1])
 
 
+def test_graph_replay_on_a_side_stream_equals_the_null_stream():
+    """Round 6 found the persistent position drawing DIFFERENT codes when its captured graph (16 positions per graph) was replayed on a stream other
+    than the null stream -- nothing else running, no error reported: the counters were zeroed by a captured hipMemsetAsync node, which a side-stream
+    replay did not order like a kernel node (tools/diag_two_handles.py).  They are zeroed by a kernel now; this is the regression test."""
+    s2, _, eng = bench_model()
+    B, n = 64, 16
+    cond = torch.from_numpy(synth.class_ids(5, B, s2.n_classes))
+    ref = eng.sample(B, cond, n, precision=PRECISION_FAST, seed=3)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    x = torch.zeros(1 << 20, device=dev())
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            got = eng.sample(B, cond, n, precision=PRECISION_FAST, seed=3)
+        if rep:                                  # ... and beside unrelated kernels of another stream
+            for _ in range(100):
+                x.add_(1.0)
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), f'replay {rep} on a side stream differs from the null stream'
+    eng.range_check()
+
+
 def test_two_root_handles_sampling_concurrently_both_finish():
     """Two ImageGPT2-sized root engines on two streams, batch 64 each, FAST: each persistent launch needs all 256 compute units, so two in
     flight at once would keep each other out until both time out (round 5: HQT_ERR_STATE on both).  The library orders persistent work of
