@@ -614,13 +614,15 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
 // ---- split-K finish of a residual producer: x[m] += bias + sum_z slab[z][m]; bf16 packed copy; whole-row statistics (one part).
 // One workgroup per row, one 4-column group per thread and round; the S slab reads of a group are issued together (S is a
 // template parameter: a runtime loop made them S dependent round trips).
-template <int S>
-__global__ __launch_bounds__(256) void resid_combine_kernel(float* __restrict__ x, const float* __restrict__ slabs, const float* __restrict__ bias,
-                                                            bf16_t* __restrict__ xpk, float* __restrict__ parts, int M, int N, int slab_rows, int pk_mb) {
-    __shared__ float red[8];
+// NT threads: the launcher picks N / 4 rounded up to whole waves (384 at D = 1536: every thread exactly one 4-column group, all S + 1 loads of the row in flight
+// at once; with 256 threads half of them ran a second, dependent round), at most 1024.
+template <int S, int NT>
+__global__ __launch_bounds__(NT) void resid_combine_kernel(float* __restrict__ x, const float* __restrict__ slabs, const float* __restrict__ bias,
+                                                           bf16_t* __restrict__ xpk, float* __restrict__ parts, int M, int N, int slab_rows, int pk_mb) {
+    __shared__ float red[2 * (NT / 64)];
     const int m = blockIdx.x;
     float rs = 0.0f, rq = 0.0f;
-    for (int n4 = threadIdx.x * 4; n4 < N; n4 += 1024) {
+    for (int n4 = threadIdx.x * 4; n4 < N; n4 += NT * 4) {
         f32x4 p[S];
 #pragma unroll
         for (int zz = 0; zz < S; ++zz) p[zz] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(slabs + ((size_t)zz * slab_rows + m) * N + n4));
@@ -645,11 +647,15 @@ __global__ __launch_bounds__(256) void resid_combine_kernel(float* __restrict__ 
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { rs += __shfl_xor(rs, off, 64); rq += __shfl_xor(rq, off, 64); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = rs; red[4 + (threadIdx.x >> 6)] = rq; }
+    constexpr int NWV = NT / 64;
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = rs; red[NWV + (threadIdx.x >> 6)] = rq; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        parts[2 * m] = (red[0] + red[1]) + (red[2] + red[3]);
-        parts[2 * m + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { a += red[w]; b += red[NWV + w]; }      // fixed order
+        parts[2 * m] = a;
+        parts[2 * m + 1] = b;
     }
 }
 
@@ -786,7 +792,10 @@ hipError_t launch_resid_combine(const GemmArgs& g, const float* slabs, int S, hi
     float* x = reinterpret_cast<float*>(g.C);
     const int rows = g.a_packed_mb * 32;
     switch (S) {
-#define COMBINE(S_) case S_: resid_combine_kernel<S_><<<g.M, 256, 0, st>>>(x, slabs, g.bias, g.resid_pk, g.resid_parts, g.M, g.N, rows, g.c_packed_mb); break;
+#define COMBINE(S_) case S_:                                                                                                                          \
+        if (g.N == 1536) resid_combine_kernel<S_, 384><<<g.M, 384, 0, st>>>(x, slabs, g.bias, g.resid_pk, g.resid_parts, g.M, g.N, rows, g.c_packed_mb);     \
+        else resid_combine_kernel<S_, 256><<<g.M, 256, 0, st>>>(x, slabs, g.bias, g.resid_pk, g.resid_parts, g.M, g.N, rows, g.c_packed_mb);                 \
+        break;
     COMBINE(2) COMBINE(3) COMBINE(4) COMBINE(6) COMBINE(8)
 #undef COMBINE
     default: return hipErrorInvalidValue;

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything profiles/r05_* is made of, in one GPU-box call (outputs under gpurun_out/r04/; copy what is to be judged into profiles/).
+# Everything profiles/r06_* is made of, in one GPU-box call (outputs under gpurun_out/r06/; copy what is to be judged into profiles/).
 #   gpurun --timeout 3300 -- 'bash tools/collect_round_evidence.sh'
 set -u
-R=r05
+R=r06
 O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -60,8 +60,7 @@ timeout 300 python tools/split_step_probe.py > $O/split_step_probe.json 2>/dev/n
 # K slices of the SPLIT AR GEMMs, conv_out in one fp32 kernel
 (for v in "HQT_PERSIST=1" "HQT_PERSIST=0" "HQT_PERSIST=1" "HQT_PERSIST=0"; do echo -n "$v "; env $v timeout 300 python bench.py --merge 1 --inflight 1 --steps 12 --no-cpu-baseline --no-exact-mode --no-roofline | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['like_for_like']['phase_ms'])"; done
  for c in configs/cc15m-12l-txt.yaml configs/imagenet-12l-level3.yaml; do for v in "HQT_PERSIST=1" "HQT_PERSIST=0"; do echo -n "$c $v "; env $v timeout 400 python bench.py --config $c --merge 1 --inflight 1 --steps 8 --no-cpu-baseline --no-exact-mode --no-roofline | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['like_for_like']['phase_ms'])"; done; done) > $O/persist_ab.txt 2>/dev/null
-(for v in "A=default" "HQT_SPLIT_KSLICES_OFF=1"; do echo "$v"; env $v timeout 400 python tools/ar_pass_time.py --rows 640 1024 2048 --precision split --reps 1 --breakdown; echo; done) > $O/split_kslices_ab.txt 2>/dev/null
-(for v in "HQT_CONV_OUT_DIRECT=0" "HQT_SPLIT_PLANES_OUT=0" "A=default"; do echo "$v"; env $v timeout 300 python tools/bench_decode.py --precision split; echo; done) > $O/decode_conv_out_direct_ab.txt 2>/dev/null
+timeout 300 python tools/diag_two_handles.py > $O/diag_two_handles.txt 2>&1
 # the launch sequence of ONE batch-64 position under the profiler (graph off: one row per launch)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats64 -- python3 bench.py --merge 1 --inflight 1 --steps 4 --warmup 1 --no-cpu-baseline --no-exact-mode --no-roofline --no-graph --skip-decode > $O/bench_serial_under_rocprof.json 2> $O/bench_serial_under_rocprof.err
 python tools/prof_summary.py $O/stats64 40 > $O/kernel_stats_serial_batch64_ar_only.txt
@@ -69,7 +68,7 @@ rm -rf $O/stats64
 # ---- micro-benchmarks
 timeout 300 tools/micro/bench_split > $O/micro_split_conv_variants.txt 2>&1
 timeout 100 tools/micro/bench_split_gemm > $O/micro_split_gemm_1x1.txt 2>&1
-timeout 300 tools/micro/bench_tile > $O/micro_tile_gemm.txt 2>&1
+(timeout 200 tools/micro/bench_tile check | grep -E '^check'; timeout 300 tools/micro/bench_tile) > $O/micro_tile_gemm.txt 2>&1
 timeout 120 tools/micro/bench_fill > $O/micro_fill.txt 2>&1
 timeout 200 tools/micro/bench_split 64 order > $O/conv_tile_order.txt 2>&1
 timeout 300 tools/micro/bench_stream > $O/micro_stream_gemm.txt 2>&1
