@@ -388,6 +388,7 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
     const int qkv_part = qkv_part_local + g.qkv_first;
     bf16_t* const qkv_base = reinterpret_cast<bf16_t*>(qkv_part == 0 ? g.C : (qkv_part == 1 ? g.C2 : g.C3));
     bf16_t* const qkv_vcopy = (STORE == TS_QKV && qkv_part == 2) ? g.qkv_v_pk : nullptr;
+    const auto rs_qkv = __builtin_amdgcn_make_buffer_rsrc(qkv_base, 0, 0xFFFFFFFF, 0x00020000);
     float* const slab_out = STORE == TS_SLAB ? slabs + (size_t)z * (MB * 32) * g.N : nullptr;
     const auto rs_slab = __builtin_amdgcn_make_buffer_rsrc(STORE == TS_FUSED ? slabs : nullptr, 0, 0xFFFFFFFF, 0x00020000);
     const unsigned slab_stride = (unsigned)((size_t)(MB * 32) * g.N * 4);          // bytes between two slices' slabs (the launcher keeps S slabs under 4 GiB)
@@ -518,7 +519,12 @@ __global__ __launch_bounds__(G::NW * 64, (G::NW / 4) * G::WG_PER_CU) void tile_g
                 if (MODE == TS_QKV) {
                     long long row = m;
                     if (qkv_part > 0) row = (long long)(m / g.rows_per_group) * g.group_stride + m % g.rows_per_group + g.row_offset + qkv_row_dev;
-                    *reinterpret_cast<uint4*>(qkv_base + row * g.ldc + (wcol0 + cg - qkv_part_local * g.qkv_D)) = pk;
+                    const long long eoff = row * g.ldc + (wcol0 + cg - qkv_part_local * g.qkv_D);      // elements from the (wave-uniform) base of this part
+                    // WRITE-THROUGH (sc1): a launch whose output stays dirty in L2 ends with the write-back of all of it at once; the attention kernel that reads
+                    // these rows runs on other CUs anyway (round 6 A/B, same box, AR pass at 640 rows: qkv 22.6 -> 22.1 ms per pass; fp32 rows, slabs and residual
+                    // rows gained nothing and keep plain stores: profiles/r06_tile_write_through_ab.txt)
+                    if (eoff < (1ll << 30)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk), rs_qkv, (unsigned)(eoff * 2), 0, 16);
+                    else *reinterpret_cast<uint4*>(qkv_base + eoff) = pk;
                 } else {
                     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(g.C) + (long long)m * g.ldc + wcol0 + cg) = pk;
                 }

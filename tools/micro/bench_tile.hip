@@ -64,6 +64,9 @@ typedef TileGeom<2, 4, 4, 2, 2, 4> Tile256k3;     // 256 x 256, 4 stages of 32 k
 typedef TileGeom<4, 2, 2, 2, 2, 4> Tile256x128k4; // 256 x 128, 4 stages of 32 k
 typedef TileGeom<2, 2, 2, 2, 4, 2> Tile128k4;     // 128 x 128, 2 stages of 64 k
 typedef TileGeom<2, 2, 2, 2, 2, 4> Tile128s3;     // 128 x 128, 4 stages of 32 k: two workgroups per CU
+typedef TileGeom<2, 2, 2, 2, 4, 3, 4> Tile128PCk4;   // loader-wave geometry with 3 stages of 64 k (96 KiB ring, one workgroup per CU)
+typedef TileGeom<2, 2, 2, 2, 2, 6, 4> Tile128PCs6;   // ... with 6 stages of 32 k (96 KiB ring)
+typedef TileGeom<2, 2, 2, 2, 2, 4, 2> Tile128PC2;    // ... with two loader waves
 
 struct Bufs {
     bf16_t *x_rows, *xpk, *cpk, *respk;
@@ -247,6 +250,7 @@ int main(int argc, char** argv) {
 #define T(G, what) report(what, time_us(st, nbuf, [&](int i) { launch_raw<G, TS_ROWS, false, float>(g, w[i], 1, nullptr, st); }));
             T(Tile256, "256x256 k64 x2, fp32 rows") T(Tile256k3, "256x256 k32 x4 , fp32 rows") T(Tile128, "128x128 k32 x3 (3/CU), fp32 rows") T(Tile128k4, "128x128 k64 x2, fp32 rows")
             T(Tile128PC, "128x128 k32 x4 + 4 loader waves, fp32 rows")
+            T(Tile128PCk4, "128x128 k64 x3 + 4 loader waves, fp32 rows") T(Tile128PCs6, "128x128 k32 x6 + 4 loader waves, fp32 rows") T(Tile128PC2, "128x128 k32 x4 + 2 loader waves, fp32 rows")
             T(Tile256x128, "256x128 k64 x3, fp32 rows") T(Tile256x128k4, "256x128 k32 x4 , fp32 rows") T(Tile128s3, "128x128 k32 x3 (k32 x4: 2/CU), fp32 rows")
 #undef T
             if (M == 640 || M == 1280 || M == 2560) {
@@ -281,6 +285,9 @@ int main(int argc, char** argv) {
                 stamps("128x128 k32 x3 rows (k32 x4: 2/CU)", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128s3, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 k32 x3 packed bf16", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 PC rows", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128PC, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
+                stamps("128x128 PC k64 x3 rows", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128PCk4, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
+                stamps("128x128 PC k32 x6 rows", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128PCs6, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
+                stamps("128x128 PC 2 loaders rows", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { launch_raw<Tile128PC2, TS_ROWS, false, float>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 PC packed bf16", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128PC, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 k32 x3 packed bf16 (k32 x4: 2/CU)", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128s3, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
             }
