@@ -446,7 +446,7 @@ def main():
         merge = 1                                  # debug runs (counter collection) sample a few positions of one pass
     rem = args.steps % merge                       # K need not be a multiple: the last pass of the timed region then holds `rem` steps
     ar_priority = bool(args.ar_priority) if args.ar_priority is not None else (DEFAULT_AR_PRIORITY and inflight > 1)
-    pipe = InflightSampler(model, lanes=inflight, device=dev, merge=merge, ar_high_priority=ar_priority, serial_ar=bool(os.environ.get('HQT_BENCH_SERIAL_AR')))
+    pipe = InflightSampler(model, lanes=inflight, device=dev, merge=merge, ar_high_priority=ar_priority)
 
     def after(ct, cb, px):
         gather_step(ct, px)

@@ -53,7 +53,7 @@ class Pending:
 
 class InflightSampler:
     def __init__(self, model, lanes: int = 3, device: Optional[torch.device] = None, merge: int = 1, record_phases: bool = False,
-                 ar_high_priority: bool = False, serial_ar: bool = False):
+                 ar_high_priority: bool = False):
         if lanes < 1 or merge < 1:
             raise ValueError('lanes and merge must be >= 1')
         self.model = model
@@ -74,10 +74,6 @@ class InflightSampler:
                 hi = torch.cuda.Stream.priority_range()[1]
             self.ar_streams = [torch.cuda.Stream(device=self.device, priority=hi) for _ in range(self.n)]
         self.k = 0
-        # serial_ar: the AR loops of different lanes never run beside each other -- a lane's AR pass starts when the previous lane's has ended, so what
-        # overlaps is one lane's decode with the next lane's AR loop (the default lets two AR passes that were submitted together share the chip first)
-        self.serial_ar = bool(serial_ar)
-        self._ar_done: Optional[torch.cuda.Event] = None
 
     def submit(self, num_candidates: int, cond, *, seed: Optional[int] = None, max_seq_len: int = 64, use_fp16: bool = True,
                decode: bool = True, precision: Optional[str] = None, clamp01: bool = True, use_graph: bool = True,
@@ -171,8 +167,6 @@ class InflightSampler:
         three = getattr(self.model.stage2.spec, 'levels', 2) == 3
         if ast is not st:
             ast.wait_stream(st)                      # the lane stays one in-order sequence: AR of this pass behind the lane's previous decode
-        if self.serial_ar and self._ar_done is not None and self.n > 1:
-            ast.wait_event(self._ar_done)
         with torch.cuda.stream(ast):
             if phase_events is not None:
                 phase_events[0].record(ast)
@@ -185,9 +179,6 @@ class InflightSampler:
                                          use_fp16=use_fp16, is_tqdm=False, use_graph=use_graph, lane=lane, precision=ar_precision, **sample_kw)
             if phase_events is not None:
                 phase_events[1].record(ast)
-            if self.serial_ar:
-                self._ar_done = torch.cuda.Event()
-                self._ar_done.record(ast)
         if ast is not st:
             st.wait_stream(ast)
             for t in (ct, *(cb if isinstance(cb, (list, tuple)) else (cb,))):
