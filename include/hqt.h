@@ -93,8 +93,8 @@ typedef struct {
      * 'parallel-add-reduce') cannot sample three levels there either. */
     int32_t depth_decoding;
     /* Which derived layouts of the AR loop's nn.Linear weights hqt_finalize_weights builds (bit mask of HQT_LAYOUT_*; 0 = all of them,
-     * what ABI <= 6 always did: 9.1 GB for the 2.1 GB ImageNet-12L model).  The fp32 tensors as received are always kept: they are
-     * what EXACT computes from.  A replica that only ever samples in FAST precision passes HQT_LAYOUT_FAST (5.2 GB); a hqt_sample /
+     * what ABI <= 6 always did: 9.6 GiB measured for the 2.1 GB ImageNet-12L model and its batch-64 workspace).  The fp32 tensors as received are always kept: they are
+     * what EXACT computes from.  A replica that only ever samples in FAST precision passes HQT_LAYOUT_FAST (5.95 GiB measured); a hqt_sample /
      * hqt_sample_l3 call in a precision whose layout the handle was built without fails with HQT_ERR_STATE (EXACT without
      * HQT_LAYOUT_EXACT still runs, on the row-major fp32 weights: same results, slower below 257 rows).  Stage 1 is not affected. */
     int32_t ar_layouts;
