@@ -120,6 +120,7 @@ def test_round4_records_of_the_committed_driver_line():
     doc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
     want = doc.get('by_rows', {}).get(str(gemm['rows_per_pass']), {}).get('stream_gemm')
     # attached only from a counter pass at these rows: None when the line predates the pass; otherwise the committed pass of its own
-    # evidence run or the one before it (the line reads the file committed when it ran) -- the same kernels, within a few per cent
-    assert gemm['traffic'] is None or (want is not None and abs(gemm['traffic'] - want) / want < 0.05)
+    # evidence run or the one before it (the line reads the file committed when it ran) -- the same family, within ten per cent (round 6 changed
+    # the 640-row tile geometry: 59.1 -> 55.7 MB per launch)
+    assert gemm['traffic'] is None or (want is not None and abs(gemm['traffic'] - want) / want < 0.10)
     assert d['cpu_baseline']['kind'] == 'native-port' and d['cpu_baseline']['cores'] >= 1
