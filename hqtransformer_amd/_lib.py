@@ -19,7 +19,7 @@ ABI_VERSION = 7
 PRECISION_EXACT, PRECISION_FAST, PRECISION_SPLIT = 0, 1, 2
 PRECISIONS = {'exact': PRECISION_EXACT, 'fast': PRECISION_FAST, 'split': PRECISION_SPLIT}
 POLICY_LATENCY, POLICY_THROUGHPUT = 0, 1
-SWITCH_PERSIST, SWITCH_SINGLE_KEY, SWITCH_PERSIST_FAULT = 0, 1, 2
+SWITCH_PERSIST, SWITCH_SINGLE_KEY, SWITCH_PERSIST_FAULT, SWITCH_SPLIT_KSLICES = 0, 1, 2, 3
 LAYOUT_FAST, LAYOUT_EXACT, LAYOUT_SPLIT, LAYOUT_ALL = 1, 2, 4, 7
 
 

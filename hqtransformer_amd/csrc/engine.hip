@@ -182,6 +182,7 @@ struct hqt_handle {
     bool persist_enabled = true;              // HQT_SWITCH_PERSIST (default: on unless HQT_PERSIST=0 was in the environment at hqt_create)
     bool persist_tripped = false;             // a persistent launch of this handle gave up (hqt_range_check): the launch chain until HQT_SWITCH_PERSIST re-arms it
     bool single_key = true;                   // HQT_SWITCH_SINGLE_KEY (default: on unless HQT_NO_SINGLE_KEY was in the environment at hqt_create)
+    bool split_kslices = true;                // HQT_SWITCH_SPLIT_KSLICES (default: on unless HQT_SPLIT_KSLICES_OFF was in the environment at hqt_create)
     bool capture_persist = false;             // run_persist ran since sample_run cleared it (is a persistent launch inside the graph being captured?)
     bool graph_has_persist = false;           // the cached graph holds persistent launches: every replay marks persist_used
     int layouts = 0;                          // HQT_LAYOUT_* bits hqt_finalize_weights builds for the AR loop's nn.Linear weights
@@ -365,6 +366,7 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
     h->tile_gemm = getenv("HQT_NO_TILE_GEMM") == nullptr;
     { const char* e = getenv("HQT_PERSIST"); h->persist_enabled = !(e && atoi(e) == 0); }
     h->single_key = getenv("HQT_NO_SINGLE_KEY") == nullptr;
+    h->split_kslices = getenv("HQT_SPLIT_KSLICES_OFF") == nullptr;
     h->cfg = *cfg;
     h->layouts = (cfg->ar_layouts & HQT_LAYOUT_ALL) ? (cfg->ar_layouts & HQT_LAYOUT_ALL) : HQT_LAYOUT_ALL;
     h->device = device;
@@ -984,8 +986,7 @@ static int run_linear(hqt_handle* h, const Mode& md, GemmArgs g, const Lin& l, i
         sg.a_f32 = 1; sg.Bw = l.w16h; sg.Bw_lo = l.w16l; sg.range_flag = h->range_flag;
         if (split_gemm_ok(sg)) {
             // few tiles (fc2 / proj at 640 rows: 60): K slices into the split-K workspace, summed in index order by the combine launch
-            static const bool no_slices = getenv("HQT_SPLIT_KSLICES_OFF") != nullptr;
-            const int S = no_slices ? 1 : split_gemm_slices(sg);
+            const int S = h->split_kslices ? split_gemm_slices(sg) : 1;
             if (S > 1 && (size_t)S * sg.M * sg.N <= h->splitk_elems) { sg.k_slices = S; sg.k_slabs = h->splitk; }
             HIPCHK(launch_split_gemm(sg, st));
             if (sg.k_slices > 1) count_variant(h, "variant:split_gemm_kslices%d:%s", sg.k_slices, tag);
@@ -1684,7 +1685,7 @@ static int sample_run(hqt_handle* h, const SampleCtx& c) {
                                      (uint64_t)logits_out, (uint64_t)opts->precision,
                                      (uint64_t)opts->n_steps, (uint64_t)opts->top_k_top, (uint64_t)opts->top_k_bot,
                                      (uint64_t)c.levels, (uint64_t)c.feed_l2, (uint64_t)c.top_k[2], (uint64_t)h->policy,
-                                     (uint64_t)((h->persist_enabled && !h->persist_tripped ? 1 : 0) + (h->single_key ? 0 : 4))};
+                                     (uint64_t)((h->persist_enabled && !h->persist_tripped ? 1 : 0) + (h->single_key ? 0 : 4) + (h->split_kslices ? 0 : 8))};
         { uint32_t f3[2]; memcpy(f3, &c.top_p[2], 4); memcpy(f3 + 1, &c.temperature[2], 4); key.push_back(f3[0]); key.push_back(f3[1]); }
         uint32_t f[4];
         memcpy(f, &opts->top_p_top, 4); memcpy(f + 1, &opts->top_p_bot, 4);
@@ -2127,6 +2128,7 @@ extern "C" int hqt_set_switch(hqt_handle* h, int which, int on) {
     if (!h) return fail(HQT_ERR_INVALID, "null handle");
     if (which == HQT_SWITCH_PERSIST) { h->persist_enabled = on != 0; if (on) h->persist_tripped = false; }
     else if (which == HQT_SWITCH_SINGLE_KEY) h->single_key = on != 0;
+    else if (which == HQT_SWITCH_SPLIT_KSLICES) h->split_kslices = on != 0;
     else if (which == HQT_SWITCH_PERSIST_FAULT) {        // test hook: a device word next to the give-up mark (persist.h: err[1]); NOT part of the graph key -- a cached graph replays it
         if (!h->persist_err) return fail(HQT_ERR_STATE, "no persistent chain on this handle (a lane, or a handle without stage 2)");
         ON_DEVICE(h);

@@ -112,6 +112,10 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.hqt_set_switch(self.h, _lib.SWITCH_PERSIST_FAULT, int(cu_plus_one)))
 
+    def set_split_kslices(self, on: bool) -> None:
+        """``hqt_set_switch(HQT_SWITCH_SPLIT_KSLICES)``: False = the SPLIT AR GEMMs are never K-sliced (one fp32 summation order at every row count)."""
+        _lib.check(self.lib.hqt_set_switch(self.h, _lib.SWITCH_SPLIT_KSLICES, int(bool(on))))
+
     def set_single_key(self, on: bool) -> None:
         """``hqt_set_switch(HQT_SWITCH_SINGLE_KEY)``: False = depth sub-step 0 the long way round (A/B runs and tests; bit-identical results)."""
         _lib.check(self.lib.hqt_set_switch(self.h, _lib.SWITCH_SINGLE_KEY, int(bool(on))))

@@ -168,10 +168,13 @@ int hqt_set_policy(hqt_handle* h, int policy);
  *                          (hqt_range_check) switches itself to 0; setting 1 re-arms it.
  *   HQT_SWITCH_SINGLE_KEY  1 (default): depth sub-step 0 (one query over one key) skips the query third of the fused GEMM and the
  *                          attention launch, bit-identically; 0: the long way round (default 0 when HQT_NO_SINGLE_KEY was set at hqt_create). */
-/*   HQT_SWITCH_PERSIST_FAULT  test hook (0 = none, the default): on = c + 1 makes compute unit c withhold its first grid-barrier signal in every
+/*   HQT_SWITCH_SPLIT_KSLICES  1 (default): SPLIT-precision hqt_sample cuts K of the narrow GEMMs (proj / fc2) of passes up to 1024 rows into slices summed in index order
+ *                          (deterministic; the fp32 summation order, hence the last bits of a logit, then depends on the row count of the pass); 0: one order at every
+ *                          row count (default 0 when HQT_SPLIT_KSLICES_OFF was set at hqt_create).
+ *   HQT_SWITCH_PERSIST_FAULT  test hook (0 = none, the default): on = c + 1 makes compute unit c withhold its first grid-barrier signal in every
  *                          later persistent launch, so the launch gives up after its time limit (tests/test_gpu_persist.py).  A device word, not
  *                          part of the graph key: a cached graph replays it.  Synchronises the device. */
-enum { HQT_SWITCH_PERSIST = 0, HQT_SWITCH_SINGLE_KEY = 1, HQT_SWITCH_PERSIST_FAULT = 2 };
+enum { HQT_SWITCH_PERSIST = 0, HQT_SWITCH_SINGLE_KEY = 1, HQT_SWITCH_PERSIST_FAULT = 2, HQT_SWITCH_SPLIT_KSLICES = 3 };
 int hqt_set_switch(hqt_handle* h, int which, int on);
 
 /* hqt_sample -- replaces sampling_ihqgpt + iHQGPT.sampling_step (hqvae/utils/sampling.py:164-237,

@@ -122,6 +122,23 @@ def test_imagenet_merged_pass_split_trained_scale():
     gate('trained.imagenet_rows320.split_logits_vs_exact', (ls - le).abs().max().item(), LOGIT_TOL)     # measured 4.3e-5
     agree = ((st == ct).float().mean().item() + (sb == cb).float().mean().item()) / 2
     gate('trained.imagenet_rows320.split_code_agreement', agree, 0.999, '>=')
+    # the same pass with the K slices of proj / fc2 switched off (hqt_set_switch(HQT_SWITCH_SPLIT_KSLICES, 0)): another fp32 summation order of the
+    # same sums -- on realistic activations the two orders stay within 1e-4 of each other and of EXACT, and draw the same codes (the
+    # schedule dependence of SPLIT logits, measured at trained scale and not only on the tiny model)
+    eng.timing(True); eng.timing_reset()
+    eng.sample(B, cond, 1, precision=PRECISION_SPLIT, noise=noise[:1], use_graph=False)
+    rep = eng.timing_report(); eng.timing(False)
+    assert any(k.startswith('variant:split_gemm_kslices') and v[0] > 0 for k, v in rep.items()), 'this pass runs no K-sliced SPLIT GEMM'
+    eng.set_split_kslices(False)
+    try:
+        ut, ub, lu = eng.sample(B, cond, n, precision=PRECISION_SPLIT, noise=noise, force_top=ct, force_bot=cb, return_logits=True, use_graph=False)
+    finally:
+        eng.set_split_kslices(True)
+    eng.range_check()
+    gate('trained.imagenet_rows320.split_unsliced_logits_vs_exact', (lu - le).abs().max().item(), LOGIT_TOL)
+    gate('trained.imagenet_rows320.split_sliced_vs_unsliced_logits', (lu - ls).abs().max().item(), 1e-4)
+    same = ((ut == st).float().mean().item() + (ub == sb).float().mean().item()) / 2
+    gate('trained.imagenet_rows320.sliced_vs_unsliced_code_agreement', same, 0.999, '>=')
 
 
 def test_imagenet_decoder_trained_scale_vs_oracle():
