@@ -291,6 +291,37 @@ int main(int argc, char** argv) {
                 stamps("128x128 PC packed bf16", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128PC, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
                 stamps("128x128 k32 x3 packed bf16 (k32 x4: 2/CU)", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128s3, TS_PACKED, false, bf16_t>(gs, w[0], 1, nullptr, st); });
             }
+            // ---- what lies BETWEEN two dependent launches: wall clock of the first workgroup start / last workgroup end of 8 launches queued back to back (one graph)
+            if (M == 640 && (sh.N == 6144 || sh.N == 4608)) {
+                const int NL = 8;
+                auto gaps = [&](const char* what, int wgs, const std::function<void(GemmArgs&, int)>& run) {
+                    CK(hipMemsetAsync(dbg, 0, (size_t)NL * wgs * 64, st));
+                    hipGraph_t graph; hipGraphExec_t ge;
+                    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                    for (int i = 0; i < NL; ++i) { GemmArgs gs = g; gs.am_best = reinterpret_cast<unsigned long long*>(dbg + (size_t)i * wgs * 8); run(gs, i); }
+                    CK(hipStreamEndCapture(st, &graph)); CK(hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+                    CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+                    CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+                    std::vector<long long> h((size_t)NL * wgs * 8);
+                    CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+                    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(graph));
+                    printf("   between launches %-34s", what);
+                    double span_sum = 0, gap_sum = 0;
+                    long long prev_end = 0;
+                    for (int i = 0; i < NL; ++i) {
+                        long long t0 = LLONG_MAX, t1 = 0;
+                        for (int b2 = 0; b2 < wgs; ++b2) { t0 = std::min(t0, h[((size_t)i * wgs + b2) * 8]); t1 = std::max(t1, h[((size_t)i * wgs + b2) * 8 + 4]); }
+                        if (i) { gap_sum += (t0 - prev_end) / 100.0; }
+                        span_sum += (t1 - t0) / 100.0;
+                        prev_end = t1;
+                    }
+                    printf(" grid span %.2f us, last end -> next first start %.2f us (mean of %d)\n", span_sum / NL, gap_sum / (NL - 1), NL - 1);
+                };
+                GemmArgs gq = g; gq.C = b.cpk; gq.store = STORE_PACKED; gq.c_packed_mb = MB;
+                gaps("128x128 PC packed bf16", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs, int i) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile128PC, TS_PACKED, false, bf16_t>(gs, w[i], 1, nullptr, st); });
+                gaps("128x128 PC fp32 rows", ((M + 127) / 128) * (sh.N / 128), [&](GemmArgs& gs, int i) { launch_raw<Tile128PC, TS_ROWS, false, float>(gs, w[i], 1, nullptr, st); });
+                gaps("64x128 W8 packed bf16", ((M + 63) / 64) * (sh.N / 128), [&](GemmArgs& gs, int i) { gs.C = b.cpk; gs.store = STORE_PACKED; gs.c_packed_mb = MB; launch_raw<Tile64W8, TS_PACKED, false, bf16_t>(gs, w[i], 1, nullptr, st); });
+            }
             // the store modes the AR loop uses, default geometries
             GemmArgs gd = g;
             gd.ln_parts = b.parts; gd.ln_nparts = 6; gd.ln_colsum = b.colsum; gd.ln_eps = 1e-5f; gd.bias = b.bias;
@@ -300,6 +331,9 @@ int main(int argc, char** argv) {
                 report("128x128 DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile128, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
                 report("128x128 PC DLN + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile128PC, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
                 report("64x128 W8 DLN + GELU + packed bf16 (product@640)", time_us(st, nbuf, [&](int i) { launch_raw<Tile64W8, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
+                // the same launches with the weights cycling through 6 buffers only (<= 113 MB: they stay in the 256-MiB Infinity Cache) -- what a launch would cost if its weights were already there
+                report("128x128 PC DLN + GELU + packed, weights in the Infinity Cache", time_us(st, nbuf, [&](int i) { launch_raw<Tile128PC, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i % 6], 1, nullptr, st); }));
+                report("128x128 DLN + GELU + packed, weights in the Infinity Cache", time_us(st, nbuf, [&](int i) { launch_raw<Tile128, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i % 6], 1, nullptr, st); }));
                 gp.ln_nparts = 1;
                 report("256x256 DLN(1 part) + GELU + packed bf16", time_us(st, nbuf, [&](int i) { launch_raw<Tile256, TS_PACKED, true, bf16_t, ACT_GELU_ERF>(gp, w[i], 1, nullptr, st); }));
             } else {
