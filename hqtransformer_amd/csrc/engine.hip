@@ -362,7 +362,7 @@ extern "C" int hqt_create(const hqt_config* cfg, int device, hqt_handle** out) {
     DeviceGuard dg(device);
     if (!dg.ok) return fail(HQT_ERR_HIP, "hipSetDevice(%d) failed", device);
     std::unique_ptr<hqt_handle> h(new hqt_handle());
-    // every environment switch of the per-call path is read HERE, once per handle (hqt_set_switch changes two of them afterwards)
+    // every environment switch of the per-call path is read HERE, once per handle (hqt_set_switch changes them afterwards)
     h->tile_gemm = getenv("HQT_NO_TILE_GEMM") == nullptr;
     { const char* e = getenv("HQT_PERSIST"); h->persist_enabled = !(e && atoi(e) == 0); }
     h->single_key = getenv("HQT_NO_SINGLE_KEY") == nullptr;
